@@ -1,0 +1,104 @@
+// common.h -- shared helpers for librgm_hip (gfx950 only; no CUDA/HIP dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include "../../include/rgm.h"
+
+namespace rgm {
+
+void set_error(const char* fmt, ...);
+
+#define RGM_CHECK_HIP(expr)                                                              \
+  do {                                                                                   \
+    hipError_t _e = (expr);                                                              \
+    if (_e != hipSuccess) {                                                              \
+      rgm::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return RGM_ERR_HIP;                                                                \
+    }                                                                                    \
+  } while (0)
+
+#define RGM_REQUIRE(cond, ...)                   \
+  do {                                           \
+    if (!(cond)) {                               \
+      rgm::set_error(__VA_ARGS__);               \
+      return RGM_ERR_INVALID;                    \
+    }                                            \
+  } while (0)
+
+#define RGM_LAUNCH_CHECK()                                                     \
+  do {                                                                         \
+    hipError_t _e = hipGetLastError();                                         \
+    if (_e != hipSuccess) {                                                    \
+      rgm::set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return RGM_ERR_HIP;                                                      \
+    }                                                                          \
+  } while (0)
+
+#define RGM_TRY(expr)          \
+  do {                         \
+    int _s = (expr);           \
+    if (_s != RGM_OK) return _s; \
+  } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float c = 0.7978845608028654f;  // sqrt(2/pi)
+  return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// GEMM  C = epi(alpha * A . B^T): see gemm.hip
+// ---------------------------------------------------------------------------------------------
+struct GemmParams {
+  const float* A = nullptr;
+  const float* B = nullptr;
+  float* C = nullptr;
+  int M = 0, N = 0, K = 0;
+  int lda = 0, ldb = 0, ldc = 0;
+  long long sA = 0, sB = 0, sC = 0;  // batch strides in elements (blockIdx.z)
+  int batch = 1;
+  // epilogue
+  const float* bias = nullptr;   // [N]
+  long long sBias = 0;
+  int act = 0;                   // 0 none, 1 silu, 2 gelu(tanh)
+  float alpha = 1.0f;
+  const float* gate = nullptr;   // gate[(row / rows_per_gate) * gate_ld + col]
+  int gate_ld = 0, rows_per_gate = 1;
+  const float* res = nullptr;    // res[row * ldres + col] (+ batch * sRes); may alias C
+  int ldres = 0;
+  long long sRes = 0;
+  // implicit-GEMM 3x3 conv A operand (aload == 1): A is NHWC [img][Hin][Win][Cin], M = imgs*H*W
+  int aload = 0;
+  int H = 0, W = 0, Cin = 0, logH = 0, logW = 0, ups = 0;
+  // tile override for experiments: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
+  int tile = 0;
+};
+int gemm_launch(const GemmParams& p, hipStream_t stream);
+
+// elementwise / reductions (elementwise.hip)
+int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,
+                              const float* bias, const float* shift, const float* scale, int mod_ld,
+                              int rows_per_batch, hipStream_t s);
+int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N,
+                            int T, int heads, int hd, int rot_half, hipStream_t s);
+
+}  // namespace rgm

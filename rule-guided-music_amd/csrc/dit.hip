@@ -1,0 +1,371 @@
+// dit.hip -- DiTRotary eps-network and DiTRotaryClassifier: weight arena + forward schedule.
+//
+// Reference: guided_diffusion/dit.py:538-634 (DiTRotary), :735-831 (DiTRotaryClassifier),
+// :315-336 (DiTBlockRotary), :359-376 (FinalLayerPatch1D), :33-70 (TimestepEmbedder), :73-100 (LabelEmbedder).
+// The host side here only sequences kernels on the caller's stream; all arithmetic lives in
+// gemm.hip / attention.hip / dit_kernels.hip.
+//
+// HBM layout
+//   * weights: ONE arena, fp32, nn.Linear layout [out][in] (K-contiguous = the GEMM's B^T operand
+//     as-is).  The adaLN projections of all blocks (+ the final layer's) are placed back to back, so
+//     the conditioning of the whole network is ONE skinny GEMM  mod[N, (6*depth+2)*D] = SiLU(c) . W^T
+//     per forward instead of depth+1 launches that each re-stream their weights for 16 rows;
+//   * activations: caller workspace; residual stream x[N*T, D] is updated in place by the gated
+//     epilogues of proj / fc2, xm / qkv / attn / hidden are scratch strips reused by every block.
+#include <map>
+#include <string>
+#include <vector>
+#include <math.h>
+#include "common.h"
+
+namespace rgm {
+int patchify_launch(const float* x, float* tok, int N, int C, int H, int W, int P, hipStream_t s);
+int unpatchify_launch(const float* tok, float* out, int N, int OC, int H, int W, hipStream_t s);
+int timestep_sincos_launch(const int64_t* t, const float* freqs, float* emb, int N, int half, hipStream_t s);
+int cond_finish_launch(const float* c, const float* table, const int32_t* y, float* cs, int N, int D, hipStream_t s);
+int fill_cls_launch(const float* cls, float* x, int N, int T, int D, hipStream_t s);
+int pool_rows_launch(const float* x, float* out, int N, int T, int D, int first, int groups, int per, hipStream_t s);
+}  // namespace rgm
+
+using namespace rgm;
+
+struct Slot {
+  size_t off = 0;     // floats from arena base
+  size_t numel = 0;
+  bool set = false;
+};
+
+struct rgm_dit {
+  rgm_dit_cfg cfg{};
+  int device = 0;
+  std::map<std::string, Slot> slots;
+  float* arena = nullptr;
+  size_t arena_floats = 0;
+  float* tfreqs = nullptr;   // [128] timestep frequencies
+  float* cos_tab = nullptr;  // [max_tokens][rot_half]
+  float* sin_tab = nullptr;
+  bool rotary_ready = false;
+  int rot_half = 0, hd = 0;
+  size_t ada_rows = 0;       // (6*depth + 2 or 0) * D
+
+  const float* p(const std::string& k) const { return arena + slots.at(k).off; }
+};
+
+static void add_slot(rgm_dit* h, const std::string& key, size_t numel) {
+  Slot s;
+  s.off = h->arena_floats;
+  s.numel = numel;
+  h->slots[key] = s;
+  h->arena_floats += (numel + 3) / 4 * 4;  // keep every tensor 16-byte aligned
+}
+
+extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
+  RGM_REQUIRE(c && out, "dit_create: null argument");
+  RGM_REQUIRE(c->hidden % c->heads == 0 && c->hidden % 32 == 0, "dit_create: hidden=%d heads=%d", c->hidden, c->heads);
+  const int hd = c->hidden / c->heads;
+  RGM_REQUIRE(hd == 64 || hd == 72, "dit_create: head_dim %d (64 or 72 supported)", hd);
+  RGM_REQUIRE((c->in_ch * c->patch) % 32 == 0, "dit_create: in_ch*patch=%d must be a multiple of 32", c->in_ch * c->patch);
+  RGM_REQUIRE(c->kind >= 0 && c->kind <= 2, "dit_create: kind %d", c->kind);
+  RGM_REQUIRE(c->max_tokens > 0 && c->max_tokens <= 288, "dit_create: max_tokens %d", c->max_tokens);
+  rgm_dit* h = new rgm_dit();
+  h->cfg = *c;
+  h->hd = hd;
+  h->rot_half = (int)(hd * 0.5) / 2;  // rotary_dim = int(head_dim * 0.5), dit.py:571
+  RGM_CHECK_HIP(hipGetDevice(&h->device));
+  const size_t D = c->hidden;
+  const int pc = c->in_ch * c->patch;
+  if (c->kind != 0) add_slot(h, "cls_token", D);
+  add_slot(h, "x_embedder.MLP.0.weight", 256 * (size_t)pc);
+  add_slot(h, "x_embedder.MLP.0.bias", 256);
+  add_slot(h, "x_embedder.MLP.2.weight", D * 256);
+  add_slot(h, "x_embedder.MLP.2.bias", D);
+  add_slot(h, "t_embedder.mlp.0.weight", D * 256);
+  add_slot(h, "t_embedder.mlp.0.bias", D);
+  add_slot(h, "t_embedder.mlp.2.weight", D * D);
+  add_slot(h, "t_embedder.mlp.2.bias", D);
+  if (c->kind == 0 && c->n_embed > 0) add_slot(h, "y_embedder.embedding_table.weight", (size_t)c->n_embed * D);
+  add_slot(h, "rotary_emb.freqs", h->rot_half);
+  // adaLN projections, contiguous across blocks (+ final layer) -> one GEMM
+  for (int i = 0; i < c->depth; ++i) add_slot(h, "blocks." + std::to_string(i) + ".adaLN_modulation.1.weight", 6 * D * D);
+  if (c->kind == 0) add_slot(h, "final_layer.adaLN_modulation.1.weight", 2 * D * D);
+  for (int i = 0; i < c->depth; ++i) add_slot(h, "blocks." + std::to_string(i) + ".adaLN_modulation.1.bias", 6 * D);
+  if (c->kind == 0) add_slot(h, "final_layer.adaLN_modulation.1.bias", 2 * D);
+  h->ada_rows = (size_t)(6 * c->depth + (c->kind == 0 ? 2 : 0)) * D;
+  for (int i = 0; i < c->depth; ++i) {
+    const std::string b = "blocks." + std::to_string(i) + ".";
+    add_slot(h, b + "attn.qkv.weight", 3 * D * D);
+    add_slot(h, b + "attn.qkv.bias", 3 * D);
+    add_slot(h, b + "attn.proj.weight", D * D);
+    add_slot(h, b + "attn.proj.bias", D);
+    add_slot(h, b + "mlp.fc1.weight", 4 * D * D);
+    add_slot(h, b + "mlp.fc1.bias", 4 * D);
+    add_slot(h, b + "mlp.fc2.weight", 4 * D * D);
+    add_slot(h, b + "mlp.fc2.bias", D);
+  }
+  if (c->kind == 0) {
+    add_slot(h, "final_layer.linear.weight", (size_t)c->patch * c->out_ch * D);
+    add_slot(h, "final_layer.linear.bias", (size_t)c->patch * c->out_ch);
+  } else {
+    add_slot(h, "norm.weight", D);
+    add_slot(h, "norm.bias", D);
+    add_slot(h, "classifier_head.0.weight", D / 4 * D);
+    add_slot(h, "classifier_head.0.bias", D / 4);
+    add_slot(h, "classifier_head.2.weight", (size_t)c->n_out * (D / 4));
+    add_slot(h, "classifier_head.2.bias", c->n_out);
+    if (c->kind == 2) {
+      add_slot(h, "norm_key.weight", D);
+      add_slot(h, "norm_key.bias", D);
+      add_slot(h, "classifier_head_key.0.weight", D / 4 * D);
+      add_slot(h, "classifier_head_key.0.bias", D / 4);
+      add_slot(h, "classifier_head_key.2.weight", 25 * (D / 4));
+      add_slot(h, "classifier_head_key.2.bias", 25);
+    }
+  }
+  RGM_CHECK_HIP(hipMalloc(&h->arena, h->arena_floats * sizeof(float)));
+  RGM_CHECK_HIP(hipMemset(h->arena, 0, h->arena_floats * sizeof(float)));
+  // timestep frequencies, float32 op order of dit.py:59-61
+  float tf[128];
+  const float a = (float)(-log(10000.0));
+  for (int k = 0; k < 128; ++k) tf[k] = expf((a * (float)k) / 128.0f);
+  RGM_CHECK_HIP(hipMalloc(&h->tfreqs, sizeof(tf)));
+  RGM_CHECK_HIP(hipMemcpy(h->tfreqs, tf, sizeof(tf), hipMemcpyHostToDevice));
+  const size_t tab = (size_t)c->max_tokens * h->rot_half * sizeof(float);
+  RGM_CHECK_HIP(hipMalloc(&h->cos_tab, tab));
+  RGM_CHECK_HIP(hipMalloc(&h->sin_tab, tab));
+  *out = h;
+  return RGM_OK;
+}
+
+extern "C" void rgm_dit_destroy(rgm_dit* h) {
+  if (!h) return;
+  if (h->arena) (void)hipFree(h->arena);
+  if (h->tfreqs) (void)hipFree(h->tfreqs);
+  if (h->cos_tab) (void)hipFree(h->cos_tab);
+  if (h->sin_tab) (void)hipFree(h->sin_tab);
+  delete h;
+}
+
+extern "C" int rgm_dit_set_param(rgm_dit* h, const char* key, const void* dptr, const int64_t* shape, int ndim) {
+  RGM_REQUIRE(h && key && dptr, "dit_set_param: null argument");
+  std::string k(key);
+  // blocks.N.attn.rotary_emb.freqs alias the shared rotary_emb.freqs Parameter (dit.py:571-575)
+  const std::string suffix = "attn.rotary_emb.freqs";
+  if (k.size() > suffix.size() && k.compare(k.size() - suffix.size(), suffix.size(), suffix) == 0) k = "rotary_emb.freqs";
+  auto it = h->slots.find(k);
+  RGM_REQUIRE(it != h->slots.end(), "dit_set_param: unknown key '%s'", key);
+  size_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+  RGM_REQUIRE(numel == it->second.numel, "dit_set_param: '%s' has %zu elements, expected %zu", key, numel, it->second.numel);
+  RGM_CHECK_HIP(hipMemcpy(h->arena + it->second.off, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
+  it->second.set = true;
+  if (k == "rotary_emb.freqs") {
+    // rotary-embedding-torch 0.3.2: angle = pos * freq in float32, then cos / sin
+    std::vector<float> fr(h->rot_half), ct((size_t)h->cfg.max_tokens * h->rot_half), st(ct.size());
+    RGM_CHECK_HIP(hipMemcpy(fr.data(), dptr, fr.size() * sizeof(float), hipMemcpyDeviceToHost));
+    for (int t = 0; t < h->cfg.max_tokens; ++t)
+      for (int j = 0; j < h->rot_half; ++j) {
+        const float ang = (float)t * fr[j];
+        ct[(size_t)t * h->rot_half + j] = cosf(ang);
+        st[(size_t)t * h->rot_half + j] = sinf(ang);
+      }
+    RGM_CHECK_HIP(hipMemcpy(h->cos_tab, ct.data(), ct.size() * sizeof(float), hipMemcpyHostToDevice));
+    RGM_CHECK_HIP(hipMemcpy(h->sin_tab, st.data(), st.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->rotary_ready = true;
+  }
+  return RGM_OK;
+}
+
+extern "C" int rgm_dit_missing_params(rgm_dit* h) {
+  if (!h) return -1;
+  int n = 0;
+  for (auto& kv : h->slots) n += kv.second.set ? 0 : 1;
+  return n;
+}
+
+namespace {
+struct Ws {
+  char* base;
+  size_t off = 0, cap;
+  Ws(void* b, size_t c) : base((char*)b), cap(c) {}
+  float* take(size_t floats) {
+    float* p = (float*)(base + off);
+    off += align_up(floats * sizeof(float), 256);
+    return p;
+  }
+};
+
+struct Plan {
+  int N, H, T0, T, M0, M;
+  size_t L;
+  float *tok_in, *h1, *x, *xm, *qkv, *ao, *hid, *temb, *c1, *c, *cs, *mod, *tok_out, *pool, *pooln, *z1;
+  size_t bytes;
+};
+
+Plan make_plan(const rgm_dit* h, int N, int H, void* ws, size_t cap) {
+  const rgm_dit_cfg& c = h->cfg;
+  Plan p{};
+  p.N = N;
+  p.H = H;
+  p.T0 = H * c.width / c.patch;
+  p.T = p.T0 + (c.kind != 0 ? 1 : 0);
+  p.M0 = N * p.T0;
+  p.M = N * p.T;
+  p.L = h->ada_rows;
+  const size_t D = c.hidden;
+  Ws w(ws, cap);
+  p.tok_in = w.take((size_t)p.M0 * c.in_ch * c.patch);
+  p.h1 = w.take((size_t)p.M0 * 256);
+  p.x = w.take((size_t)p.M * D);
+  p.xm = w.take((size_t)p.M * D);
+  p.qkv = w.take((size_t)p.M * 3 * D);
+  p.ao = w.take((size_t)p.M * D);
+  p.hid = w.take((size_t)p.M * 4 * D);
+  p.temb = w.take((size_t)N * 256);
+  p.c1 = w.take((size_t)N * D);
+  p.c = w.take((size_t)N * D);
+  p.cs = w.take((size_t)N * D);
+  p.mod = w.take((size_t)N * p.L);
+  p.tok_out = w.take((size_t)p.M0 * c.patch * (c.kind == 0 ? c.out_ch : 1));
+  const size_t groups = 1 + (size_t)(H / c.width);
+  p.pool = w.take((size_t)N * groups * D);
+  p.pooln = w.take((size_t)N * groups * D);
+  p.z1 = w.take((size_t)N * groups * (D / 4));
+  p.bytes = w.off;
+  return p;
+}
+
+int lin(const float* A, int lda, const float* W, const float* bias, float* C, int ldc, int M, int N, int K, int act,
+        hipStream_t s) {
+  GemmParams g;
+  g.A = A; g.lda = lda; g.B = W; g.ldb = K; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act;
+  return gemm_launch(g, s);
+}
+
+int lin_gated(const float* A, int lda, const float* W, const float* bias, float* X, int M, int N, int K,
+              const float* gate, int gate_ld, int rows_per_gate, hipStream_t s) {
+  GemmParams g;
+  g.A = A; g.lda = lda; g.B = W; g.ldb = K; g.C = X; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.bias = bias;
+  g.gate = gate; g.gate_ld = gate_ld; g.rows_per_gate = rows_per_gate;
+  g.res = X; g.ldres = N;
+  return gemm_launch(g, s);
+}
+
+// embedders + blocks; leaves the residual stream in plan.x and SiLU(c) modulation in plan.mod
+int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, const int32_t* y, hipStream_t s) {
+  const rgm_dit_cfg& c = h->cfg;
+  const int D = c.hidden, pc = c.in_ch * c.patch, T = p.T, L = (int)p.L;
+  RGM_TRY(patchify_launch(x, p.tok_in, p.N, c.in_ch, p.H, c.width, c.patch, s));
+  RGM_TRY(lin(p.tok_in, pc, h->p("x_embedder.MLP.0.weight"), h->p("x_embedder.MLP.0.bias"), p.h1, 256, p.M0, 256, pc, 1, s));
+  if (c.kind == 0) {
+    RGM_TRY(lin(p.h1, 256, h->p("x_embedder.MLP.2.weight"), h->p("x_embedder.MLP.2.bias"), p.x, D, p.M0, D, 256, 0, s));
+  } else {  // rows 1..T0 of every sample; row 0 is the cls token (dit.py:813)
+    GemmParams g;
+    g.A = p.h1; g.lda = 256; g.sA = (long long)p.T0 * 256;
+    g.B = h->p("x_embedder.MLP.2.weight"); g.ldb = 256;
+    g.C = p.x + D; g.ldc = D; g.sC = (long long)T * D;
+    g.M = p.T0; g.N = D; g.K = 256; g.batch = p.N;
+    g.bias = h->p("x_embedder.MLP.2.bias");
+    RGM_TRY(gemm_launch(g, s));
+    RGM_TRY(fill_cls_launch(h->p("cls_token"), p.x, p.N, T, D, s));
+  }
+  RGM_TRY(timestep_sincos_launch(t, h->tfreqs, p.temb, p.N, 128, s));
+  RGM_TRY(lin(p.temb, 256, h->p("t_embedder.mlp.0.weight"), h->p("t_embedder.mlp.0.bias"), p.c1, D, p.N, D, 256, 1, s));
+  RGM_TRY(lin(p.c1, D, h->p("t_embedder.mlp.2.weight"), h->p("t_embedder.mlp.2.bias"), p.c, D, p.N, D, D, 0, s));
+  const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
+  RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, p.N, D, s));
+  RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, p.N, L, D, 0, s));
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = "blocks." + std::to_string(i) + ".";
+    const float* m = p.mod + (size_t)i * 6 * D;
+    RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
+    RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, p.M, 3 * D, D, 0, s));
+    RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s));
+    RGM_TRY(lin_gated(p.ao, D, h->p(b + "attn.proj.weight"), h->p(b + "attn.proj.bias"), p.x, p.M, D, D, m + 2 * D, L, T, s));
+    RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s));
+    RGM_TRY(lin(p.xm, D, h->p(b + "mlp.fc1.weight"), h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, p.M, 4 * D, D, 2, s));
+    RGM_TRY(lin_gated(p.hid, 4 * D, h->p(b + "mlp.fc2.weight"), h->p(b + "mlp.fc2.bias"), p.x, p.M, D, 4 * D, m + 5 * D, L, T, s));
+  }
+  return RGM_OK;
+}
+
+int check_ready(rgm_dit* h, int N, int H, size_t ws_bytes, const void* ws, Plan* plan) {
+  RGM_REQUIRE(h && N > 0 && H > 0, "dit: bad arguments");
+  const rgm_dit_cfg& c = h->cfg;
+  RGM_REQUIRE((H * c.width) % c.patch == 0, "dit: H*W=%d not divisible by patch", H * c.width);
+  const int T = H * c.width / c.patch + (c.kind != 0 ? 1 : 0);
+  RGM_REQUIRE(T <= c.max_tokens, "dit: %d tokens exceed max_tokens=%d given at create", T, c.max_tokens);
+  if (rgm_dit_missing_params(h) != 0 || !h->rotary_ready) {
+    std::string miss;
+    for (auto& kv : h->slots)
+      if (!kv.second.set && miss.size() < 200) miss += kv.first + " ";
+    set_error("dit: %d parameters not set: %s", rgm_dit_missing_params(h), miss.c_str());
+    return RGM_ERR_STATE;
+  }
+  *plan = make_plan(h, N, H, const_cast<void*>(ws), ws_bytes);
+  if (plan->bytes > ws_bytes || ws == nullptr) {
+    set_error("dit: workspace %zu bytes < required %zu", ws_bytes, plan->bytes);
+    return RGM_ERR_WORKSPACE;
+  }
+  RGM_REQUIRE(((uintptr_t)ws & 255) == 0, "dit: workspace must be 256-byte aligned");
+  return RGM_OK;
+}
+}  // namespace
+
+extern "C" size_t rgm_dit_workspace_bytes(const rgm_dit* h, int N, int H) {
+  if (!h || N <= 0 || H <= 0) return 0;
+  return make_plan(h, N, H, nullptr, 0).bytes;
+}
+
+extern "C" int rgm_dit_forward(rgm_dit* h, const float* x, const int64_t* t, const int32_t* y, float* eps, int N, int H,
+                               void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind == 0, "dit_forward: handle is not an eps-network");
+  RGM_REQUIRE(x && t && eps, "dit_forward: null tensor");
+  Plan p;
+  RGM_TRY(check_ready(h, N, H, ws_bytes, ws, &p));
+  hipStream_t s = (hipStream_t)stream;
+  const rgm_dit_cfg& c = h->cfg;
+  const int D = c.hidden, L = (int)p.L;
+  RGM_TRY(run_backbone(h, p, x, t, y, s));
+  const float* m = p.mod + (size_t)c.depth * 6 * D;
+  RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, p.T, s));
+  const int po = c.patch * c.out_ch;
+  RGM_TRY(lin(p.xm, D, h->p("final_layer.linear.weight"), h->p("final_layer.linear.bias"), p.tok_out, po, p.M, po, D, 0, s));
+  RGM_TRY(unpatchify_launch(p.tok_out, eps, N, c.out_ch, H, c.width, s));
+  return RGM_OK;
+}
+
+static int run_head(rgm_dit* h, const Plan& p, const char* norm, const char* head, int rows, int n_out, float* out,
+                    hipStream_t s) {
+  const int D = h->cfg.hidden;
+  const std::string nk(norm), hk(head);
+  RGM_TRY(layernorm_modulate_launch(p.pool, p.pooln, rows, D, 1e-5f, h->p(nk + ".weight"), h->p(nk + ".bias"), nullptr, nullptr, 0, 1, s));
+  RGM_TRY(lin(p.pooln, D, h->p(hk + ".0.weight"), h->p(hk + ".0.bias"), p.z1, D / 4, rows, D / 4, D, 1, s));
+  RGM_TRY(lin(p.z1, D / 4, h->p(hk + ".2.weight"), h->p(hk + ".2.bias"), out, n_out, rows, n_out, D / 4, 0, s));
+  return RGM_OK;
+}
+
+extern "C" int rgm_dit_classify(rgm_dit* h, const float* x, const int64_t* t, float* logits, float* key_out, int N, int H,
+                                void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind != 0, "dit_classify: handle is not a classifier");
+  RGM_REQUIRE(x && t && logits, "dit_classify: null tensor");
+  Plan p;
+  RGM_TRY(check_ready(h, N, H, ws_bytes, ws, &p));
+  hipStream_t s = (hipStream_t)stream;
+  const rgm_dit_cfg& c = h->cfg;
+  const int D = c.hidden;
+  RGM_TRY(run_backbone(h, p, x, t, nullptr, s));
+  if (c.kind == 1) {
+    RGM_TRY(pool_rows_launch(p.x, p.pool, N, p.T, D, 0, 1, 1, s));
+    return run_head(h, p, "norm", "classifier_head", N, c.n_out, logits, s);
+  }
+  if (key_out) {
+    RGM_TRY(pool_rows_launch(p.x, p.pool, N, p.T, D, 0, 1, 1, s));
+    RGM_TRY(run_head(h, p, "norm_key", "classifier_head_key", N, 25, key_out, s));
+  }
+  const int n_token = H / c.width;
+  RGM_REQUIRE(n_token > 0 && p.T0 % n_token == 0, "dit_classify: H=%d gives %d chord windows", H, n_token);
+  RGM_TRY(pool_rows_launch(p.x, p.pool, N, p.T, D, 1, n_token, p.T0 / n_token, s));
+  return run_head(h, p, "norm", "classifier_head", N * n_token, c.n_out, logits, s);
+}

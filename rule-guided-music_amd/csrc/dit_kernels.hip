@@ -1,0 +1,186 @@
+// dit_kernels.hip -- the bandwidth-bound glue of the DiT forward (HBM-bound; no MFMA here).
+//
+//   layernorm_modulate   LN(eps, no affine) * (1 + scale) + shift      guided_diffusion/dit.py:25-26, :334-335, :374
+//                        (optional affine LN for the classifier head, dit.py:770, :828)
+//   patchify / unpatchify FlattenPatchify1D.forward dit.py:219-224 ; DiTRotary.unpatchify dit.py:608-616
+//   timestep_sincos      TimestepEmbedder.timestep_embedding dit.py:47-65
+//   cond_finish          c = t_emb (+ y_embedder table row) ; SiLU(c)  dit.py:627-629, :333
+//   fill_cls / gather / mean-pool rows for the classifier heads        dit.py:813, :817-828
+//
+// All are one pass over their tensor with 16-byte lanes; LN keeps the row in registers (one wave
+// per row, shuffle reductions), so x is read once and the modulated row written once.
+#include "common.h"
+
+namespace rgm {
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int D,
+                                                     float eps, const float* __restrict__ weight,
+                                                     const float* __restrict__ bias, const float* __restrict__ shift,
+                                                     const float* __restrict__ scale, int mod_ld, int rows_per_batch) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * D);
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const long long mo = (long long)(row / rows_per_batch) * mod_ld;
+  float4* orow = reinterpret_cast<float4*>(out + (long long)row * D);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c >= nv) continue;
+    float4 y = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+    if (weight) {
+      const float4 w = reinterpret_cast<const float4*>(weight)[c], b = reinterpret_cast<const float4*>(bias)[c];
+      y = make_float4(y.x * w.x + b.x, y.y * w.y + b.y, y.z * w.z + b.z, y.w * w.w + b.w);
+    }
+    if (scale) {
+      const float4 sc = reinterpret_cast<const float4*>(scale + mo)[c], sh = reinterpret_cast<const float4*>(shift + mo)[c];
+      y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
+    }
+    orow[c] = y;
+  }
+}
+
+int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight, const float* bias,
+                              const float* shift, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s) {
+  RGM_REQUIRE(M > 0 && D > 0 && (D & 3) == 0 && D <= 2048, "layernorm: D=%d must be a multiple of 4, <= 2048", D);
+  RGM_REQUIRE((scale == nullptr) == (shift == nullptr) && (weight == nullptr) == (bias == nullptr), "layernorm: shift/scale and weight/bias come in pairs");
+  RGM_REQUIRE(scale == nullptr || ((mod_ld & 3) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0), "layernorm: modulation rows must be 16-byte aligned");
+  if (rows_per_batch <= 0) rows_per_batch = 1;
+  dim3 grid(cdiv(M, 4)), block(256);
+  const int nv = D / 4;
+  if (nv <= 128)
+    hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch);
+  else if (nv <= 320)
+    hipLaunchKernelGGL(ln_mod_kernel<5>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch);
+  else
+    hipLaunchKernelGGL(ln_mod_kernel<8>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// x (N,C,H,W) -> tok (N*H*W/P, P*C): token = h*(W/P) + w/P, feature = (w%P)*C + c
+__global__ void patchify_kernel(const float* __restrict__ x, float* __restrict__ tok, int N, int C, int H, int W, int P) {
+  const long long total = (long long)N * C * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // i indexes the OUTPUT (contiguous writes): [n][h][w][c]
+    const int c = i % C;
+    long long r = i / C;
+    const int w = r % W;
+    r /= W;
+    const int h = r % H;
+    const int n = r / H;
+    tok[i] = x[(((long long)n * C + c) * H + h) * W + w];
+  }
+}
+
+// tok (N*T, P*OC) -> out (N,OC,H,W), inverse of the map above (out indexed contiguously)
+__global__ void unpatchify_kernel(const float* __restrict__ tok, float* __restrict__ out, int N, int OC, int H, int W) {
+  const long long total = (long long)N * OC * H * W;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int w = i % W;
+    long long r = i / W;
+    const int h = r % H;
+    r /= H;
+    const int c = r % OC;
+    const int n = r / OC;
+    out[i] = tok[(((long long)n * H + h) * W + w) * OC + c];
+  }
+}
+
+// emb[n][0:half] = cos(t*freq), emb[n][half:] = sin(t*freq)
+__global__ void timestep_sincos_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ emb, int N, int half) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * half) return;
+  const int n = i / half, k = i - n * half;
+  const float a = (float)t[n] * freqs[k];
+  emb[(long long)n * 2 * half + k] = cosf(a);
+  emb[(long long)n * 2 * half + half + k] = sinf(a);
+}
+
+// cs = SiLU(c + table[y])   (c updated in place too when c_out != nullptr)
+__global__ void cond_finish_kernel(const float* __restrict__ c, const float* __restrict__ table, const int32_t* __restrict__ y,
+                                   float* __restrict__ cs, int N, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D) return;
+  const int n = i / D, d = i - n * D;
+  float v = c[i];
+  if (table && y) v += table[(long long)y[n] * D + d];
+  cs[i] = silu_f(v);
+}
+
+// x[n*T + 0][:] = cls[:]
+__global__ void fill_cls_kernel(const float* __restrict__ cls, float* __restrict__ x, int N, int T, int D) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D) return;
+  const int n = i / D, d = i - n * D;
+  x[(long long)n * T * D + d] = cls[d];
+}
+
+// out[n][g][:] = mean over `per` consecutive token rows starting at x[n*T + first + g*per]; per==1 is a row gather
+__global__ void pool_rows_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int T, int D, int first, int groups, int per) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * groups * D) return;
+  const int d = i % D;
+  const int g = (i / D) % groups;
+  const int n = i / (D * groups);
+  const float* p = x + ((long long)n * T + first + (long long)g * per) * D + d;
+  float s = 0.f;
+  for (int k = 0; k < per; ++k) s += p[(long long)k * D];
+  out[i] = per == 1 ? s : s / (float)per;
+}
+
+int patchify_launch(const float* x, float* tok, int N, int C, int H, int W, int P, hipStream_t s) {
+  const long long total = (long long)N * C * H * W;
+  hipLaunchKernelGGL(patchify_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s, x, tok, N, C, H, W, P);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+int unpatchify_launch(const float* tok, float* out, int N, int OC, int H, int W, hipStream_t s) {
+  const long long total = (long long)N * OC * H * W;
+  hipLaunchKernelGGL(unpatchify_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s, tok, out, N, OC, H, W);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+int timestep_sincos_launch(const int64_t* t, const float* freqs, float* emb, int N, int half, hipStream_t s) {
+  hipLaunchKernelGGL(timestep_sincos_kernel, dim3(cdiv(N * half, 256)), dim3(256), 0, s, t, freqs, emb, N, half);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+int cond_finish_launch(const float* c, const float* table, const int32_t* y, float* cs, int N, int D, hipStream_t s) {
+  hipLaunchKernelGGL(cond_finish_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, s, c, table, y, cs, N, D);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+int fill_cls_launch(const float* cls, float* x, int N, int T, int D, hipStream_t s) {
+  hipLaunchKernelGGL(fill_cls_kernel, dim3(cdiv(N * D, 256)), dim3(256), 0, s, cls, x, N, T, D);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+int pool_rows_launch(const float* x, float* out, int N, int T, int D, int first, int groups, int per, hipStream_t s) {
+  hipLaunchKernelGGL(pool_rows_kernel, dim3(cdiv(N * groups * D, 256)), dim3(256), 0, s, x, out, N, T, D, first, groups, per);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+}  // namespace rgm

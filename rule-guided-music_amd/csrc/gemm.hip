@@ -1,0 +1,245 @@
+// gemm.hip -- fp32 GEMM on the CDNA4 matrix cores: C = epi(alpha * A[M,K] . B[N,K]^T).
+//
+// This one kernel family carries every dense contraction of the hot path:
+//   nn.Linear of the DiT blocks (qkv / proj / fc1 / fc2 / adaLN / embedders / final)
+//       guided_diffusion/dit.py:219-227, :263-288, :326, :333, :372-376
+//   1x1 convs and the 3x3 convs of the taming decoder as an implicit GEMM over NHWC activations
+//       taming/modules/diffusionmodules/model.py:38-53, :78-137, :140-192
+//
+// Why fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference computes in fp32 and the contract is 1e-3
+// relative on latents after 28 blocks x 50..1000 steps; the f32-input MFMA is bitwise an fmaf chain
+// (MI355X_MICROARCH: 157 TF peak = 1/16 of bf16) so parity is a re-association question only.
+//
+// Structure (wave64, 4 waves / workgroup):
+//   * block tile BM x BN x 32, each wave owns TM x TN accumulators of 32x32 (16 VGPR each);
+//   * A and B are both K-contiguous ("B^T form" -- nn.Linear weights are [out,in]), staged
+//     global -> VGPR (16 B / lane, one full 128-B line per 8 lanes) -> LDS, double buffered, one
+//     barrier per K-tile, the next tile's global loads issued before the current tile's MFMAs;
+//   * LDS rows are 32 floats = 8 slots of 16 B; slot' = slot ^ ((row >> 1) & 7) makes both the
+//     8-lane ds_write_b128 groups and the non-contiguous 16-lane ds_read_b128 groups conflict-free;
+//   * fragment trick: the MFMA sums over its two k-slots (lane halves); which k lands in which slot
+//     is free as long as A and B agree, so lane-half h reads k = 8j+4h .. 8j+4h+3 with ONE
+//     ds_read_b128 and feeds element s to step s (steps cover {s, 4+s}) -- no b32 reads, no shuffles;
+//   * blockIdx -> tile map: bijective XCD remap (block b runs on XCD b%8) so each XCD's private L2
+//     serves a contiguous band of tiles, rastered in groups of 8 M-tiles so co-resident blocks share
+//     A / B panels;
+//   * fused epilogue: bias, SiLU / GELU(tanh), adaLN gate, residual add (in place allowed).
+#include "common.h"
+
+namespace rgm {
+
+template <int BM, int BN, int WM, int WN, int ALOAD>
+__global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int tiles_m, int tiles_n) {
+  constexpr int NT = WM * WN * 64;
+  constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
+  constexpr int RPP = NT / 8;  // rows staged per pass
+  constexpr int PA = BM / RPP, PB = BN / RPP;
+  static_assert(PA >= 1 && PB >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
+
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* As = smem;                 // [2][BM][32]
+  float* Bs = smem + 2 * BM * 32;   // [2][BN][32]
+
+  // ---- blockIdx -> (tile_m, tile_n): XCD-contiguous bands, grouped raster
+  const int nb = tiles_m * tiles_n;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, loc = bid >> 3, q = nb >> 3, r = nb & 7;
+  const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  constexpr int GROUP = 8;
+  const int per_group = GROUP * tiles_n;
+  const int grp = sid / per_group;
+  const int first_m = grp * GROUP;
+  const int gsz = min(tiles_m - first_m, GROUP);
+  const int in_g = sid - grp * per_group;
+  const int m0 = (first_m + in_g % gsz) * BM;
+  const int n0 = (in_g / gsz) * BN;
+
+  const int z = blockIdx.z;
+  const float* __restrict__ Ab = p.A + (long long)z * p.sA;
+  const float* __restrict__ Bb = p.B + (long long)z * p.sB;
+
+  const int tid = threadIdx.x;
+  const int srow = tid >> 3, slot = tid & 7;
+  const int ssw = (srow >> 1) & 7;
+
+  // ---- per-thread staging coordinates
+  long long a_off[PA];
+  bool a_ok[PA];
+  int a_y[PA], a_x[PA];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = m0 + srow + i * RPP;
+    a_ok[i] = row < p.M;
+    if (ALOAD == 0) {
+      a_off[i] = (long long)row * p.lda + slot * 4;
+      a_y[i] = a_x[i] = 0;
+    } else {
+      const int img = row >> (p.logH + p.logW);
+      a_y[i] = (row >> p.logW) & (p.H - 1);
+      a_x[i] = row & (p.W - 1);
+      a_off[i] = (long long)img * (p.H >> p.ups) * (p.W >> p.ups) * p.Cin + slot * 4;
+    }
+  }
+  long long b_off[PB];
+  bool b_ok[PB];
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = n0 + srow + i * RPP;
+    b_ok[i] = row < p.N;
+    b_off[i] = (long long)row * p.ldb + slot * 4;
+  }
+  const int cpt = (ALOAD == 1) ? (p.Cin >> 5) : 1;  // k-tiles per 3x3 tap
+
+  float4 ra[PA], rb[PB];
+  auto gload = [&](int kt) {
+    if (ALOAD == 0) {
+#pragma unroll
+      for (int i = 0; i < PA; ++i)
+        ra[i] = a_ok[i] ? *reinterpret_cast<const float4*>(Ab + a_off[i] + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+      const int tap = kt / cpt;
+      const int c0 = (kt - tap * cpt) << 5;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int Win = p.W >> p.ups;
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+        const bool ok = a_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        const long long off = a_off[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin + c0;
+        ra[i] = ok ? *reinterpret_cast<const float4*>(Ab + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(Bb + b_off[i] + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto lstore = [&](int buf) {
+    float* Ad = As + buf * BM * 32;
+    float* Bd = Bs + buf * BN * 32;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      *reinterpret_cast<float4*>(Ad + (srow + i * RPP) * 32 + ((slot ^ ssw) << 2)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      *reinterpret_cast<float4*>(Bd + (srow + i * RPP) * 32 + ((slot ^ ssw) << 2)) = rb[i];
+  };
+
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wr = wave / WN, wc = wave - wr * WN;
+  const int arow0 = wr * TM * 32, bcol0 = wc * TN * 32;
+  const int rsw = (l31 >> 1) & 7;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int KT = p.K >> 5;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1);
+    const float* Asb = As + buf * BM * 32;
+    const float* Bsb = Bs + buf * BN * 32;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f32x4 a[TM], b[TN];
+      const int so = ((2 * j + hh) ^ rsw) << 2;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Asb + (arow0 + i * 32 + l31) * 32 + so);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const f32x4*>(Bsb + (bcol0 + i * 32 + l31) * 32 + so);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int im = 0; im < TM; ++im)
+#pragma unroll
+          for (int in = 0; in < TN; ++in)
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+    }
+    if (kt + 1 < KT) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  float* __restrict__ Cb = p.C + (long long)z * p.sC;
+  const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
+  const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+#pragma unroll
+  for (int im = 0; im < TM; ++im) {
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int col = n0 + bcol0 + in * 32 + l31;
+      if (col >= p.N) continue;
+      const float bv = biasb ? biasb[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + arow0 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        if (row >= p.M) continue;
+        float v = acc[im][in][e] * p.alpha + bv;
+        if (p.act == 1) v = silu_f(v);
+        else if (p.act == 2) v = gelu_tanh_f(v);
+        if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
+        if (resb) v += resb[(long long)row * p.ldres + col];
+        Cb[(long long)row * p.ldc + col] = v;
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const GemmParams& p, hipStream_t s) {
+  const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
+  const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
+  dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64);
+  if (p.aload == 0)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0>), grid, block, lds, s, p, tm, tn);
+  else
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1>), grid, block, lds, s, p, tm, tn);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+static double wave_eff(int M, int N, int bm, int bn, int batch) {
+  const double tiles = (double)cdiv(M, bm) * cdiv(N, bn) * batch;
+  const double rounds = tiles / 256.0;
+  const double useful = ((double)M * N * batch) / (tiles * bm * bn);  // padding waste
+  return useful * rounds / (double)((long long)(rounds + 0.999999));
+}
+
+int gemm_launch(const GemmParams& p, hipStream_t s) {
+  RGM_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && (p.K & 31) == 0, "gemm: bad shape M=%d N=%d K=%d (K%%32)", p.M, p.N, p.K);
+  RGM_REQUIRE(p.aload == 0 || (p.Cin % 32 == 0 && p.K == 9 * p.Cin), "gemm: implicit conv needs Cin%%32==0, K=9*Cin");
+  RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
+              "gemm: operands must be 16-byte aligned with ld%%4==0");
+  int tile = p.tile;
+  if (tile == 0) {
+    if (p.M <= 64) tile = 4;
+    else {
+      // pick the tile that wastes the fewest CU-rounds; smaller tiles pay more L2->LDS traffic
+      const double e1 = wave_eff(p.M, p.N, 128, 128, p.batch);
+      const double e2 = wave_eff(p.M, p.N, 128, 64, p.batch) * 0.96;
+      const double e3 = wave_eff(p.M, p.N, 64, 64, p.batch) * 0.92;
+      tile = 1;
+      double best = e1;
+      if (e2 > best) { best = e2; tile = 2; }
+      if (e3 > best) { best = e3; tile = 3; }
+    }
+  }
+  switch (tile) {
+    case 1: return launch_cfg<128, 128, 2, 2>(p, s);
+    case 2: return launch_cfg<128, 64, 2, 2>(p, s);
+    case 3: return launch_cfg<64, 64, 2, 2>(p, s);
+    case 4: return launch_cfg<32, 128, 1, 4>(p, s);
+    default: break;
+  }
+  set_error("gemm: unknown tile %d", tile);
+  return RGM_ERR_INVALID;
+}
+
+}  // namespace rgm

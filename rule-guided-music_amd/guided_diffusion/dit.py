@@ -1,0 +1,229 @@
+"""DiTRotary eps-network and DiTRotaryClassifier -- reference API, native MI355X forward.
+
+Mirrors the public surface of the reference's guided_diffusion/dit.py that the sampling path
+uses (dit.py:538-634 DiTRotary, :735-831 DiTRotaryClassifier, :969 DiT_models): same constructor
+arguments, same state_dict keys (x_embedder.MLP.{0,2}.*, t_embedder.mlp.{0,2}.*,
+y_embedder.embedding_table.weight, rotary_emb.freqs, blocks.N.attn.{qkv,proj}.*,
+blocks.N.attn.rotary_emb.freqs, blocks.N.mlp.{fc1,fc2}.*, blocks.N.adaLN_modulation.1.*,
+final_layer.{linear,adaLN_modulation.1}.*, cls_token, norm*, classifier_head*), same
+`model(x, t, y=None)` call.  The modules only OWN parameters (torch = device memory); the forward
+is one call into librgm_hip.so (rgm_dit_forward / rgm_dit_classify).  No eager fallback.
+
+Legacy non-rotary variants of the reference (DiT, DiT_classifier, PatchEmbed, ...) are out of
+scope and are not registered.
+"""
+import ctypes as C
+import math
+
+import torch
+import torch.nn as nn
+
+from rgm import native as _rgm
+from rgm.native import DitCfg
+from rgm.synth import dit_param_shapes
+
+
+def _attach(root, dotted, param):
+    """Register `param` under a dotted state_dict key, creating bare container modules on the way."""
+    *path, leaf = dotted.split(".")
+    mod = root
+    for name in path:
+        nxt = mod._modules.get(name)
+        if nxt is None:
+            nxt = nn.Module()
+            mod.add_module(name, nxt)
+        mod = nxt
+    mod.register_parameter(leaf, param)
+
+
+class _NativeDiT(nn.Module):
+    """Parameter container + native handle shared by the eps-network and the classifiers."""
+
+    def __init__(self, *, input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_ratio,
+                 kind, out_channels=0, n_embed=0, n_out=0, chord=False):
+        super().__init__()
+        if isinstance(input_size, int):
+            input_size = [input_size, input_size]
+        assert float(mlp_ratio) == 4.0, "the native blocks implement mlp_ratio=4 (all registered configs)"
+        self.input_size = list(input_size)
+        self.patch_size, self.in_channels, self.num_heads = patch_size, in_channels, num_heads
+        self.hidden_size, self.depth = hidden_size, depth
+        self._kind, self._n_embed, self._n_out, self._out_ch = kind, n_embed, n_out, out_channels
+        self._arch = dict(depth=depth, hidden=hidden_size, heads=num_heads, patch=patch_size, in_ch=in_channels,
+                          out_ch=out_channels, num_classes=n_embed, class_dropout=False,
+                          classifier=kind != 0, cls_classes=n_out, chord=chord)
+        shared = {}
+        for key, shape in dit_param_shapes(**self._arch):
+            if key.endswith("rotary_emb.freqs"):          # ONE Parameter, visible under every alias
+                if "freqs" not in shared:
+                    shared["freqs"] = nn.Parameter(torch.empty(shape), requires_grad=False)
+                _attach(self, key, shared["freqs"])
+            else:
+                _attach(self, key, nn.Parameter(torch.empty(shape)))
+        self._handle = None
+        self._dirty = True
+        self._ws = None
+        self.register_load_state_dict_post_hook(lambda m, _: setattr(m, "_dirty", True))
+        self.reset_parameters()
+
+    # ---- initialisation with the reference's distributions (dit.py:578-606, :780-801)
+    def reset_parameters(self):
+        D, heads = self.hidden_size, self.num_heads
+        rot = int(D // heads * 0.5)
+        with torch.no_grad():
+            for key, p in self.named_parameters(remove_duplicate=True):
+                if key.endswith("freqs"):
+                    p.copy_(1.0 / (10000.0 ** (torch.arange(0, rot, 2).float() / rot)))
+                elif key == "cls_token":
+                    nn.init.normal_(p, std=1e-6)
+                elif key.endswith("embedding_table.weight") or key.startswith("t_embedder") and key.endswith("weight"):
+                    nn.init.normal_(p, std=0.02)
+                elif "adaLN_modulation" in key or key.startswith("final_layer"):
+                    nn.init.zeros_(p)                      # adaLN-zero: a fresh eps-network outputs 0
+                elif key.startswith("norm"):
+                    (nn.init.ones_ if key.endswith("weight") else nn.init.zeros_)(p)
+                elif p.dim() == 2:
+                    nn.init.xavier_uniform_(p)
+                else:
+                    nn.init.zeros_(p)
+        self._dirty = True
+
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    # ---- native side
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _ensure_native(self, n_tokens):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise _rgm.RgmError("DiTRotary runs only on a HIP device (model.to('cuda')); there is no CPU path "
+                                "in the product -- the CPU restatement lives in oracle/ for tests only")
+        if self._handle is not None and n_tokens > self._max_tokens:
+            _rgm.lib.rgm_dit_destroy(self._handle)
+            self._handle = None
+        if self._handle is None:
+            self._max_tokens = max(n_tokens, 2 * self.input_size[0] * self.input_size[1] // self.patch_size // 2 + 1, 257)
+            self._max_tokens = min(self._max_tokens, 288)
+            cfg = DitCfg(depth=self.depth, hidden=self.hidden_size, heads=self.num_heads, patch=self.patch_size,
+                         in_ch=self.in_channels, out_ch=self._out_ch, width=self.input_size[1],
+                         n_embed=self._n_embed, kind=self._kind, n_out=self._n_out, max_tokens=self._max_tokens)
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                _rgm.check(_rgm.lib.rgm_dit_create(C.byref(cfg), C.byref(h)))
+            self._handle, self._dirty = h, True
+        if self._dirty:
+            torch.cuda.synchronize(dev)
+            with torch.cuda.device(dev):
+                for key, p in self.state_dict().items():
+                    t = p.detach().to(torch.float32).contiguous()
+                    shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                    _rgm.check(_rgm.lib.rgm_dit_set_param(self._handle, key.encode(), _rgm.ptr(t), shape, t.dim()))
+            self._dirty = False
+
+    def _workspace(self, N, H):
+        need = _rgm.lib.rgm_dit_workspace_bytes(self._handle, N, H)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != self._device():
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self._device())
+        return self._ws, need
+
+    @staticmethod
+    def _as_index(t, dtype):
+        if t.is_floating_point():
+            if not bool((t == t.round()).all()):
+                raise NotImplementedError("fractional timesteps (rescale_timesteps with T != 1000) are not supported")
+            t = t.round()
+        return t.to(dtype).contiguous()
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _rgm.lib.rgm_dit_destroy(self._handle)
+        except Exception:
+            pass
+
+
+class DiTRotary(_NativeDiT):
+    """Diffusion eps-network with rotary attention (reference dit.py:538-634)."""
+
+    def __init__(self, input_size=32, patch_size=8, in_channels=3, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, class_dropout_prob=0.1, num_classes=9, learn_sigma=True):
+        self.learn_sigma = learn_sigma
+        self.num_classes = num_classes
+        out_ch = in_channels * 2 if learn_sigma else in_channels
+        n_embed = (num_classes + int(class_dropout_prob > 0)) if num_classes else 0
+        super().__init__(input_size=input_size, patch_size=patch_size, in_channels=in_channels,
+                         hidden_size=hidden_size, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                         kind=0, out_channels=out_ch, n_embed=n_embed)
+        self.out_channels = out_ch
+
+    def forward(self, x, t, y=None):
+        """x (N,C,H,W) f32, t (N,) diffusion timesteps, y (N,) class labels or None -> eps (N,out,H,W)."""
+        _rgm.require_cuda(x, t, y)
+        N, _, H, W = x.shape
+        assert W == self.input_size[1], "pitch axis of the latent is fixed by input_size[1]"
+        self._ensure_native(H * W // self.patch_size)
+        x = x.detach().to(torch.float32).contiguous()
+        t = self._as_index(t, torch.int64)
+        yy = self._as_index(y, torch.int32) if (self.num_classes and y is not None) else None
+        out = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        ws, need = self._workspace(N, H)
+        with torch.cuda.device(x.device):
+            _rgm.check(_rgm.lib.rgm_dit_forward(self._handle, _rgm.ptr(x), _rgm.ptr(t), _rgm.ptr(yy), _rgm.ptr(out),
+                                                N, H, _rgm.ptr(ws), need, _rgm.current_stream()))
+        return out
+
+
+class DiTRotaryClassifier(_NativeDiT):
+    """Guidance classifier on noisy latents (reference dit.py:735-831); chord=True adds the key head."""
+
+    def __init__(self, input_size=32, patch_size=8, in_channels=3, hidden_size=1152, depth=28, num_heads=16,
+                 mlp_ratio=4.0, num_classes=9, chord=False):
+        self.chord = chord
+        self.num_classes = num_classes
+        super().__init__(input_size=input_size, patch_size=patch_size, in_channels=in_channels,
+                         hidden_size=hidden_size, depth=depth, num_heads=num_heads, mlp_ratio=mlp_ratio,
+                         kind=2 if chord else 1, n_out=num_classes, chord=chord)
+
+    def forward(self, x, t, y=None):
+        _rgm.require_cuda(x, t)
+        N, _, H, W = x.shape
+        self._ensure_native(H * W // self.patch_size + 1)
+        x = x.detach().to(torch.float32).contiguous()
+        t = self._as_index(t, torch.int64)
+        ws, need = self._workspace(N, H)
+        if self.chord:
+            n_token = H // W
+            key = torch.empty((N, 25), dtype=torch.float32, device=x.device)
+            out = torch.empty((N, n_token, self.num_classes), dtype=torch.float32, device=x.device)
+        else:
+            key = None
+            out = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _rgm.check(_rgm.lib.rgm_dit_classify(self._handle, _rgm.ptr(x), _rgm.ptr(t), _rgm.ptr(out), _rgm.ptr(key),
+                                                 N, H, _rgm.ptr(ws), need, _rgm.current_stream()))
+        return (key, out) if self.chord else out
+
+
+def _eps(depth, hidden, heads, patch):
+    return lambda **kw: DiTRotary(depth=depth, hidden_size=hidden, patch_size=patch, num_heads=heads, **kw)
+
+
+def _cls(depth, hidden, heads, patch, chord=False):
+    return lambda **kw: DiTRotaryClassifier(depth=depth, hidden_size=hidden, patch_size=patch, num_heads=heads,
+                                            chord=chord, **kw)
+
+
+# Registry names of the reference (dit.py:969-983) for the rotary family.
+DiT_models = {
+    "DiTRotary_XL_8": _eps(28, 1152, 16, 8),
+    "DiTRotary_XL_16": _eps(28, 1152, 16, 16),
+    "DiTRotary_B_8": _eps(12, 768, 12, 8),
+    "DiTRotary_B_16": _eps(12, 768, 12, 16),
+    "DiTRotary-XS/8-cls": _cls(4, 384, 6, 8),
+    "DiTRotary-S/8-cls": _cls(12, 384, 6, 8),
+    "DiTRotary-S/8-chord-cls": _cls(12, 384, 6, 8, chord=True),
+    "DiTRotary-B/8-cls": _cls(12, 768, 12, 8),
+}

@@ -1,0 +1,84 @@
+"""Load librgm_hip.so and declare the C ABI of include/rgm.h."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librgm_hip.so")
+
+
+class RgmError(RuntimeError):
+    pass
+
+
+class DitCfg(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("depth", "hidden", "heads", "patch", "in_ch", "out_ch", "width",
+                                         "n_embed", "kind", "n_out", "max_tokens")]
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise RgmError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(or `make -C rule-guided-music_amd/csrc`).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    sig = {
+        "rgm_version": (C.c_int, []),
+        "rgm_last_error": (C.c_char_p, []),
+        "rgm_dit_create": (C.c_int, [C.POINTER(DitCfg), C.POINTER(vp)]),
+        "rgm_dit_destroy": (None, [vp]),
+        "rgm_dit_set_param": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]),
+        "rgm_dit_missing_params": (C.c_int, [vp]),
+        "rgm_dit_workspace_bytes": (sz, [vp, i32, i32]),
+        "rgm_dit_forward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+        "rgm_dit_classify": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+        "rgm_gemm": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, vp]),
+        "rgm_gemm_tile": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+        "rgm_layernorm_modulate": (C.c_int, [vp, vp, i32, i32, f32, vp, vp, vp, vp, i32, i32, vp]),
+        "rgm_rotary_attention": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)            # AttributeError here == header/library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return L
+
+
+class _Lazy:
+    """Defer dlopen to first use so CPU-only tooling can import the package metadata."""
+    _lib = None
+
+    def __getattr__(self, name):
+        if _Lazy._lib is None:
+            _Lazy._lib = _load()
+        return getattr(_Lazy._lib, name)
+
+
+lib = _Lazy()
+EXPORTS = ["rgm_version", "rgm_last_error", "rgm_dit_create", "rgm_dit_destroy", "rgm_dit_set_param",
+           "rgm_dit_missing_params", "rgm_dit_workspace_bytes", "rgm_dit_forward", "rgm_dit_classify",
+           "rgm_gemm", "rgm_layernorm_modulate", "rgm_rotary_attention"]
+
+
+def check(status):
+    if status != 0:
+        raise RgmError(f"librgm_hip status {status}: {lib.rgm_last_error().decode()}")
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RgmError("rgm ops need tensors on a HIP device (no CPU fallback in the product path)")
+
+
+def ptr(t):
+    """Device pointer of a contiguous torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise RgmError("rgm ops need contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
