@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""bench.py -- denoising steps/s of the rule-guided sampling hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Metric (BASELINE.json): denoising steps/sec, whole node, DiTRotary_XL_8 on 4x128x16 latents.
+Workload at N=1 = BASELINE config[1] ("C2"): unconditional DDIM-50 (eta=1) on a batch of 16 latents, one
+"step" = one ddim_sample call over that batch (eps-network forward + fused step update + Philox noise).
+For N>1 every rank runs the same batch-16 chain on its own GPU (the path shards over samples; no data-path
+collective), scaling = weak, value = N*K / max-over-ranks time.  Other workloads (--workload scg) time the
+SCG branch-and-select step (config[3] shape) with the RCCL log-prob all-gather.
+
+One JSON line on stdout (rank 0) per the driver contract, plus
+  roofline     : the dominant kernel (fp32-MFMA GEMM, 128x128 tile) -- algorithmic 2MNK FLOPs of its launches
+                 divided by their HIP-event durations measured live on the launch stream (separate short pass
+                 with rgm_prof_enable, same workload), against the 157.3 TFLOP/s f32 matrix peak;
+  cpu_baseline : the numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "rule-guided-music_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+XL = dict(depth=28, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4)
+DIT_GFLOP_PER_SAMPLE = 237.4          # DiTRotary_XL_8 forward, T=256
+VAE_GFLOP_PER_TILE = 114.48
+F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH: v_mfma_f32_32x32x2_f32, dense
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def build_eps_model(num_classes, device):
+    from rgm import synth
+    from guided_diffusion.dit import DiT_models
+    m = DiT_models["DiTRotary_XL_8"](input_size=[128, 16], in_channels=4, num_classes=num_classes, learn_sigma=False)
+    arch = dict(XL, num_classes=num_classes + (1 if num_classes else 0), class_dropout=False)
+    sd = synth.dit_state_dict(1, final_std=0.3 / 1152 ** 0.5, device=device, **arch)
+    m.load_state_dict(sd, strict=True)
+    return m.to(device).eval()
+
+
+def make_diffusion(respacing):
+    from guided_diffusion.script_util import create_diffusion
+    return create_diffusion(learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=respacing,
+                            use_kl=False, predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+
+
+class C2Workload:
+    """Unconditional DDIM-50, eta = 1, batch 16 (sample_rule.py with num_classes=0, class_cond False)."""
+    name = "C2 unconditional DDIM-50 (eta=1), DiTRotary_XL_8, batch 16 per GPU, latent 4x128x16"
+
+    def __init__(self, device, batch):
+        from functools import partial
+        from guided_diffusion.condition_functions import model_fn
+        self.B = batch
+        self.device = device
+        self.model = build_eps_model(0, device)
+        self.fn = partial(model_fn, model=self.model, num_classes=0, class_cond=False, cfg=False, w=0.)
+        self.d = make_diffusion("ddim50")
+        self.d.t_end = 0
+        self.x = self.d._draw((batch, 4, 128, 16), device)
+        self.k = 0
+        self.flop_per_step = batch * DIT_GFLOP_PER_SAMPLE * 1e9
+
+    def step(self):
+        i = 49 - (self.k % 50)
+        self.k += 1
+        if i == 49:
+            self.x = self.d._draw(self.x.shape, self.device)      # new chain
+        t = torch.full((self.B,), i, dtype=torch.int64, device=self.device)
+        self.d._t_host = i
+        out = self.d.ddim_sample(self.fn, self.x, t, clip_denoised=False, model_kwargs={}, eta=1.0)
+        self.d._t_host = None
+        self.x = out["sample"]
+
+
+class SCGWorkload:
+    """One guided SCG step (config[3] shape): B=4, n=16 candidates, DiT-XL + VAE decode + 2 rules, DDPM chain."""
+    name = "C4 SCG guided DDPM step, DiTRotary_XL_8 + KL-VAE decode + pitch_hist/note_density, B=4, n=16 (sharded over GPUs)"
+
+    def __init__(self, device, batch):
+        from functools import partial
+        from types import SimpleNamespace
+        from rgm import synth
+        from guided_diffusion.condition_functions import model_fn
+        from taming.models.klvae_pedal import AutoencoderKL
+        self.B = batch
+        self.device = device
+        self.model = build_eps_model(3, device)
+        self.fn = partial(model_fn, model=self.model, num_classes=3, class_cond=True, cfg=False, w=0.)
+        self.vae = AutoencoderKL()
+        self.vae.load_state_dict(synth.vae_state_dict(2, device=device))
+        self.vae = self.vae.to(device).eval()
+        self.d = make_diffusion("")
+        self.d.t_end = 0
+        self.d.noise = __import__("guided_diffusion.gaussian_diffusion", fromlist=["PhiloxNoise"]).PhiloxNoise(seed=0)
+        self.x = self.d._draw((batch, 4, 128, 16), device)
+        ph = torch.tensor([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], device=device).repeat(batch, 1)
+        nd = torch.tensor([3.] * 8 + [3.] * 8, device=device).repeat(batch, 1)
+        self.kw = {"y": torch.ones(batch, dtype=torch.int64, device=device), "rule": {"pitch_hist": ph, "note_density": nd}}
+        self.guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+        self.scg = {"num_samples": 16, "pitch_hist": 40., "note_density": 1.}
+        self.k = 0
+        self.flop_per_step = batch * ((1 + 16) * DIT_GFLOP_PER_SAMPLE + 16 * 8 * VAE_GFLOP_PER_TILE) * 1e9
+
+    def step(self):
+        i = 700 - (self.k % 600)
+        self.k += 1
+        t = torch.full((self.B,), i, dtype=torch.int64, device=self.device)
+        self.d._t_host = i
+        out = self.d.p_sample(self.fn, self.x, t, clip_denoised=False, model_kwargs=self.kw, embed_model=self.vae,
+                              scale_factor=1.2465, guidance_kwargs=self.guid, scg_kwargs=self.scg)
+        self.d._t_host = None
+        self.x = out["sample"]
+
+
+def roofline_pass(work, steps=2):
+    """Dominant-kernel roofline from HIP events around every GEMM launch (its own short pass)."""
+    from rgm import native as R
+    R.check(R.lib.rgm_prof_reset())
+    R.check(R.lib.rgm_prof_enable(1))
+    for _ in range(steps):
+        work.step()
+    torch.cuda.synchronize()
+    R.check(R.lib.rgm_prof_enable(0))
+    rows = {}
+    for kid in (1, 2, 3, 4, 11, 12, 13, 14):
+        n, ms, fl = C.c_int(), C.c_double(), C.c_double()
+        R.check(R.lib.rgm_prof_report(kid, C.byref(n), C.byref(ms), C.byref(fl)))
+        if n.value:
+            rows[kid] = dict(launches=n.value, ms=ms.value, flops=fl.value)
+    R.check(R.lib.rgm_prof_reset())
+    names = {1: "gemm_kernel<128,128,2,2,0>", 2: "gemm_kernel<128,64,2,2,0>", 3: "gemm_kernel<64,64,2,2,0>",
+             4: "gemm_kernel<32,128,1,4,0>", 11: "gemm_kernel<128,128,2,2,1>", 12: "gemm_kernel<128,64,2,2,1>",
+             13: "gemm_kernel<64,64,2,2,1>", 14: "gemm_kernel<32,128,1,4,1>"}
+    kid = max(rows, key=lambda k: rows[k]["ms"])
+    r = rows[kid]
+    achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes/launch from separate rocprofv3 --pmc passes
+    if os.path.exists(tp):
+        try:
+            traffic = json.load(open(tp)).get(names[kid])
+        except Exception:
+            traffic = None
+    all_ms = sum(v["ms"] for v in rows.values())
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": names[kid],
+            "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2), "launches_per_step": r["launches"] // steps,
+            "gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3),
+            "share_of_gemm_time": round(r["ms"] / all_ms, 3),
+            "all_gemm_tflops": round(sum(v["flops"] for v in rows.values()) / (all_ms * 1e-3) / 1e12, 2)}
+
+
+def cpu_baseline(work, batch):
+    """The numpy oracle (a port; the reference itself cannot travel) on the host cores: DDIM steps of the same
+    chain on a bounded sample."""
+    from oracle import diffusion_np as odf, dit_np as odit
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    sd = {k: v.detach().cpu().numpy() for k, v in work.model.state_dict().items()}
+    S = odf.Schedule(1000, "linear", "ddim50")
+    b = min(batch, 4)
+    rng = np.random.RandomState(0)
+    x = rng.randn(b, 4, 128, 16).astype(np.float32)
+
+    def model(xx, tt, **kw):
+        return odit.dit_forward(sd, xx, tt, None, depth=28, heads=16)
+    n_steps, t0 = 0, time.perf_counter()
+    for i in (49, 48, 47):
+        t = np.full((b,), i, dtype=np.int64)
+        x = odf.ddim_sample(S, model, x, t, rng.randn(*x.shape).astype(np.float32), eta=1.0)["sample"]
+        n_steps += 1
+        if time.perf_counter() - t0 > 20:
+            break
+    dt = time.perf_counter() - t0
+    # one step of batch `batch` costs batch/b times a step of batch b (GEMM-bound, linear in batch)
+    return {"value": round(n_steps / dt * b / batch, 4), "unit": "steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"{n_steps} DDIM steps of the same chain at batch {b} with the numpy oracle ({dt:.1f} s), scaled to batch {batch}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--workload", default="c2", choices=["c2", "scg"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    torch.manual_seed(0)
+    batch = args.batch or (16 if args.workload == "c2" else 4)
+    work = (C2Workload if args.workload == "c2" else SCGWorkload)(device, batch)
+    for _ in range(args.warmup):
+        work.step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        work.step()
+    e1.record()
+    fence()
+    dt = time.perf_counter() - t0
+    gpu_ms = e0.elapsed_time(e1)
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    try:                                                         # every rank runs it (SCG steps hold a collective)
+        roof = roofline_pass(work)
+    except Exception as e:                                       # never lose the headline number
+        log("roofline pass failed:", repr(e))
+        roof = None
+    if rank == 0:
+        sharded = args.workload == "scg"
+        units = args.steps * (1 if sharded else world)           # SCG shards ONE chain; C2 runs one chain per GPU
+        res = {
+            "metric": "denoising steps/sec (whole node), DiTRotary_XL_8 4x128x16",
+            "value": round(units / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": work.name, "batch_per_gpu": batch, "sample_steps_per_s": round(units * batch / dt, 2),
+                       "weights": "synthetic random-init (rgm.synth seed 1; adaLN/final layers re-randomised)",
+                       "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
+                       "algorithmic_tflops": round(work.flop_per_step * units / dt / 1e12, 2)},
+        }
+        res["roofline"] = roof
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
+            try:
+                res["cpu_baseline"] = cpu_baseline(work, batch)
+            except Exception as e:
+                log("cpu baseline failed:", repr(e))
+                res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

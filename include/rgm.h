@@ -91,6 +91,104 @@ int rgm_layernorm_modulate(const float* x, float* out, int M, int D, float eps, 
 int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const float* sin_tab,
                          int N, int T, int heads, int hd, int rot_half, void* stream);
 
+/* Same as rgm_gemm without gate/residual but with an explicit tile shape (1: 128x128, 2: 128x64, 3: 64x64,
+ * 4: 32x128, 0: auto) -- used by the parity tests and tile-selection experiments. */
+int rgm_gemm_tile(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
+                  const float* bias, int act, int tile, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sampler step kernels                                   guided_diffusion/gaussian_diffusion.py
+ * `tables_host`: HOST array of 8 DEVICE pointers to the float32-cast schedule tables (length = number of
+ * re-spaced timesteps), in this order: sqrt_recip_alphas_cumprod, sqrt_recipm1_alphas_cumprod,
+ * posterior_mean_coef1, posterior_mean_coef2, model_variance (FIXED_LARGE, :316-329), model_log_variance,
+ * alphas_cumprod, alphas_cumprod_prev  -- i.e. what _extract_into_tensor (:1331-1344) would upload per call.
+ * t: (N) int64 indices into those tables.  E = elements per sample.
+ * ---------------------------------------------------------------------------------------------- */
+/* Counter-based N(0,1): element i depends only on (seed, offset+i) (Philox4x32-10 + Box-Muller).
+ * Replaces th.randn / th.randn_like at :846, :699, :715, :944, :512. */
+int rgm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+/* p_mean_variance + condition_mean + p_sample update (:252-357, :402-407, :698-703):
+ *   x0 = c1 x - c2 eps (clip) ; mean = pc1 x0 + pc2 x (+ var * grad) ; sample = mean + [t > t_end] exp(.5 logvar) noise.
+ * grad / noise may be NULL (noise NULL -> sample = mean).  g_out (N) or NULL receives exp(.5 logvar). */
+int rgm_ddpm_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
+                  const float* const* tables_host, int clip_denoised, int t_end, float* sample, float* pred_xstart,
+                  float* g_out, int N, int E, void* stream);
+/* ddim_sample (:881-952) incl. condition_score (:467-489) when grad != NULL; g_out receives sigma. */
+int rgm_ddim_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
+                  const float* const* tables_host, int clip_denoised, int t_end, float eta, float* sample,
+                  float* pred_xstart, float* g_out, int N, int E, void* stream);
+/* scg_sample candidate expansion (:509-514): cand[k][b] = mean[b] + g[b] * noise[k][b], k < n. */
+int rgm_scg_candidates(const float* mean, const float* g, const float* noise, float* cand, int n, int B, int E,
+                       void* stream);
+/* _predict_xstart_from_eps (:359-364) times out_scale (the 1/scale_factor of _decode :1350). */
+int rgm_xstart_from_eps(const float* x, const float* eps, const int64_t* t, const float* const* tables_host,
+                        float out_scale, float* out, int N, int E, void* stream);
+/* scg_sample selection (:539-554): max_ind[b] = first argmax_k total[k][b]; out[b] = cand[max_ind[b]][b].
+ * cand and out may both be NULL (index only); max_ind may be NULL. */
+int rgm_scg_select(const float* cand, const float* total_logp, float* out, int64_t* max_ind, int n, int B, int E,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * taming KL-VAE decoder (f8-all-onset config)            taming/models/klvae_pedal.py:80-85,
+ *                                                        taming/modules/diffusionmodules/model.py:436-537
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct rgm_vae rgm_vae;
+int rgm_vae_create(rgm_vae** out);
+void rgm_vae_destroy(rgm_vae* h);
+/* key as in the Lightning checkpoint's ["state_dict"] ("decoder.*", "post_quant_conv.*"; klvae_pedal.py:50-59).
+ * 3x3 conv weights are repacked to [cout][tap][cin] on the device.  Other prefixes (encoder., loss., quant_conv.)
+ * are not part of the decode path: query with rgm_vae_has_param and skip them (strict=False semantics). */
+int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, const int64_t* shape, int ndim);
+int rgm_vae_has_param(rgm_vae* h, const char* key);
+int rgm_vae_missing_params(rgm_vae* h);
+size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M /* number of 16x16 latent squares */);
+/* AutoencoderKL.decode(z): z (M,4,16,16) -> out (M,3,128,128). */
+int rgm_vae_decode(rgm_vae* h, const float* z, float* out, int M, void* ws, size_t ws_bytes, void* stream);
+/* _decode (gaussian_diffusion.py:1347-1358) fused: latent (N,4,H,16) * inv_scale -> H/16 squares per sample ->
+ * roll (N,3,128,8H) float32 (may be NULL) and/or roll_u8 (N,128,8H,3) uint8 with the background threshold and
+ * truncating cast of decode_sample_for_midi (midi_util.py:59-63) (may be NULL). */
+int rgm_vae_decode_latent(rgm_vae* h, const float* latent, float inv_scale, float* roll, uint8_t* roll_u8,
+                          float threshold, int N, int H, void* ws, size_t ws_bytes, void* stream);
+/* midi_util.py:59-63 on an existing roll: (B,3,128,T) float32 -> (B,128,T,3) uint8. */
+int rgm_quantise_roll(const float* roll, uint8_t* out_u8, int B, int T, float threshold, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Rule programs (FUNC_DICT / LOSS_DICT built-ins)        music_rule_guidance/music_rules.py, rule_maps.py
+ * roll (N,C,128,T) float32, channel 0 is read AND WRITTEN (piano_like mask / background threshold, like the
+ * reference's in-place view writes).
+ * ---------------------------------------------------------------------------------------------- */
+/* total_pitch_class_histogram (:29-43): out (N,12); scratch N*128 floats. */
+int rgm_rule_pitch_hist(float* roll, float* out, float* scratch, int N, int C, int T, void* stream);
+/* note_density (:46-83): out (N, 2*T/interval) = [vertical..., horizontal...]; interval divides 256 and T. */
+int rgm_rule_note_density(float* roll, float* out, int N, int C, int T, int interval, float hscale, void* stream);
+/* torch.bucketize(v, bounds) as used by note_density_class (:86-94): out int64. */
+int rgm_bucketize(const float* v, const float* bounds, int nb, int64_t* out, int n, void* stream);
+/* mse_loss_mean / zero_one_loss_mean (rule_maps.py:17-22) over the last dim: a,b (rows,K) -> out (rows). */
+int rgm_row_loss(const float* a, const float* b, float* out, int rows, int K, int zero_one, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py roofline leg): with profiling on, every GEMM launch is bracketed by two
+ * hipEvents recorded on the launch stream.  kernel ids: 1..4 = dense tiles 128x128 / 128x64 / 64x64 /
+ * 32x128, 11..14 = the same tiles with the implicit 3x3-conv loader.
+ * ---------------------------------------------------------------------------------------------- */
+int rgm_prof_enable(int on);
+int rgm_prof_reset(void);
+int rgm_prof_report(int kernel, int* launches, double* total_ms, double* total_flops);
+
+/* ------------------------------------------------------------------------------------------------
+ * DiffCollage long-sequence composition                   diff_collage/w_img.py, condind_long.py, condind_circle.py
+ * ---------------------------------------------------------------------------------------------- */
+/* split_wimg (:8-24): img (B,C,h,W) -> wins (B*n,C,h,128), window i at columns [i*(128-overlap), +128), read
+ * circularly (column >= W wraps) so the circular variant needs no concatenated copy.  halves (B*n,C,h,overlap)
+ * or NULL receives the right `overlap` columns of every window (input of the half-window eps call). */
+int rgm_collage_split(const float* img, float* wins, float* halves, int B, int C, int h, int W, int n, int overlap,
+                      void* stream);
+/* get_eps_t_fn tail (condind_long.py:36-50 / condind_circle.py:57-82): out = fold-sum of full_i minus half_i
+ * (i < n-1) on the right overlaps; circle != 0 averages the wrapped seam; is_avg divides by the coverage
+ * count (avg_merge_wimg is_avg=True).  half may be NULL (plain merge). */
+int rgm_collage_merge(const float* full, const float* half, float* out, int B, int C, int h, int n, int overlap,
+                      int circle, int is_avg, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,7 @@ namespace rgm {
 // per strip spill the scalar file): exp2 of the product x*log2(e) carried in two floats, ~1-2 ulp.
 __device__ __forceinline__ float exp_neg(float x) {
   const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+  x = fmaxf(x, -104.0f);   // masked scores are -inf: (-inf)*c + inf would be NaN below; 2^-150 flushes to exactly 0
   const float t = x * L2E_HI;
   float r = fmaf(x, L2E_HI, -t);
   r = fmaf(x, L2E_LO, r);

@@ -24,6 +24,7 @@
 //     serves a contiguous band of tiles, rastered in groups of 8 M-tiles so co-resident blocks share
 //     A / B panels;
 //   * fused epilogue: bias, SiLU / GELU(tanh), adaLN gate, residual add (in place allowed).
+#include <vector>
 #include "common.h"
 
 namespace rgm {
@@ -192,16 +193,37 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
   }
 }
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg)
+struct ProfRec {
+  hipEvent_t a, b;
+  int tile;
+  double flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
 template <int BM, int BN, int WM, int WN>
-static int launch_cfg(const GemmParams& p, hipStream_t s) {
+static int launch_cfg(const GemmParams& p, hipStream_t s, int tile_id) {
   const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
   dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64);
+  ProfRec rec{};
+  if (g_prof_on) {
+    RGM_CHECK_HIP(hipEventCreate(&rec.a));
+    RGM_CHECK_HIP(hipEventCreate(&rec.b));
+    rec.tile = tile_id + (p.aload ? 10 : 0);
+    rec.flops = 2.0 * p.M * (double)p.N * p.K * p.batch;
+    RGM_CHECK_HIP(hipEventRecord(rec.a, s));
+  }
   if (p.aload == 0)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0>), grid, block, lds, s, p, tm, tn);
   else
     hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1>), grid, block, lds, s, p, tm, tn);
   RGM_LAUNCH_CHECK();
+  if (g_prof_on) {
+    RGM_CHECK_HIP(hipEventRecord(rec.b, s));
+    g_prof.push_back(rec);
+  }
   return RGM_OK;
 }
 
@@ -232,10 +254,10 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
     }
   }
   switch (tile) {
-    case 1: return launch_cfg<128, 128, 2, 2>(p, s);
-    case 2: return launch_cfg<128, 64, 2, 2>(p, s);
-    case 3: return launch_cfg<64, 64, 2, 2>(p, s);
-    case 4: return launch_cfg<32, 128, 1, 4>(p, s);
+    case 1: return launch_cfg<128, 128, 2, 2>(p, s, 1);
+    case 2: return launch_cfg<128, 64, 2, 2>(p, s, 2);
+    case 3: return launch_cfg<64, 64, 2, 2>(p, s, 3);
+    case 4: return launch_cfg<32, 128, 1, 4>(p, s, 4);
     default: break;
   }
   set_error("gemm: unknown tile %d", tile);
@@ -243,3 +265,36 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
 }
 
 }  // namespace rgm
+
+// Profiling hooks: with profiling on, every GEMM launch is bracketed by two hipEvents on ITS stream.
+// kernel ids: 1..4 = dense tiles (128x128, 128x64, 64x64, 32x128), 11..14 = the same tiles with the implicit-conv loader.
+extern "C" int rgm_prof_enable(int on) {
+  rgm::g_prof_on = on != 0;
+  return RGM_OK;
+}
+extern "C" int rgm_prof_reset(void) {
+  for (auto& r : rgm::g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  rgm::g_prof.clear();
+  return RGM_OK;
+}
+// sums over the recorded launches of kernel id `kernel`: launches, total milliseconds, total algorithmic FLOPs (2MNK)
+extern "C" int rgm_prof_report(int kernel, int* launches, double* total_ms, double* total_flops) {
+  int n = 0;
+  double ms = 0.0, fl = 0.0;
+  for (auto& r : rgm::g_prof) {
+    if (r.tile != kernel) continue;
+    RGM_CHECK_HIP(hipEventSynchronize(r.b));
+    float e = 0.f;
+    RGM_CHECK_HIP(hipEventElapsedTime(&e, r.a, r.b));
+    ms += e;
+    fl += r.flops;
+    ++n;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  return RGM_OK;
+}

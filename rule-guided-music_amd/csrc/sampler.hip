@@ -1,0 +1,247 @@
+// sampler.hip -- the per-step elementwise work of the DDPM / DDIM / SCG sampler, fused.
+//
+// Reference: guided_diffusion/gaussian_diffusion.py
+//   :359-364 _predict_xstart_from_eps, :380-385 _predict_eps_from_xstart, :228-250 q_posterior_mean_variance
+//   :252-357 p_mean_variance (EPSILON mean, FIXED_LARGE variance), :387-407 condition_mean,
+//   :467-489 condition_score, :635-735 p_sample, :881-976 ddim_sample, :491-554 scg_sample
+//   (candidate expansion :509-514, argmax-select :539-554), :1331-1344 _extract_into_tensor.
+//
+// The reference issues ~12 tiny ATen launches and ~10 host->device table uploads per step; here a
+// step is ONE launch over the latent (32 KiB per sample -- pure launch-latency territory), with the
+// float32-cast schedule tables resident on the device and indexed by the per-sample timestep.
+// Noise comes from a counter-based Philox4x32-10 stream (seed, offset): every rank of a multi-GPU
+// SCG run can regenerate any candidate's noise without communication.
+#include "common.h"
+
+namespace rgm {
+
+// ------------------------------------------------------------------------------------- philox
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  c[1] = (uint32_t)p1;
+  c[3] = (uint32_t)p0;
+  c[0] = n0;
+  c[2] = n2;
+}
+
+__device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint32_t (&out)[4]) {
+  uint32_t c[4] = {(uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) out[i] = c[i];
+}
+
+// out[i] ~ N(0,1); element i is a pure function of (seed, offset + i): counter = (offset+i)/4, lane (offset+i)%4
+__global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset) {
+  const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;  // one Philox block = 4 normals
+  const uint64_t first = offset >> 2;
+  const long long nblk = (long long)(((offset + (uint64_t)n + 3) >> 2) - first);
+  if (q >= nblk) return;
+  uint32_t r[4];
+  philox4x32_10(first + (uint64_t)q, seed, r);
+  float z[4];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // Box-Muller on (0,1] x [0,1)
+    const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
+    const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincosf(6.283185307179586f * u2, &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const long long g = (long long)((first + (uint64_t)q) * 4 + j) - (long long)offset;
+    if (g >= 0 && g < n) out[g] = z[j];
+  }
+}
+
+// ------------------------------------------------------------------------------------- steps
+struct StepTables {          // device float32 copies of the float64 schedule tables (len T')
+  const float* sqrt_recip_ac;
+  const float* sqrt_recipm1_ac;
+  const float* post_c1;
+  const float* post_c2;
+  const float* var;           // FIXED_LARGE variance
+  const float* logvar;
+  const float* ac;
+  const float* ac_prev;
+};
+
+// DDPM ancestral step.  One thread per element; E = elements per sample.
+//   x0 = c1*x - c2*eps (clip) ; mean = pc1*x0 + pc2*x (+ var*grad) ; sample = mean + [t>t_end]*exp(.5 logvar)*noise
+// noise == nullptr -> sample = mean (SCG: candidates are drawn by scg_candidates instead).
+__global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ grad,
+                                 const float* __restrict__ noise, const int64_t* __restrict__ t, StepTables tb, int clip,
+                                 int t_end, float* __restrict__ sample, float* __restrict__ pred_xstart,
+                                 float* __restrict__ g_out, long long total, int E) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / E);
+  const int ti = (int)t[b];
+  const float xv = x[i];
+  float x0 = tb.sqrt_recip_ac[ti] * xv - tb.sqrt_recipm1_ac[ti] * eps[i];
+  if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  float mean = tb.post_c1[ti] * x0 + tb.post_c2[ti] * xv;
+  if (grad) mean = mean + tb.var[ti] * grad[i];
+  const float g = expf(0.5f * tb.logvar[ti]);
+  float s = mean;
+  if (noise) s = mean + (ti > t_end ? 1.f : 0.f) * g * noise[i];
+  sample[i] = s;
+  pred_xstart[i] = x0;
+  if (g_out && (i % E) == 0) g_out[b] = g;
+}
+
+// DDIM step (eta general; the CLI always runs eta = 1).  grad != nullptr applies condition_score first.
+__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps_in, const float* __restrict__ grad,
+                                 const float* __restrict__ noise, const int64_t* __restrict__ t, StepTables tb, int clip,
+                                 int t_end, float eta, float* __restrict__ sample, float* __restrict__ pred_xstart,
+                                 float* __restrict__ g_out, long long total, int E) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int b = (int)(i / E);
+  const int ti = (int)t[b];
+  const float xv = x[i];
+  const float c1 = tb.sqrt_recip_ac[ti], c2 = tb.sqrt_recipm1_ac[ti];
+  const float ab = tb.ac[ti], abp = tb.ac_prev[ti];
+  float x0 = c1 * xv - c2 * eps_in[i];
+  if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  if (grad) {
+    float e = (c1 * xv - x0) / c2;
+    e = e - sqrtf(1.f - ab) * grad[i];
+    x0 = c1 * xv - c2 * e;
+  }
+  const float e2 = (c1 * xv - x0) / c2;
+  const float sigma = eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+  const float mean = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * e2;
+  float s = mean;
+  if (noise) s = mean + (ti != t_end ? 1.f : 0.f) * sigma * noise[i];
+  sample[i] = s;
+  pred_xstart[i] = x0;
+  if (g_out && (i % E) == 0) g_out[b] = sigma;
+}
+
+// cand[k][b][:] = mean[b][:] + g[b] * noise[k][b][:]   (gaussian_diffusion.py:509-514); k in [0, n_local)
+__global__ void scg_candidates_kernel(const float* __restrict__ mean, const float* __restrict__ g,
+                                      const float* __restrict__ noise, float* __restrict__ cand, int n, int B, int E) {
+  const long long total = (long long)n * B * E;
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long be = i % ((long long)B * E);
+  cand[i] = mean[be] + g[be / E] * noise[i];
+}
+
+// x0 = c1[t]*x - c2[t]*eps  (optionally * inv_scale: the 1/scale_factor of _decode :1350)
+__global__ void xstart_from_eps_kernel(const float* __restrict__ x, const float* __restrict__ eps,
+                                       const int64_t* __restrict__ t, StepTables tb, float out_scale,
+                                       float* __restrict__ out, long long total, int E) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ti = (int)t[i / E];
+  out[i] = (tb.sqrt_recip_ac[ti] * x[i] - tb.sqrt_recipm1_ac[ti] * eps[i]) * out_scale;
+}
+
+// max_ind[b] = first argmax_k total[k][b] ; out[b][:] = cand[max_ind[b]][b][:]   (:539-554)
+__global__ void scg_select_kernel(const float* __restrict__ cand, const float* __restrict__ total, float* __restrict__ out,
+                                  int64_t* __restrict__ max_ind, int n, int B, int E) {
+  const int b = blockIdx.y;
+  int best = 0;
+  float bv = total[b];
+  for (int k = 1; k < n; ++k) {
+    const float v = total[(long long)k * B + b];
+    if (v > bv) { bv = v; best = k; }   // strict '>' keeps the FIRST maximum (torch argmax tie-break)
+  }
+  // NaN handling: torch.argmax treats NaN as maximal; reproduce (first NaN wins)
+  for (int k = 0; k < n; ++k)
+    if (total[(long long)k * B + b] != total[(long long)k * B + b]) { best = k; break; }
+  if (cand && out) {
+    const float* src = cand + ((long long)best * B + b) * E;
+    float* dst = out + (long long)b * E;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E; i += gridDim.x * blockDim.x) dst[i] = src[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && max_ind) max_ind[b] = best;
+}
+
+}  // namespace rgm
+
+using namespace rgm;
+
+static StepTables make_tables(const float* const* tabs) {
+  StepTables t;
+  t.sqrt_recip_ac = tabs[0];
+  t.sqrt_recipm1_ac = tabs[1];
+  t.post_c1 = tabs[2];
+  t.post_c2 = tabs[3];
+  t.var = tabs[4];
+  t.logvar = tabs[5];
+  t.ac = tabs[6];
+  t.ac_prev = tabs[7];
+  return t;
+}
+
+extern "C" int rgm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+  RGM_REQUIRE(out && n >= 0, "randn: bad arguments");
+  if (n == 0) return RGM_OK;
+  const long long nblk = (long long)(((offset + (uint64_t)n + 3) >> 2) - (offset >> 2));
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, seed, offset);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_ddpm_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
+                             const float* const* tables, int clip_denoised, int t_end, float* sample, float* pred_xstart,
+                             float* g_out, int N, int E, void* stream) {
+  RGM_REQUIRE(x && eps && t && tables && sample && pred_xstart && N > 0 && E > 0, "ddpm_step: bad arguments");
+  const long long total = (long long)N * E;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, grad,
+                     noise, t, make_tables(tables), clip_denoised, t_end, sample, pred_xstart, g_out, total, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_ddim_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
+                             const float* const* tables, int clip_denoised, int t_end, float eta, float* sample,
+                             float* pred_xstart, float* g_out, int N, int E, void* stream) {
+  RGM_REQUIRE(x && eps && t && tables && sample && pred_xstart && N > 0 && E > 0, "ddim_step: bad arguments");
+  const long long total = (long long)N * E;
+  hipLaunchKernelGGL(ddim_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, grad,
+                     noise, t, make_tables(tables), clip_denoised, t_end, eta, sample, pred_xstart, g_out, total, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_scg_candidates(const float* mean, const float* g, const float* noise, float* cand, int n, int B, int E,
+                                  void* stream) {
+  RGM_REQUIRE(mean && g && noise && cand && n > 0 && B > 0 && E > 0, "scg_candidates: bad arguments");
+  const long long total = (long long)n * B * E;
+  hipLaunchKernelGGL(scg_candidates_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, g, noise, cand, n, B, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_xstart_from_eps(const float* x, const float* eps, const int64_t* t, const float* const* tables,
+                                   float out_scale, float* out, int N, int E, void* stream) {
+  RGM_REQUIRE(x && eps && t && tables && out && N > 0 && E > 0, "xstart_from_eps: bad arguments");
+  const long long total = (long long)N * E;
+  hipLaunchKernelGGL(xstart_from_eps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, t,
+                     make_tables(tables), out_scale, out, total, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_scg_select(const float* cand, const float* total_logp, float* out, int64_t* max_ind, int n, int B, int E,
+                              void* stream) {
+  RGM_REQUIRE(total_logp && n > 0 && B > 0 && E > 0 && ((cand == nullptr) == (out == nullptr)), "scg_select: bad arguments");
+  hipLaunchKernelGGL(scg_select_kernel, dim3(cdiv(E, 1024) > 64 ? 64 : cdiv(E, 1024), B), dim3(256), 0, (hipStream_t)stream, cand,
+                     total_logp, out, max_ind, n, B, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}

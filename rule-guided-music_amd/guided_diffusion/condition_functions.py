@@ -1,0 +1,80 @@
+"""eps-network adapters and classifier-gradient cond_fns -- reference API
+(guided_diffusion/condition_functions.py:17-42, :58-85, :149-174).
+
+model_fn / dc_model_fn are thin: class-conditional call, null label (= num_classes) when unconditional,
+classifier-free guidance as two forwards.  The grad_nn_zt_* guidance functions call the classifier's
+fused value-and-input-gradient kernel chain (no autograd graph; weights are frozen at sampling time).
+DPS variants (nn_z0_*, rule_x0_*) are a 'next' row.
+"""
+import torch as th
+import torch.nn as nn
+
+
+def _null_labels(x, num_classes):
+    return th.full((x.shape[0],), num_classes, dtype=th.int64, device=x.device)
+
+
+def model_fn(x, t, y=None, rule=None, model=nn.Identity(), num_classes=3, class_cond=True, cfg=False, w=0.):
+    """`rule` is a dummy argument (model_kwargs carries it for the cond_fn / SCG)."""
+    if not class_cond:
+        return model(x, t, _null_labels(x, num_classes))
+    if cfg:
+        return (1 + w) * model(x, t, y) - w * model(x, t, _null_labels(x, num_classes))
+    return model(x, t, y)
+
+
+def dc_model_fn(x, t, y=None, rule=None, model=nn.Identity(), num_classes=3, class_cond=True, cfg=False, w=0.):
+    """DiffCollage eps functions work on (4, pitch, time); the sampler's latents are (4, time, pitch)."""
+    xt = x.permute(0, 1, 3, 2)
+    if not class_cond:
+        return model(xt, t, _null_labels(xt, num_classes)).permute(0, 1, 3, 2)
+    if cfg:
+        eps = (1 + w) * model(xt, t, y) - w * model(xt, t, _null_labels(xt, num_classes))
+        return eps.permute(0, 1, 3, 2)
+    return model(xt, t, y).permute(0, 1, 3, 2)
+
+
+def _value_and_grad(classifier, x, t, target, loss_kind, scale):
+    if not hasattr(classifier, "value_and_grad"):
+        raise NotImplementedError("classifier guidance needs a native DiTRotaryClassifier (value_and_grad)")
+    return classifier.value_and_grad(x, t, target, loss_kind, scale)[1]
+
+
+def grad_nn_zt_mse(x, t, y=None, rule=None, classifier_scale=10., classifier=nn.Identity()):
+    """grad_x of -sum((classifier(x,t) - rule)^2), times classifier_scale."""
+    assert rule is not None
+    return _value_and_grad(classifier, x, t, rule, "mse", classifier_scale)
+
+
+def grad_nn_zt_chord(x, t, y=None, rule=None, classifier_scale=10., classifier=nn.Identity(), both=False):
+    """grad_x of -sum CE(chord_logits, rule), times classifier_scale."""
+    assert rule is not None
+    if both:
+        raise NotImplementedError("both=True (key + chord) is unused by the shipped configs")
+    return _value_and_grad(classifier, x, t, rule, "chord_ce", classifier_scale)
+
+
+def _dps(*a, **k):
+    raise NotImplementedError("DPS guidance (nn_z0_* / rule_x0_*) is a 'next' row: SURVEY 8f.1")
+
+
+function_map = {
+    "grad_nn_zt_mse": grad_nn_zt_mse,
+    "grad_nn_zt_chord": grad_nn_zt_chord,
+    "nn_z0_chord_dummy": _dps, "nn_z0_mse_dummy": _dps, "nn_z0_mse": _dps,
+    "rule_x0_mse_dummy": _dps, "rule_x0_mse": _dps,
+}
+
+
+def composite_nn_zt(x, t, y=None, rule=None, fns=None, classifier_scales=None, classifiers=None, rule_names=None):
+    out = 0
+    for fn, scale, cls, name in zip(fns, classifier_scales, classifiers, rule_names):
+        out = out + function_map[fn](x, t, y=y, rule=rule[name], classifier_scale=scale, classifier=cls)
+    return out
+
+
+def composite_rule(x, t, y=None, rule=None, fns=None, classifier_scales=None, rule_names=None):
+    out = 0
+    for fn, scale, name in zip(fns, classifier_scales, rule_names):
+        out = out + function_map[fn](x, t, y=y, rule=rule[name], rule_name=name) * scale
+    return out

@@ -1,0 +1,100 @@
+"""Config loading, final decode to the uint8 piano roll and rule-loss reporting -- reference API
+(guided_diffusion/midi_util.py:26-64, :96-124).  MIDI writing / plotting of the reference need mido +
+the vendored pretty_midi fork (pure I/O, out of scope); save_piano_roll_midi stores .npy rolls instead and
+hands over to an optional user hook."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pandas as pd
+import torch
+import yaml
+
+from music_rule_guidance.rule_maps import FUNC_DICT, LOSS_DICT
+from music_rule_guidance.music_rules import MAX_PIANO, MIN_PIANO  # noqa: F401  (re-exported like the reference)
+from rgm import native as _rgm
+
+
+def dict_to_obj(d):
+    """Nested dicts -> attribute namespaces (lists keep their element types)."""
+    if isinstance(d, list):
+        return [dict_to_obj(x) if isinstance(x, dict) else x for x in d]
+    if isinstance(d, dict):
+        return SimpleNamespace(**{k: dict_to_obj(v) for k, v in d.items()})
+    return d
+
+
+def load_config(filename):
+    with open(filename, "r") as f:
+        return dict_to_obj(yaml.safe_load(f))
+
+
+@torch.no_grad()
+def decode_sample_for_midi(sample, embed_model=None, scale_factor=1., threshold=-0.95):
+    """Latent batch -> uint8 piano roll (B, 128, T, 3) in [0, 127].
+
+    With the native AutoencoderKL the whole chain (1/scale_factor, square gather, decoder, background
+    threshold, (x+1)*63.5 clamp, truncating cast, layout change) is one decode call; other embed models are
+    driven through tensor views and only the final quantisation runs in the HIP kernel."""
+    if embed_model is not None and hasattr(embed_model, "decode_latent") and sample.shape[-2] >= sample.shape[-1]:
+        return embed_model.decode_latent(sample, scale_factor, want_u8=True, threshold=threshold, want_float=False)
+    sample = sample / scale_factor
+    if embed_model is not None:
+        h, w = sample.shape[-2:]
+        if h > w:
+            sample = sample.permute(0, 1, 3, 2)
+        n_lat = sample.shape[-1] // sample.shape[-2]
+        if h >= w:
+            sample = torch.cat(torch.chunk(sample, n_lat, dim=-1), dim=0)
+        sample = embed_model.decode(sample)
+        if h >= w:
+            sample = torch.cat(torch.chunk(sample, n_lat, dim=0), dim=-1)
+    _rgm.require_cuda(sample)
+    roll = sample.to(torch.float32).contiguous()
+    B, Cc, P, T = roll.shape
+    assert Cc == 3 and P == 128, "quantise kernel expects (B,3,128,T)"
+    out = torch.empty((B, 128, T, 3), dtype=torch.uint8, device=roll.device)
+    with torch.cuda.device(roll.device):
+        _rgm.check(_rgm.lib.rgm_quantise_roll(_rgm.ptr(roll), _rgm.ptr(out), B, T, float(threshold), _rgm.current_stream()))
+    return out
+
+
+_MIDI_WRITER = None
+
+
+def register_midi_writer(fn):
+    """fn(piano_roll_uint8 (C,128,T), path, fs) -- plug in a MIDI writer (the reference uses its pretty_midi fork)."""
+    global _MIDI_WRITER
+    _MIDI_WRITER = fn
+
+
+def save_piano_roll_midi(sample, save_dir, fs=100, y=None, save_piano_roll=False, save_ind=0):
+    """sample: (B, 3, 128, T) uint8 array.  Writes one file per sample (names as in the reference)."""
+    os.makedirs(save_dir, exist_ok=True)
+    for i in range(sample.shape[0]):
+        stem = f"sample_{i + save_ind}" + (f"_y_{int(y[i])}" if y is not None else "")
+        if _MIDI_WRITER is not None:
+            _MIDI_WRITER(sample[i], os.path.join(save_dir, stem + ".midi"), fs)
+        else:
+            np.save(os.path.join(save_dir, stem + ".npy"), sample[i])
+
+
+def eval_rule_loss(generated_samples, target_rules):
+    """DataFrame with <rule>.target_rule / .gen_rule / .loss columns, one row per sample."""
+    results = {}
+    B = generated_samples.shape[0]
+    for name, target in target_rules.items():
+        tl = target.tolist()
+        results[name + ".target_rule"] = [tl] if B == 1 else tl
+        target = target.to(generated_samples.device)
+        if "chord" in name:
+            gen, key, corr = FUNC_DICT[name](generated_samples, return_key=True)
+            results[name + ".key_str"] = list(key)
+            results[name + ".key_corr"] = corr
+        else:
+            gen = FUNC_DICT[name](generated_samples)
+        loss = LOSS_DICT[name](gen, target)
+        gl = gen.tolist()
+        results[name + ".gen_rule"] = [gl] if B == 1 else gl
+        results[name + ".loss"] = loss.tolist() if loss.dim() else [loss.item()]
+    return pd.DataFrame(results)

@@ -35,6 +35,30 @@ def _load():
         "rgm_gemm_tile": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
         "rgm_layernorm_modulate": (C.c_int, [vp, vp, i32, i32, f32, vp, vp, vp, vp, i32, i32, vp]),
         "rgm_rotary_attention": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "rgm_randn": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_uint64, vp]),
+        "rgm_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp]),
+        "rgm_ddim_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, i32, vp]),
+        "rgm_scg_candidates": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+        "rgm_xstart_from_eps": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, i32, vp]),
+        "rgm_scg_select": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+        "rgm_vae_create": (C.c_int, [C.POINTER(vp)]),
+        "rgm_vae_destroy": (None, [vp]),
+        "rgm_vae_set_param": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]),
+        "rgm_vae_has_param": (C.c_int, [vp, C.c_char_p]),
+        "rgm_vae_missing_params": (C.c_int, [vp]),
+        "rgm_vae_workspace_bytes": (sz, [vp, i32]),
+        "rgm_vae_decode": (C.c_int, [vp, vp, vp, i32, vp, sz, vp]),
+        "rgm_vae_decode_latent": (C.c_int, [vp, vp, f32, vp, vp, f32, i32, i32, vp, sz, vp]),
+        "rgm_quantise_roll": (C.c_int, [vp, vp, i32, i32, f32, vp]),
+        "rgm_rule_pitch_hist": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+        "rgm_rule_note_density": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, vp]),
+        "rgm_bucketize": (C.c_int, [vp, vp, i32, vp, i32, vp]),
+        "rgm_row_loss": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+        "rgm_collage_split": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+        "rgm_collage_merge": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+        "rgm_prof_enable": (C.c_int, [i32]),
+        "rgm_prof_reset": (C.c_int, []),
+        "rgm_prof_report": (C.c_int, [i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)            # AttributeError here == header/library mismatch: fail loudly

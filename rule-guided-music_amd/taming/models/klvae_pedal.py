@@ -1,0 +1,138 @@
+"""AutoencoderKL (decode side) -- reference API (taming/models/klvae_pedal.py:17-85), native MI355X decoder.
+
+Owns the parameters of `post_quant_conv` and `decoder.*` under the SAME state_dict keys as the reference's
+Lightning checkpoint (weights under ckpt["state_dict"]; prefixes decoder. / post_quant_conv. / encoder. /
+quant_conv. / loss.), loads them with strict=False like init_from_ckpt, and decodes through librgm_hip.so:
+    decode(z)            (M,4,16,16) -> (M,3,128,128)                       [AutoencoderKL.decode]
+    decode_latent(x, s)  (N,4,H,16)/s -> (N,3,128,8H)  fused _decode        [gaussian_diffusion._decode]
+    decode_latent_u8(..) same, straight to the uint8 (N,128,8H,3) roll      [midi_util.decode_sample_for_midi]
+The encoder / training parts of the reference class are out of scope of the sampling path.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from rgm import native as _rgm
+from rgm.synth import vae_decoder_param_shapes
+
+
+def _attach(root, dotted, param):
+    *path, leaf = dotted.split(".")
+    mod = root
+    for name in path:
+        nxt = mod._modules.get(name)
+        if nxt is None:
+            nxt = nn.Module()
+            mod.add_module(name, nxt)
+        mod = nxt
+    mod.register_parameter(leaf, param)
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self, ddconfig=None, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
+                 colorize_nlabels=None, monitor=None):
+        super().__init__()
+        dd = dict(ch=128, ch_mult=(1, 2, 2, 4), num_res_blocks=2, z_channels=4, out_ch=3, attn_resolutions=[])
+        dd.update({k: v for k, v in dict(ddconfig or {}).items() if k in dd})
+        if (dd["ch"], tuple(dd["ch_mult"]), dd["num_res_blocks"], dd["z_channels"], dd["out_ch"], list(dd["attn_resolutions"])) \
+                != (128, (1, 2, 2, 4), 2, 4, 3, []):
+            raise NotImplementedError("the native decoder implements the kl/f8-all-onset config (ch 128, mult 1-2-2-4)")
+        self.embed_dim = embed_dim
+        for key, shape in vae_decoder_param_shapes():
+            p = nn.Parameter(torch.empty(shape))
+            with torch.no_grad():
+                if key.endswith("weight") and len(shape) == 4:
+                    nn.init.kaiming_uniform_(p, a=5 ** 0.5)
+                elif "norm" in key and key.endswith("weight"):
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+            _attach(self, key, p)
+        self._handle, self._dirty, self._ws = None, True, None
+        self.register_load_state_dict_post_hook(lambda m, _: setattr(m, "_dirty", True))
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=list(ignore_keys))
+
+    def init_from_ckpt(self, path, ignore_keys=list()):
+        sd = torch.load(path, map_location="cpu")["state_dict"]
+        sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
+        own = set(self.state_dict().keys())
+        self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)   # encoder./loss. keys are not ours
+        print(f"Restored from {path}")
+
+    def _apply(self, fn, *a, **k):
+        self._dirty = True
+        return super()._apply(fn, *a, **k)
+
+    def _ensure_native(self):
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise _rgm.RgmError("AutoencoderKL.decode runs only on a HIP device; there is no CPU path in the product")
+        if self._handle is None:
+            h = C.c_void_p()
+            with torch.cuda.device(dev):
+                _rgm.check(_rgm.lib.rgm_vae_create(C.byref(h)))
+            self._handle, self._dirty = h, True
+        if self._dirty:
+            torch.cuda.synchronize(dev)
+            with torch.cuda.device(dev):
+                for key, p in self.state_dict().items():
+                    t = p.detach().to(torch.float32).contiguous()
+                    shape = (C.c_int64 * max(t.dim(), 1))(*t.shape)
+                    _rgm.check(_rgm.lib.rgm_vae_set_param(self._handle, key.encode(), _rgm.ptr(t), shape, t.dim()))
+            self._dirty = False
+        return dev
+
+    def _workspace(self, M, dev):
+        need = _rgm.lib.rgm_vae_workspace_bytes(self._handle, M)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._ws, need
+
+    @torch.no_grad()
+    def decode(self, z, octave=False):
+        if octave:
+            raise NotImplementedError("octave re-indexing is unused by the sampling path")
+        _rgm.require_cuda(z)
+        dev = self._ensure_native()
+        z = z.detach().to(torch.float32).contiguous()
+        M = z.shape[0]
+        assert tuple(z.shape[1:]) == (4, 16, 16), "the decoder consumes 16x16 latent squares"
+        out = torch.empty((M, 3, 128, 128), dtype=torch.float32, device=dev)
+        ws, need = self._workspace(M, dev)
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_vae_decode(self._handle, _rgm.ptr(z), _rgm.ptr(out), M, _rgm.ptr(ws), need, _rgm.current_stream()))
+        return out
+
+    @torch.no_grad()
+    def decode_latent(self, latent, scale_factor=1., want_u8=False, threshold=-0.95, want_float=True):
+        """(N,4,H,16) latent -> (N,3,128,8H) roll [and/or (N,128,8H,3) uint8], squares gathered in-kernel."""
+        _rgm.require_cuda(latent)
+        dev = self._ensure_native()
+        latent = latent.detach().to(torch.float32).contiguous()
+        N, Cc, H, W = latent.shape
+        assert Cc == 4 and W == 16 and H % 16 == 0, f"latent must be (N,4,16k,16), got {tuple(latent.shape)}"
+        roll = torch.empty((N, 3, 128, 8 * H), dtype=torch.float32, device=dev) if want_float else None
+        u8 = torch.empty((N, 128, 8 * H, 3), dtype=torch.uint8, device=dev) if want_u8 else None
+        ws, need = self._workspace(N * (H // 16), dev)
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_vae_decode_latent(self._handle, _rgm.ptr(latent), 1.0 / float(scale_factor), _rgm.ptr(roll),
+                                                      _rgm.ptr(u8), float(threshold), N, H, _rgm.ptr(ws), need,
+                                                      _rgm.current_stream()))
+        if want_u8 and want_float:
+            return roll, u8
+        return u8 if want_u8 else roll
+
+    def encode(self, *a, **k):
+        raise NotImplementedError("VAE encoder is a 'next' row (editing / dataset targets): SURVEY 8f.2")
+
+    encode_save = encode
+
+    def __del__(self):
+        try:
+            if self._handle is not None:
+                _rgm.lib.rgm_vae_destroy(self._handle)
+        except Exception:
+            pass

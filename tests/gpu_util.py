@@ -1,0 +1,48 @@
+"""Helpers shared by the -m gpu tests: every call goes through the C ABI (ctypes), never torch math."""
+import ctypes as C
+import numpy as np
+import torch
+
+from rgm import native as R
+
+DEV = "cuda"
+
+
+def dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def gemm(A, B, bias=None, act=0, alpha=1.0, gate=None, rows_per_gate=1, res=None, tile=None):
+    """C = epi(alpha * A @ B.T) through rgm_gemm; numpy in, numpy out."""
+    M, K = A.shape
+    N = B.shape[0]
+    a, b = dev(A), dev(B)
+    c = torch.full((M, N), float("nan"), device=DEV)
+    bb = dev(bias) if bias is not None else None
+    gg = dev(gate) if gate is not None else None
+    if res is not None:
+        c.copy_(dev(res))
+    st = R.current_stream()
+    if tile is None:
+        R.check(R.lib.rgm_gemm(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bb), act, alpha,
+                               R.ptr(gg), gate.shape[1] if gate is not None else 0, rows_per_gate,
+                               R.ptr(c) if res is not None else None, N, st))
+    else:
+        R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bb), act, tile, st))
+    torch.cuda.synchronize()
+    return c.cpu().numpy()
+
+
+def load_module(module, sd_np_or_torch):
+    sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd_np_or_torch.items()}
+    module.load_state_dict(sd, strict=True)
+    return module.to(DEV).eval()

@@ -1,0 +1,103 @@
+"""-m gpu: building-block HIP kernels (through the C ABI) against the numpy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dit_np as odit
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need a HIP device"
+
+
+def _ref_gemm(A, B, bias, act, alpha, gate, rpg, res):
+    y = alpha * (A.astype(np.float64) @ B.astype(np.float64).T)
+    if bias is not None:
+        y = y + bias
+    if act == 1:
+        y = y / (1 + np.exp(-y))
+    elif act == 2:
+        y = 0.5 * y * (1 + np.tanh(np.sqrt(2 / np.pi) * (y + 0.044715 * y ** 3)))
+    if gate is not None:
+        y = y * gate[np.arange(A.shape[0]) // rpg]
+    if res is not None:
+        y = y + res
+    return y
+
+
+@pytest.mark.parametrize("tile", [None, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (513, 1152, 1152), (1000, 3456, 384), (16, 700, 256), (4096, 32, 1152)])
+def test_gemm_asymmetric_data_all_tiles(tile, M, N, K):
+    from gpu_util import gemm, rel
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K).astype(F32)
+    B = (rng.randn(N, K) * (1 + np.arange(N)[:, None] / N)).astype(F32)     # rows of B differ in scale: catches transposes
+    bias = rng.randn(N).astype(F32)
+    out = gemm(A, B, bias=bias, act=0, tile=tile)
+    assert rel(out, _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)) < 2e-6
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_gemm_fused_epilogues(act):
+    from gpu_util import gemm, rel
+    rng = np.random.RandomState(act)
+    M, N, K, T = 3 * 128 + 7, 1152, 1152, 128
+    A = rng.randn(M, K).astype(F32) * 0.5
+    B = rng.randn(N, K).astype(F32) * 0.05
+    bias = rng.randn(N).astype(F32)
+    gate = rng.randn((M + T - 1) // T, N).astype(F32)
+    res = rng.randn(M, N).astype(F32)
+    out = gemm(A, B, bias=bias, act=act, alpha=0.7, gate=gate, rows_per_gate=T, res=res)
+    assert rel(out, _ref_gemm(A, B, bias, act, 0.7, gate, T, res)) < 3e-6
+
+
+@pytest.mark.parametrize("D,affine,mod", [(1152, False, True), (384, False, True), (384, True, False), (768, True, True)])
+def test_layernorm_modulate(D, affine, mod):
+    from gpu_util import dev, rel
+    from rgm import native as R
+    rng = np.random.RandomState(D)
+    N, T = 3, 37
+    x = (rng.randn(N * T, D) * 3 + 1).astype(F32)
+    w, b = (1 + 0.1 * rng.randn(D)).astype(F32), rng.randn(D).astype(F32)
+    modbuf = rng.randn(N, 6 * D).astype(F32)
+    xd, od = dev(x), torch.empty(N * T, D, device="cuda")
+    wd, bd, md = dev(w), dev(b), dev(modbuf)
+    sh = md[:, D:] if mod else None         # views into a strided modulation buffer, like the DiT's
+    R.check(R.lib.rgm_layernorm_modulate(R.ptr(xd), R.ptr(od), N * T, D, 1e-6, R.ptr(wd) if affine else None,
+                                         R.ptr(bd) if affine else None,
+                                         md.data_ptr() + 4 * D if mod else None, md.data_ptr() + 8 * D if mod else None,
+                                         6 * D, T, R.current_stream()))
+    torch.cuda.synchronize()
+    ref = odit.layernorm(x, 1e-6, w if affine else None, b if affine else None).reshape(N, T, D)
+    if mod:
+        ref = ref * (1 + modbuf[:, None, 2 * D:3 * D]) + modbuf[:, None, D:2 * D]
+    assert rel(od.cpu().numpy(), ref.reshape(N * T, D)) < 2e-6
+
+
+@pytest.mark.parametrize("N,T,heads,hd", [(2, 256, 16, 72), (3, 128, 16, 72), (2, 257, 6, 64), (2, 129, 6, 64), (1, 256, 12, 64), (2, 200, 6, 64)])
+def test_rotary_attention(N, T, heads, hd):
+    from gpu_util import dev, rel
+    from rgm import native as R
+    from rgm.synth import rotary_freqs
+    rng = np.random.RandomState(T + hd)
+    D = heads * hd
+    rot = int(hd * 0.5)
+    qkv = (rng.randn(N * T, 3 * D) * 1.5).astype(F32)
+    cos, sin = odit.rotary_tables(rotary_freqs(rot), T)
+    od = torch.full((N * T, D), float("nan"), device="cuda")
+    qd, cd, sd_ = dev(qkv), dev(cos), dev(sin)
+    R.check(R.lib.rgm_rotary_attention(R.ptr(qd), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, rot // 2, R.current_stream()))
+    torch.cuda.synchronize()
+    r = qkv.reshape(N, T, 3, heads, hd)
+    q, k, v = (r[:, :, i].transpose(0, 2, 1, 3).astype(np.float64) for i in range(3))
+    q = odit.apply_rotary(q.astype(F32), cos, sin).astype(np.float64)
+    k = odit.apply_rotary(k.astype(F32), cos, sin).astype(np.float64)
+    s = q @ k.transpose(0, 1, 3, 2) * hd ** -0.5
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v).transpose(0, 2, 1, 3).reshape(N * T, D)
+    assert rel(od.cpu().numpy(), ref) < 3e-6
