@@ -448,8 +448,45 @@ def g_e2e(vae, tag, arch, seed, full_oracle=True):
     save(f"e2e_ddim50_{tag}", seed=np.array(seed), y=y, latent=ref, u8=u8)
 
 
+def g_cli():
+    """Host-side CLI logic of scripts/sample_rule.py: target-rule construction (:170-193, executed from the
+    reference source itself), output directory naming (:42-46) and the argparse defaults (:285-314)."""
+    print("[cli]")
+    import json
+    import yaml
+    from types import SimpleNamespace
+    src = open(os.path.join(ref_shims.REF_ROOT, "scripts", "sample_rule.py")).read().split("\n")
+    body = "\n".join(l[8:] if l.startswith("        ") else l for l in src[170:193])     # lines 171-193 (body of the else:), de-indented
+    out = {}
+    cfgs = {"demo2": {"pitch_hist": [0.5, 0., 0., 0., 0.25, 0., 0., 0.25, 0., 0., 0., 0.], "vertical_nd": [3.] * 8, "horizontal_nd": [15.] * 8},
+            "hr2": {"vertical_nd_hr_2": [1., 2., 3., 4.], "horizontal_nd_hr_2": [4., 6., 8., 10.]},
+            "pitch_only": {"pitch_hist": [2., 0., 1., 0., 0., 1., 0., 0., 0., 0., 0., 0.]}}
+    for tag, tr in cfgs.items():
+        env = {"target_rules": {k: list(v) for k, v in tr.items()}, "th": torch,
+               "dist_util": SimpleNamespace(dev=lambda: "cpu"), "args": SimpleNamespace(batch_size=3)}
+        exec(body, env)
+        for k, v in env["model_kwargs"]["rule"].items():
+            out[f"{tag}.{k}"] = v.numpy()
+        out[f"{tag}.__keys__"] = np.array(list(env["model_kwargs"]["rule"].keys()))
+        out[f"{tag}.__input__"] = np.array(json.dumps(tr))
+    sys.argv = ["sample_rule.py"]
+    sys.path.insert(0, os.path.join(ref_shims.REF_ROOT, "scripts"))
+    import importlib.util
+    sys.modules.setdefault("load_utils", types.ModuleType("load_utils")).load_model = None
+    sys.modules.setdefault("guided_diffusion.pr_datasets_all", types.ModuleType("x"))
+    spec = importlib.util.spec_from_file_location("ref_sample_rule", os.path.join(ref_shims.REF_ROOT, "scripts", "sample_rule.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    parser = mod.create_argparser()
+    defaults = {a.dest: a.default for a in parser._actions if a.dest != "help"}
+    out["argparse_defaults"] = np.array(json.dumps(defaults, sort_keys=True))
+    a = parser.parse_args(["--image_size", "128", "16", "--class_cond", "True", "--clip_denoised", "no"])
+    out["parsed_example"] = np.array(json.dumps({"image_size": a.image_size, "class_cond": a.class_cond, "clip_denoised": a.clip_denoised}))
+    save("cli", **out)
+
+
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "e2e"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -468,6 +505,8 @@ if __name__ == "__main__":
         g_steps(vae)
     if "collage" in which:
         g_collage()
+    if "cli" in which:
+        g_cli()
     if "e2e" in which:
         g_e2e(vae, "sm", SM, 11)
         g_e2e(vae, "xl28", XL28, 1)

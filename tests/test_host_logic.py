@@ -1,0 +1,178 @@
+"""CPU: host-side logic of the product (no HIP calls): schedule tables and re-spacing of the product's
+GaussianDiffusion/SpacedDiffusion against the reference goldens, CLI helpers against the reference's own
+source, YAML configs, and the SCG sharding protocol under world_size-2 gloo."""
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, ROOT, PKG
+
+
+def _diffusion(rs):
+    from guided_diffusion.script_util import create_diffusion
+    return create_diffusion(learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs,
+                            use_kl=False, predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+
+
+def test_product_schedule_tables_bit_exact():
+    g = load_golden("schedule")
+    for tag, rs in (("full", ""), ("ddim50", "ddim50"), ("r250", "250")):
+        d = _diffusion(rs)
+        assert np.array_equal(np.array(d.timestep_map), g[f"{tag}.timestep_map"])
+        for k in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod", "sqrt_recipm1_alphas_cumprod",
+                  "posterior_variance", "posterior_mean_coef1", "posterior_mean_coef2"):
+            assert np.array_equal(getattr(d, k), g[f"{tag}.{k}"]), (tag, k)
+        assert np.array_equal(d._model_variance, g[f"{tag}.model_variance"])
+
+
+def test_space_timesteps_properties():
+    from guided_diffusion.respace import space_timesteps
+    assert space_timesteps(1000, "ddim50") == set(range(0, 1000, 20))
+    assert space_timesteps(1000, "ddim25") == set(range(0, 1000, 40))
+    assert sorted(space_timesteps(1000, "250"))[-3:] == [991, 995, 999]
+    assert space_timesteps(300, [10, 15, 20]) == space_timesteps(300, "10,15,20") and len(space_timesteps(300, "10,15,20")) == 45
+    assert space_timesteps(1000, [1000]) == set(range(1000))
+    with pytest.raises(ValueError):
+        space_timesteps(1000, "ddim37")
+    with pytest.raises(ValueError):
+        space_timesteps(10, "20")
+
+
+def test_guide_schedule_and_wrapped_timestep_map():
+    from guided_diffusion.gaussian_diffusion import guide_schedule
+    assert guide_schedule([749], 750, 0, 1) and not guide_schedule([750], 750, 0, 1)
+    assert guide_schedule([9], 750, 0, 5) and not guide_schedule([8], 750, 0, 5)
+    d = _diffusion("ddim50")
+    seen = {}
+    w = d._wrap_model(lambda x, t, **kw: seen.setdefault("t", t))
+    w(None, torch.tensor([49, 0, 3]))
+    assert seen["t"].tolist() == [980, 0, 60]
+    assert d._wrap_model(w) is w                                   # idempotent, like the reference
+
+
+def _load_cli():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sample_rule_cli", os.path.join(PKG, "scripts", "sample_rule.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def test_cli_target_rules_dirs_and_flags_match_reference():
+    g = load_golden("cli")
+    cli = _load_cli()
+    for tag in ("demo2", "hr2", "pitch_only"):
+        tr = json.loads(str(g[f"{tag}.__input__"]))
+        out = cli.build_target_rules(tr, 3, "cpu")
+        assert list(out.keys()) == [str(k) for k in g[f"{tag}.__keys__"]]
+        for k, v in out.items():
+            assert np.array_equal(v.numpy(), g[f"{tag}.{k}"]), (tag, k)
+    assert cli.output_dir_for("scripts/configs/cond_table/all/scg_classifier_all.yml", 1) == "cond_demo/all/scg_classifier_all_cls_1"
+    assert cli.output_dir_for("scripts/configs/cond_demo/demo2.yml", 2) == "cond_demo/demo2_cls_2"
+    ref = json.loads(str(g["argparse_defaults"]))
+    mine = {a.dest: a.default for a in cli.create_argparser()._actions if a.dest != "help"}
+    for k, v in ref.items():
+        assert k in mine and mine[k] == v, f"flag --{k}: {mine.get(k)!r} vs reference {v!r}"
+    assert set(mine) - set(ref) == {"synthetic_weights", "progress"}
+    a = cli.create_argparser().parse_args(["--image_size", "128", "16", "--class_cond", "True", "--clip_denoised", "no"])
+    assert json.loads(str(g["parsed_example"])) == {"image_size": a.image_size, "class_cond": a.class_cond, "clip_denoised": a.clip_denoised}
+
+
+def test_yaml_configs_follow_the_reference_schema():
+    from guided_diffusion.midi_util import load_config
+    base = os.path.join(PKG, "scripts", "configs")
+    n = 0
+    for dp, _, files in os.walk(base):
+        for f in files:
+            cfg = load_config(os.path.join(dp, f))
+            n += 1
+            assert hasattr(cfg, "target_rules") and hasattr(cfg.guidance, "vae") and hasattr(cfg.guidance, "nn")
+            assert hasattr(cfg.sampling, "use_ddim") and hasattr(cfg.sampling, "diff_collage") and hasattr(cfg.sampling, "t_end")
+            if cfg.guidance.nn:
+                c = cfg.guidance.cond_fn
+                assert len(c.rule_names) == len(c.fns) == len(c.classifier_scales) == len(c.classifiers.names)
+            if getattr(cfg.guidance, "scg", False):
+                assert cfg.scg.num_samples >= 1
+            if cfg.sampling.diff_collage:
+                assert cfg.dc.type in ("linear", "circle") and cfg.dc.overlap_size == 64
+    assert n >= 5
+    cfg = load_config(os.path.join(base, "cond_demo", "demo2.yml"))
+    assert vars(cfg.scg) == {"num_samples": 16, "pitch_hist": 40.0, "note_density": 1.0} and cfg.guidance.cond_fn is None
+
+
+def test_scg_partition_is_contiguous_and_order_preserving():
+    from rgm import scg_shard
+    for n, R in ((16, 1), (16, 2), (16, 4), (16, 8), (4, 2)):
+        blocks = [scg_shard.partition(n, R, r) for r in range(R)]
+        flat = [k for k0, nl, _ in blocks for k in range(k0, k0 + nl)]
+        assert flat == list(range(n)) and all(sh == (R > 1) for _, _, sh in blocks)
+    assert scg_shard.partition(6, 4, 1) == (0, 6, False)           # does not divide -> unsharded
+    t = torch.tensor([[1., 5.], [3., 5.], [3., 2.]])
+    assert scg_shard.first_argmax(t).tolist() == [1, 0]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _scg_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    from rgm import scg_shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n, B = 16, 3
+    gen = torch.Generator().manual_seed(123)
+    table = torch.randn(n, B, generator=gen)
+    table[5, 1] = table[11, 1] = table[:, 1].max() + 1.0           # a tie across two ranks: the first index must win
+    k0, nl, sharded = scg_shard.partition(n)
+    local = table[k0:k0 + nl].clone()                              # what this rank's decode + rule kernels would produce
+    full = scg_shard.gather_totals(local)
+    q.put((rank, k0, nl, sharded, torch.equal(full, table), scg_shard.first_argmax(full).tolist()))
+    dist.destroy_process_group()
+
+
+def test_scg_sharding_two_ranks_gloo():
+    """world_size 2 over gloo: both ranks rebuild the same (n,B) table and pick the same, first-index winners."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scg_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gen = torch.Generator().manual_seed(123)
+    table = torch.randn(16, 3, generator=gen)
+    table[5, 1] = table[11, 1] = table[:, 1].max() + 1.0
+    want = torch.argmax(table, dim=0).tolist()
+    assert want[1] == 5
+    assert [(r[1], r[2], r[3]) for r in res] == [(0, 8, True), (8, 8, True)]
+    assert all(r[4] for r in res) and all(r[5] == want for r in res)
+
+
+def test_product_modules_keep_the_reference_state_dict_keys():
+    from guided_diffusion.dit import DiT_models
+    m = DiT_models["DiTRotary_XL_8"](input_size=[128, 16], in_channels=4, num_classes=3, learn_sigma=False)
+    keys = list(m.state_dict().keys())
+    assert len(keys) == 322                                         # 321 (incl. aliased rotary freqs) + label table
+    m0 = DiT_models["DiTRotary_XL_8"](input_size=[128, 16], in_channels=4, num_classes=0, learn_sigma=False)
+    assert len(m0.state_dict()) == 321
+    assert "blocks.27.attn.rotary_emb.freqs" in keys and "final_layer.adaLN_modulation.1.weight" in keys
+    assert m.state_dict()["y_embedder.embedding_table.weight"].shape == (4, 1152)
+    assert m.state_dict()["blocks.0.attn.rotary_emb.freqs"].data_ptr() == m.state_dict()["rotary_emb.freqs"].data_ptr()
+    from taming.models.klvae_pedal import AutoencoderKL
+    v = AutoencoderKL()
+    assert "decoder.up.3.upsample.conv.weight" in v.state_dict() and "post_quant_conv.bias" in v.state_dict()
