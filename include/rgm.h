@@ -167,6 +167,24 @@ int rgm_bucketize(const float* v, const float* bounds, int nb, int64_t* out, int
 int rgm_row_loss(const float* a, const float* b, float* out, int rows, int K, int zero_one, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Classifier guidance backward                            guided_diffusion/condition_functions.py:58-85
+ * ---------------------------------------------------------------------------------------------- */
+/* Value and input-gradient of a DiTRotaryClassifier log-probability in one call (replaces
+ * th.autograd.grad(log_probs.sum(), x_in) * classifier_scale; weights are frozen, so only dgrad runs):
+ *   loss_kind 0 (kind-1 handle): log p = -sum_k (logits - target)^2, target float32 (N, n_out)    [grad_nn_zt_mse]
+ *   loss_kind 1 (kind-2 handle): log p = -sum_w CE(chord_logits[w], target[w]), target int64 (N, H/width)
+ *                                                                                 [grad_nn_zt_chord, both=False]
+ * grad_x (N,in_ch,H,width) = d(sum log p)/dx * scale;  logits_out (N[,H/width], n_out) or NULL. */
+size_t rgm_dit_grad_workspace_bytes(const rgm_dit* h, int N, int H);
+int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,
+                               float scale, float* logits_out, float* grad_x, int N, int H, void* ws,
+                               size_t ws_bytes, void* stream);
+/* d(qkv) of the RotaryAttention core from dO, the saved qkv, O and per-query log-sum-exp (N, heads, T); hd = 64. */
+int rgm_rotary_attention_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                             const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
+                             int rot_half, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py roofline leg): with profiling on, every GEMM launch is bracketed by two
  * hipEvents recorded on the launch stream.  kernel ids: 1..4 = dense tiles 128x128 / 128x64 / 64x64 /
  * 32x128, 11..14 = the same tiles with the implicit 3x3-conv loader.

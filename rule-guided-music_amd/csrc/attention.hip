@@ -40,7 +40,7 @@ template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                const float* __restrict__ cos_tab,
                                                                const float* __restrict__ sin_tab, int T, int heads,
-                                                               int rot_half) {
+                                                               int rot_half, float* __restrict__ lse) {
   constexpr int HDP = HD + 4;          // padded K row (floats)
   constexpr int KB = HD / 8;           // k-blocks of 8 in QK^T
   constexpr int DT = (HD + 31) / 32;   // 32-wide output-channel tiles
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __re
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    if (lse && hh == 0 && q < T) lse[((long long)n * heads + head) * T + q] = mx + logf(sum);   // saved for the backward
     // ---- O^T[d][query] = V^T . P^T ; A operand = V[key][d] with d = lane&31, B operand = P registers
     f32x16 oacc[DT];
 #pragma unroll
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __re
 
 template <int HD, int NKT>
 static int launch_attn(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads,
-                       int rot_half, hipStream_t s) {
+                       int rot_half, float* lse, hipStream_t s) {
   constexpr int TP = NKT * 32;
   // V strip + K strip; channel reads of the last (partial) 32-wide tile run past a V row into the
   // next row / the K strip, which is finite data feeding discarded accumulator rows only.
@@ -197,27 +198,27 @@ static int launch_attn(const float* qkv, float* o, const float* ct, const float*
     RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half);
+  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
 int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T,
-                            int heads, int hd, int rot_half, hipStream_t s) {
+                            int heads, int hd, int rot_half, hipStream_t s, float* lse) {
   RGM_REQUIRE(N > 0 && T > 0 && T <= 288, "attention: T=%d out of range (1..288)", T);
   RGM_REQUIRE((2 * rot_half) % 4 == 0 && 2 * rot_half <= hd, "attention: rotary dim %d", 2 * rot_half);
   const int nkt = (T + 31) / 32;
   if (hd == 72) {
-    if (nkt <= 4) return launch_attn<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, s);
-    if (nkt <= 8) return launch_attn<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, s);
+    if (nkt <= 4) return launch_attn<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
+    if (nkt <= 8) return launch_attn<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
     set_error("attention: head_dim 72 supports T <= 256 (K+V of one head must fit the 160 KiB LDS), got %d", T);
     return RGM_ERR_INVALID;
   }
   if (hd == 64) {
-    if (nkt <= 4) return launch_attn<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, s);
-    if (nkt <= 5) return launch_attn<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, s);
-    if (nkt <= 8) return launch_attn<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, s);
-    return launch_attn<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, s);
+    if (nkt <= 4) return launch_attn<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
+    if (nkt <= 5) return launch_attn<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
+    if (nkt <= 8) return launch_attn<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
+    return launch_attn<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
   }
   set_error("attention: head_dim %d not supported (64, 72)", hd);
   return RGM_ERR_INVALID;

@@ -54,6 +54,16 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float c = 0.7978845608028654f;  // sqrt(2/pi)
   return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
 }
+__device__ __forceinline__ float gelu_tanh_grad_f(float x) {
+  const float c = 0.7978845608028654f;
+  const float u = c * (x + 0.044715f * x * x * x);
+  const float th = tanhf(u);
+  return 0.5f * (1.0f + th) + 0.5f * x * (1.0f - th * th) * c * (1.0f + 3.0f * 0.044715f * x * x);
+}
+__device__ __forceinline__ float silu_grad_f(float x) {
+  const float sg = 1.0f / (1.0f + expf(-x));
+  return sg * (1.0f + x * (1.0f - sg));
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -86,6 +96,10 @@ struct GemmParams {
   const float* res = nullptr;    // res[row * ldres + col] (+ batch * sRes); may alias C
   int ldres = 0;
   long long sRes = 0;
+  // act 3 / 4: multiply by gelu_tanh'(aux) / silu'(aux) (backward through an activation); aux[row*ldaux + col]
+  const float* aux = nullptr;
+  int ldaux = 0;
+  long long sAux = 0;
   // implicit-GEMM 3x3 conv A operand (aload == 1): A is NHWC [img][Hin][Win][Cin], M = imgs*H*W
   int aload = 0;
   int H = 0, W = 0, Cin = 0, logH = 0, logW = 0, ups = 0;
@@ -99,6 +113,11 @@ int layernorm_modulate_launch(const float* x, float* out, int M, int D, float ep
                               const float* bias, const float* shift, const float* scale, int mod_ld,
                               int rows_per_batch, hipStream_t s);
 int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N,
-                            int T, int heads, int hd, int rot_half, hipStream_t s);
+                            int T, int heads, int hd, int rot_half, hipStream_t s, float* lse = nullptr);
+// attention backward (attention_bwd.hip): dqkv (N*T, 3*heads*hd) from dO, the saved qkv / O / lse
+int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
+                                const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
+                                int rot_half, hipStream_t s);
+int transpose_launch(const float* in, float* out, int R, int Cc, int out_ld, int batch, hipStream_t s);
 
 }  // namespace rgm

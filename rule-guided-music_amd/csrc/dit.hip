@@ -25,6 +25,12 @@ int timestep_sincos_launch(const int64_t* t, const float* freqs, float* emb, int
 int cond_finish_launch(const float* c, const float* table, const int32_t* y, float* cs, int N, int D, hipStream_t s);
 int fill_cls_launch(const float* cls, float* x, int N, int T, int D, hipStream_t s);
 int pool_rows_launch(const float* x, float* out, int N, int T, int D, int first, int groups, int per, hipStream_t s);
+int ln_mod_bwd_launch(const float* dy, const float* x, const float* res, float* out, int M, int D, float eps,
+                      const float* weight, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s);
+int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int D, int gate_ld, int rows_per_batch, hipStream_t s);
+int act_rows_launch(const float* in, float* out, long long total, int act, hipStream_t s);
+int loss_grad_launch(const float* logits, const void* target, float* dl, int rows, int K, int Kp, float scale, int kind, hipStream_t s);
+int scatter_rows_launch(const float* src, float* dx, int N, int T, int D, int first, int groups, int per, hipStream_t s);
 }  // namespace rgm
 
 using namespace rgm;
@@ -33,6 +39,7 @@ struct Slot {
   size_t off = 0;     // floats from arena base
   size_t numel = 0;
   bool set = false;
+  int t_rows = 0, t_cols = 0, t_ld = 0;   // ".T" slots: transposed copy of a [t_cols(out)][t_rows(in)] weight, row stride t_ld
 };
 
 struct rgm_dit {
@@ -57,6 +64,20 @@ static void add_slot(rgm_dit* h, const std::string& key, size_t numel) {
   s.numel = numel;
   h->slots[key] = s;
   h->arena_floats += (numel + 3) / 4 * 4;  // keep every tensor 16-byte aligned
+}
+
+// transposed copy W^T [in][out_padded] of a Linear weight [out][in]: the B operand of the dgrad GEMM dX = dY . W
+static void add_t_slot(rgm_dit* h, const std::string& key, int out_f, int in_f) {
+  const int ld = (out_f + 31) / 32 * 32;
+  Slot s;
+  s.off = h->arena_floats;
+  s.numel = (size_t)in_f * ld;
+  s.set = true;                    // filled as a side effect of setting `key`
+  s.t_rows = in_f;
+  s.t_cols = out_f;
+  s.t_ld = ld;
+  h->slots[key + ".T"] = s;
+  h->arena_floats += s.numel;
 }
 
 extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
@@ -121,6 +142,20 @@ extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
       add_slot(h, "classifier_head_key.2.bias", 25);
     }
   }
+  if (c->kind != 0) {              // classifiers are differentiated w.r.t. their input (guidance): keep W^T too
+    const int Di = c->hidden;
+    add_t_slot(h, "x_embedder.MLP.0.weight", 256, pc);
+    add_t_slot(h, "x_embedder.MLP.2.weight", Di, 256);
+    for (int i = 0; i < c->depth; ++i) {
+      const std::string b = "blocks." + std::to_string(i) + ".";
+      add_t_slot(h, b + "attn.qkv.weight", 3 * Di, Di);
+      add_t_slot(h, b + "attn.proj.weight", Di, Di);
+      add_t_slot(h, b + "mlp.fc1.weight", 4 * Di, Di);
+      add_t_slot(h, b + "mlp.fc2.weight", Di, 4 * Di);
+    }
+    add_t_slot(h, "classifier_head.0.weight", Di / 4, Di);
+    add_t_slot(h, "classifier_head.2.weight", c->n_out, Di / 4);
+  }
   RGM_CHECK_HIP(hipMalloc(&h->arena, h->arena_floats * sizeof(float)));
   RGM_CHECK_HIP(hipMemset(h->arena, 0, h->arena_floats * sizeof(float)));
   // timestep frequencies, float32 op order of dit.py:59-61
@@ -158,6 +193,12 @@ extern "C" int rgm_dit_set_param(rgm_dit* h, const char* key, const void* dptr, 
   RGM_REQUIRE(numel == it->second.numel, "dit_set_param: '%s' has %zu elements, expected %zu", key, numel, it->second.numel);
   RGM_CHECK_HIP(hipMemcpy(h->arena + it->second.off, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
   it->second.set = true;
+  auto tt = h->slots.find(k + ".T");
+  if (tt != h->slots.end()) {
+    const Slot& ts = tt->second;
+    RGM_TRY(transpose_launch(h->arena + it->second.off, h->arena + ts.off, ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
+    RGM_CHECK_HIP(hipStreamSynchronize(0));
+  }
   if (k == "rotary_emb.freqs") {
     // rotary-embedding-torch 0.3.2: angle = pos * freq in float32, then cos / sin
     std::vector<float> fr(h->rot_half), ct((size_t)h->cfg.max_tokens * h->rot_half), st(ct.size());
@@ -368,4 +409,198 @@ extern "C" int rgm_dit_classify(rgm_dit* h, const float* x, const int64_t* t, fl
   RGM_REQUIRE(n_token > 0 && p.T0 % n_token == 0, "dit_classify: H=%d gives %d chord windows", H, n_token);
   RGM_TRY(pool_rows_launch(p.x, p.pool, N, p.T, D, 1, n_token, p.T0 / n_token, s));
   return run_head(h, p, "norm", "classifier_head", N * n_token, c.n_out, logits, s);
+}
+
+// =====================================================================================================
+// Classifier guidance: value and input gradient in one call (forward with saved activations + dgrad chain).
+// Replaces th.autograd.grad(log_probs.sum(), x_in) of condition_functions.py:58-85.
+// =====================================================================================================
+namespace {
+struct GPlan {
+  int N, H, T0, T, M0, M, L, Kp, groups;
+  float *tok_in, *zpre, *h1, *temb, *c1, *c, *cs, *mod;
+  float *xs, *x1s, *qkvs, *aos, *pres, *lses;   // per-block saves (xs has depth+1 entries)
+  float *xm, *hid, *dx, *dx1, *t1, *dbig, *dqkv, *dsmall;
+  float *pool, *pooln, *z1pre, *z1, *logits, *dl, *dz1, *dpooln, *dpool, *dz, *dtin;
+  size_t bytes;
+};
+
+GPlan gplan(const rgm_dit* h, int N, int H, void* ws) {
+  const rgm_dit_cfg& c = h->cfg;
+  GPlan p{};
+  p.N = N; p.H = H;
+  p.T0 = H * c.width / c.patch;
+  p.T = p.T0 + 1;
+  p.M0 = N * p.T0;
+  p.M = N * p.T;
+  p.L = (int)h->ada_rows;
+  p.Kp = (c.n_out + 31) / 32 * 32;
+  p.groups = c.kind == 2 ? H / c.width : 1;
+  const size_t D = c.hidden, M = p.M, dep = c.depth;
+  Ws w(ws, 0);
+  p.tok_in = w.take((size_t)p.M0 * c.in_ch * c.patch);
+  p.zpre = w.take((size_t)p.M0 * 256);
+  p.h1 = w.take((size_t)p.M0 * 256);
+  p.temb = w.take((size_t)N * 256);
+  p.c1 = w.take(N * D); p.c = w.take(N * D); p.cs = w.take(N * D);
+  p.mod = w.take((size_t)N * p.L);
+  p.xs = w.take((dep + 1) * M * D);
+  p.x1s = w.take(dep * M * D);
+  p.qkvs = w.take(dep * M * 3 * D);
+  p.aos = w.take(dep * M * D);
+  p.pres = w.take(dep * M * 4 * D);
+  p.lses = w.take(dep * (size_t)N * c.heads * p.T);
+  p.xm = w.take(M * D);
+  p.hid = w.take(M * 4 * D);
+  p.dx = w.take(M * D); p.dx1 = w.take(M * D); p.t1 = w.take(M * D);
+  p.dbig = w.take(M * 4 * D);
+  p.dqkv = w.take(M * 3 * D);
+  p.dsmall = w.take(M * D);
+  const size_t R = (size_t)N * p.groups;
+  p.pool = w.take(R * D); p.pooln = w.take(R * D);
+  p.z1pre = w.take(R * (D / 4)); p.z1 = w.take(R * (D / 4));
+  p.logits = w.take(R * c.n_out);
+  p.dl = w.take(R * p.Kp);
+  p.dz1 = w.take(R * (D / 4)); p.dpooln = w.take(R * D); p.dpool = w.take(R * D);
+  p.dz = w.take((size_t)p.M0 * 256);
+  p.dtin = w.take((size_t)p.M0 * c.in_ch * c.patch);
+  p.bytes = w.off;
+  return p;
+}
+
+// dX[M, in] = dY[M, out(ld lda)] . W  using the stored W^T ([in][out_padded]); optional act-grad epilogue
+int dgrad(rgm_dit* h, const std::string& wkey, const float* dY, int lda, float* dX, int ldc, int M, const float* aux, int ldaux,
+          int act, hipStream_t s) {
+  const Slot& ts = h->slots.at(wkey + ".T");
+  GemmParams g;
+  g.A = dY; g.lda = lda; g.B = h->arena + ts.off; g.ldb = ts.t_ld; g.C = dX; g.ldc = ldc;
+  g.M = M; g.N = ts.t_rows; g.K = ts.t_ld;
+  g.aux = aux; g.ldaux = ldaux; g.act = act;
+  return gemm_launch(g, s);
+}
+}  // namespace
+
+extern "C" size_t rgm_dit_grad_workspace_bytes(const rgm_dit* h, int N, int H) {
+  if (!h || h->cfg.kind == 0 || N <= 0 || H <= 0) return 0;
+  return gplan(h, N, H, nullptr).bytes;
+}
+
+// loss_kind 0: log p = -sum_k (logits - target)^2, target float (N, n_out)                  [grad_nn_zt_mse]
+// loss_kind 1: log p = -sum_windows CE(chord_logits, target), target int64 (N, H/width)     [grad_nn_zt_chord, both=False]
+// grad_x (N,in_ch,H,width) = d(sum log p)/dx * scale ; logits_out (N[,H/width], n_out) optional.
+extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,
+                                          float scale, float* logits_out, float* grad_x, int N, int H, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind != 0, "cls_value_and_grad: handle is not a classifier");
+  RGM_REQUIRE(x && t && target && grad_x, "cls_value_and_grad: null tensor");
+  RGM_REQUIRE((loss_kind == 0 && h->cfg.kind == 1) || (loss_kind == 1 && h->cfg.kind == 2),
+              "cls_value_and_grad: loss_kind %d does not match classifier kind %d", loss_kind, h->cfg.kind);
+  RGM_REQUIRE(h->hd == 64, "cls_value_and_grad: head_dim %d (the backward kernels cover the 64-wide classifier family)", h->hd);
+  Plan chk;
+  RGM_TRY(check_ready(h, N, H, (size_t)-1, (void*)256, &chk));   // shapes + parameters (its workspace test is moot here)
+  const rgm_dit_cfg& c = h->cfg;
+  GPlan p = gplan(h, N, H, ws);
+  if (!ws || p.bytes > ws_bytes) {
+    set_error("cls_value_and_grad: workspace %zu bytes < required %zu", ws_bytes, p.bytes);
+    return RGM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int D = c.hidden, pc = c.in_ch * c.patch, T = p.T, L = p.L, M = p.M;
+  const size_t MD = (size_t)M * D;
+  // ---------------- forward, keeping what the backward needs
+  RGM_TRY(patchify_launch(x, p.tok_in, N, c.in_ch, H, c.width, c.patch, s));
+  RGM_TRY(lin(p.tok_in, pc, h->p("x_embedder.MLP.0.weight"), h->p("x_embedder.MLP.0.bias"), p.zpre, 256, p.M0, 256, pc, 0, s));
+  RGM_TRY(act_rows_launch(p.zpre, p.h1, (long long)p.M0 * 256, 1, s));
+  {
+    GemmParams g;
+    g.A = p.h1; g.lda = 256; g.sA = (long long)p.T0 * 256;
+    g.B = h->p("x_embedder.MLP.2.weight"); g.ldb = 256;
+    g.C = p.xs + D; g.ldc = D; g.sC = (long long)T * D;
+    g.M = p.T0; g.N = D; g.K = 256; g.batch = N;
+    g.bias = h->p("x_embedder.MLP.2.bias");
+    RGM_TRY(gemm_launch(g, s));
+    RGM_TRY(fill_cls_launch(h->p("cls_token"), p.xs, N, T, D, s));
+  }
+  RGM_TRY(timestep_sincos_launch(t, h->tfreqs, p.temb, N, 128, s));
+  RGM_TRY(lin(p.temb, 256, h->p("t_embedder.mlp.0.weight"), h->p("t_embedder.mlp.0.bias"), p.c1, D, N, D, 256, 1, s));
+  RGM_TRY(lin(p.c1, D, h->p("t_embedder.mlp.2.weight"), h->p("t_embedder.mlp.2.bias"), p.c, D, N, D, D, 0, s));
+  RGM_TRY(cond_finish_launch(p.c, nullptr, nullptr, p.cs, N, D, s));
+  RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, N, L, D, 0, s));
+  const size_t lse_sz = (size_t)N * c.heads * T;
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = "blocks." + std::to_string(i) + ".";
+    const float* m = p.mod + (size_t)i * 6 * D;
+    float* xi = p.xs + i * MD;
+    float* x1 = p.x1s + i * MD;
+    float* xn = p.xs + (i + 1) * MD;
+    float* qkv = p.qkvs + i * MD * 3;
+    float* ao = p.aos + i * MD;
+    float* pre = p.pres + i * MD * 4;
+    RGM_TRY(layernorm_modulate_launch(xi, p.xm, M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
+    RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), qkv, 3 * D, M, 3 * D, D, 0, s));
+    RGM_TRY(rotary_attention_launch(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, p.lses + i * lse_sz));
+    {
+      GemmParams g;
+      g.A = ao; g.lda = D; g.B = h->p(b + "attn.proj.weight"); g.ldb = D; g.C = x1; g.ldc = D;
+      g.M = M; g.N = D; g.K = D; g.bias = h->p(b + "attn.proj.bias");
+      g.gate = m + 2 * D; g.gate_ld = L; g.rows_per_gate = T; g.res = xi; g.ldres = D;
+      RGM_TRY(gemm_launch(g, s));
+    }
+    RGM_TRY(layernorm_modulate_launch(x1, p.xm, M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s));
+    RGM_TRY(lin(p.xm, D, h->p(b + "mlp.fc1.weight"), h->p(b + "mlp.fc1.bias"), pre, 4 * D, M, 4 * D, D, 0, s));
+    RGM_TRY(act_rows_launch(pre, p.hid, (long long)M * 4 * D, 2, s));
+    {
+      GemmParams g;
+      g.A = p.hid; g.lda = 4 * D; g.B = h->p(b + "mlp.fc2.weight"); g.ldb = 4 * D; g.C = xn; g.ldc = D;
+      g.M = M; g.N = D; g.K = 4 * D; g.bias = h->p(b + "mlp.fc2.bias");
+      g.gate = m + 5 * D; g.gate_ld = L; g.rows_per_gate = T; g.res = x1; g.ldres = D;
+      RGM_TRY(gemm_launch(g, s));
+    }
+  }
+  const float* xf = p.xs + (size_t)c.depth * MD;
+  // ---------------- head forward + loss gradient
+  const int rows = N * p.groups, per = c.kind == 2 ? p.T0 / p.groups : 1, first = c.kind == 2 ? 1 : 0;
+  RGM_TRY(pool_rows_launch(xf, p.pool, N, T, D, first, p.groups, per, s));
+  RGM_TRY(layernorm_modulate_launch(p.pool, p.pooln, rows, D, 1e-5f, h->p("norm.weight"), h->p("norm.bias"), nullptr, nullptr, 0, 1, s));
+  RGM_TRY(lin(p.pooln, D, h->p("classifier_head.0.weight"), h->p("classifier_head.0.bias"), p.z1pre, D / 4, rows, D / 4, D, 0, s));
+  RGM_TRY(act_rows_launch(p.z1pre, p.z1, (long long)rows * (D / 4), 1, s));
+  float* logits = logits_out ? logits_out : p.logits;
+  RGM_TRY(lin(p.z1, D / 4, h->p("classifier_head.2.weight"), h->p("classifier_head.2.bias"), logits, c.n_out, rows, c.n_out, D / 4, 0, s));
+  RGM_TRY(loss_grad_launch(logits, target, p.dl, rows, c.n_out, p.Kp, scale, loss_kind, s));
+  // ---------------- head backward -> gradient of the residual stream
+  RGM_TRY(dgrad(h, "classifier_head.2.weight", p.dl, p.Kp, p.dz1, D / 4, rows, p.z1pre, D / 4, 4, s));
+  RGM_TRY(dgrad(h, "classifier_head.0.weight", p.dz1, D / 4, p.dpooln, D, rows, nullptr, 0, 0, s));
+  RGM_TRY(ln_mod_bwd_launch(p.dpooln, p.pool, nullptr, p.dpool, rows, D, 1e-5f, h->p("norm.weight"), nullptr, 0, 1, s));
+  RGM_TRY(scatter_rows_launch(p.dpool, p.dx, N, T, D, first, p.groups, per, s));
+  // ---------------- blocks, last to first
+  for (int i = c.depth - 1; i >= 0; --i) {
+    const std::string b = "blocks." + std::to_string(i) + ".";
+    const float* m = p.mod + (size_t)i * 6 * D;
+    const float* xi = p.xs + i * MD;
+    const float* x1 = p.x1s + i * MD;
+    RGM_TRY(gate_rows_launch(p.dx, m + 5 * D, p.t1, M, D, L, T, s));                                   // d f2 = g2 * dx
+    RGM_TRY(dgrad(h, b + "mlp.fc2.weight", p.t1, D, p.dbig, 4 * D, M, p.pres + i * MD * 4, 4 * D, 3, s)); // d pre = (. W2) * gelu'
+    RGM_TRY(dgrad(h, b + "mlp.fc1.weight", p.dbig, 4 * D, p.dsmall, D, M, nullptr, 0, 0, s));            // d m2
+    RGM_TRY(ln_mod_bwd_launch(p.dsmall, x1, p.dx, p.dx1, M, D, 1e-6f, nullptr, m + 4 * D, L, T, s));      // dx1 = dx + LN'
+    RGM_TRY(gate_rows_launch(p.dx1, m + 2 * D, p.t1, M, D, L, T, s));                                   // d a = g1 * dx1
+    RGM_TRY(dgrad(h, b + "attn.proj.weight", p.t1, D, p.dsmall, D, M, nullptr, 0, 0, s));               // d o
+    RGM_TRY(rotary_attention_bwd_launch(p.qkvs + i * MD * 3, p.aos + i * MD, p.dsmall, p.lses + i * lse_sz, p.dqkv, h->cos_tab,
+                                        h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s));
+    RGM_TRY(dgrad(h, b + "attn.qkv.weight", p.dqkv, 3 * D, p.dsmall, D, M, nullptr, 0, 0, s));          // d m1
+    RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s));         // dx = dx1 + LN'
+  }
+  // ---------------- patch embedder backward (token rows 1..T0 of every sample), then un-patchify
+  {
+    const Slot& ts = h->slots.at("x_embedder.MLP.2.weight.T");
+    GemmParams g;
+    g.A = p.dx + D; g.lda = D; g.sA = (long long)T * D;
+    g.B = h->arena + ts.off; g.ldb = ts.t_ld;
+    g.C = p.dz; g.ldc = 256; g.sC = (long long)p.T0 * 256;
+    g.M = p.T0; g.N = 256; g.K = D; g.batch = N;
+    g.aux = p.zpre; g.ldaux = 256; g.sAux = (long long)p.T0 * 256; g.act = 4;
+    RGM_TRY(gemm_launch(g, s));
+  }
+  RGM_TRY(dgrad(h, "x_embedder.MLP.0.weight", p.dz, 256, p.dtin, pc, p.M0, nullptr, 0, 0, s));
+  RGM_TRY(unpatchify_launch(p.dtin, grad_x, N, c.in_ch, H, c.width, s));
+  return RGM_OK;
 }

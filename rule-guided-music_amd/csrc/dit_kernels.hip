@@ -150,6 +150,30 @@ __global__ void pool_rows_kernel(const float* __restrict__ x, float* __restrict_
   out[i] = per == 1 ? s : s / (float)per;
 }
 
+// out[b][c*out_ld + r] = in[b][r*Cc + c]  (batched transpose through a padded LDS tile)
+__global__ void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc, int out_ld) {
+  __shared__ float tile[32][33];
+  const int b = blockIdx.z;
+  const float* ib = in + (long long)b * R * Cc;
+  float* ob = out + (long long)b * Cc * out_ld;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int r = r0 + i, c = c0 + threadIdx.x;
+    if (r < R && c < Cc) tile[i][threadIdx.x] = ib[(long long)r * Cc + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
+    const int c = c0 + i, r = r0 + threadIdx.x;
+    if (r < R && c < Cc) ob[(long long)c * out_ld + r] = tile[threadIdx.x][i];
+  }
+}
+
+int transpose_launch(const float* in, float* out, int R, int Cc, int out_ld, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), batch), dim3(32, 8), 0, s, in, out, R, Cc, out_ld);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
 int patchify_launch(const float* x, float* tok, int N, int C, int H, int W, int P, hipStream_t s) {
   const long long total = (long long)N * C * H * W;
   hipLaunchKernelGGL(patchify_kernel, dim3((int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s, x, tok, N, C, H, W, P);

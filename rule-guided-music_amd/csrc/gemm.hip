@@ -171,6 +171,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
   float* __restrict__ Cb = p.C + (long long)z * p.sC;
   const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
   const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  const float* auxb = p.aux ? p.aux + (long long)z * p.sAux : nullptr;
 #pragma unroll
   for (int im = 0; im < TM; ++im) {
 #pragma unroll
@@ -185,6 +186,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
         float v = acc[im][in][e] * p.alpha + bv;
         if (p.act == 1) v = silu_f(v);
         else if (p.act == 2) v = gelu_tanh_f(v);
+        else if (p.act == 3) v *= gelu_tanh_grad_f(auxb[(long long)row * p.ldaux + col]);
+        else if (p.act == 4) v *= silu_grad_f(auxb[(long long)row * p.ldaux + col]);
         if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
         if (resb) v += resb[(long long)row * p.ldres + col];
         Cb[(long long)row * p.ldc + col] = v;

@@ -149,24 +149,6 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s
   for (int c = lane; c < cols; c += 64) r[c] *= inv;
 }
 
-// out[b][c][r] = in[b][r][c]
-__global__ void transpose_batched_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
-  __shared__ float tile[32][33];
-  const int b = blockIdx.z;
-  const float* ib = in + (long long)b * R * Cc;
-  float* ob = out + (long long)b * R * Cc;
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
-    const int r = r0 + i, c = c0 + threadIdx.x;
-    if (r < R && c < Cc) tile[i][threadIdx.x] = ib[(long long)r * Cc + c];
-  }
-  __syncthreads();
-  for (int i = threadIdx.y; i < 32; i += blockDim.y) {
-    const int c = c0 + i, r = r0 + threadIdx.x;
-    if (r < R && c < Cc) ob[(long long)c * R + r] = tile[threadIdx.x][i];
-  }
-}
-
 // conv_out 3x3 (C=128 -> 3) on 128x128; x NHWC (post GN+swish); weights [3][9][128] staged in LDS.
 // One thread per pixel; writes roll[n][co][y][s*128 + x] (tile m = s*Nb + n) and optionally the uint8 roll.
 __global__ __launch_bounds__(256) void vae_conv_out_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -509,8 +491,7 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
     RGM_TRY(gemm_launch(g, s));
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, c.p.sc, rows, 256);
     RGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(transpose_batched_kernel, dim3(C / 32, 256 / 32, M), dim3(32, 8), 0, s, c.p.v, c.p.vt, 256, C);
-    RGM_LAUNCH_CHECK();
+    RGM_TRY(transpose_launch(c.p.v, c.p.vt, 256, C, 256, M, s));
     GemmParams o;  // o[m] = p[m] . v[m]  (B^T form: vt[m] is [C][256])
     o.A = c.p.sc; o.lda = 256; o.sA = 256LL * 256; o.B = c.p.vt; o.ldb = 256; o.sB = 256LL * C;
     o.C = t1; o.ldc = C; o.sC = 256LL * C; o.M = 256; o.N = C; o.K = 256; o.batch = M;

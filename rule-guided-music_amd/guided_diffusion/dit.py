@@ -206,6 +206,37 @@ class DiTRotaryClassifier(_NativeDiT):
                                                  N, H, _rgm.ptr(ws), need, _rgm.current_stream()))
         return (key, out) if self.chord else out
 
+    def value_and_grad(self, x, t, target, loss_kind, scale):
+        """(logits, grad_x) with grad_x = scale * d(sum log p)/dx, in one native call (no autograd graph).
+
+        loss_kind "mse": log p = -sum (logits - target)^2, target (N, num_classes) float
+        loss_kind "chord_ce": log p = -sum CE(chord_logits, target), target (N, H/W) integer   [chord=True]"""
+        _rgm.require_cuda(x, t, target)
+        N, _, H, W = x.shape
+        self._ensure_native(H * W // self.patch_size + 1)
+        x = x.detach().to(torch.float32).contiguous()
+        t = self._as_index(t, torch.int64)
+        if loss_kind == "mse":
+            assert not self.chord
+            tgt, kind = target.to(torch.float32).contiguous(), 0
+            logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
+        elif loss_kind == "chord_ce":
+            assert self.chord
+            tgt, kind = target.reshape(N, -1).to(torch.int64).contiguous(), 1
+            logits = torch.empty((N, H // W, self.num_classes), dtype=torch.float32, device=x.device)
+        else:
+            raise ValueError(loss_kind)
+        grad = torch.empty_like(x)
+        need = _rgm.lib.rgm_dit_grad_workspace_bytes(self._handle, N, H)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _rgm.check(_rgm.lib.rgm_dit_cls_value_and_grad(self._handle, _rgm.ptr(x), _rgm.ptr(t), _rgm.ptr(tgt), kind, float(scale),
+                                                           _rgm.ptr(logits), _rgm.ptr(grad), N, H, _rgm.ptr(self._ws), need,
+                                                           _rgm.current_stream()))
+        return logits, grad
+
 
 def _eps(depth, hidden, heads, patch):
     return lambda **kw: DiTRotary(depth=depth, hidden_size=hidden, patch_size=patch, num_heads=heads, **kw)

@@ -56,6 +56,9 @@ def _load():
         "rgm_row_loss": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "rgm_collage_split": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
         "rgm_collage_merge": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
+        "rgm_dit_grad_workspace_bytes": (sz, [vp, i32, i32]),
+        "rgm_dit_cls_value_and_grad": (C.c_int, [vp, vp, vp, vp, i32, f32, vp, vp, i32, i32, vp, sz, vp]),
+        "rgm_rotary_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_prof_enable": (C.c_int, [i32]),
         "rgm_prof_reset": (C.c_int, []),
         "rgm_prof_report": (C.c_int, [i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
