@@ -36,6 +36,7 @@ XL = dict(depth=28, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4)
 DIT_GFLOP_PER_SAMPLE = 237.4          # DiTRotary_XL_8 forward, T=256
 VAE_GFLOP_PER_TILE = 114.48
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH: v_mfma_f32_32x32x2_f32, dense
+BF16X3_EQUIV_PEAK_TFLOPS = 2500.0 / 3  # dense bf16 MFMA peak, 3 MFMAs per useful (algorithmic) product
 
 
 def log(*a):
@@ -137,18 +138,19 @@ def roofline_pass(work, steps=2):
     torch.cuda.synchronize()
     R.check(R.lib.rgm_prof_enable(0))
     rows = {}
-    for kid in (1, 2, 3, 4, 11, 12, 13, 14):
+    for kid in (1, 2, 3, 4, 11, 12, 13, 14, 21, 22, 23, 24, 31, 32, 33, 34):
         n, ms, fl = C.c_int(), C.c_double(), C.c_double()
         R.check(R.lib.rgm_prof_report(kid, C.byref(n), C.byref(ms), C.byref(fl)))
         if n.value:
             rows[kid] = dict(launches=n.value, ms=ms.value, flops=fl.value)
     R.check(R.lib.rgm_prof_reset())
-    names = {1: "gemm_kernel<128,128,2,2,0>", 2: "gemm_kernel<128,64,2,2,0>", 3: "gemm_kernel<64,64,2,2,0>",
-             4: "gemm_kernel<32,128,1,4,0>", 11: "gemm_kernel<128,128,2,2,1>", 12: "gemm_kernel<128,64,2,2,1>",
-             13: "gemm_kernel<64,64,2,2,1>", 14: "gemm_kernel<32,128,1,4,1>"}
+    tiles = {1: "128,128,2,2", 2: "128,64,2,2", 3: "64,64,2,2", 4: "32,128,1,4"}
+    names = {k: f"gemm_kernel<{tiles[k % 10]},{(k // 10) % 2},{k // 20}>" for k in rows}      # <BM,BN,WM,WN,ALOAD,PREC>
     kid = max(rows, key=lambda k: rows[k]["ms"])
     r = rows[kid]
+    bf16x3 = kid >= 20
     achieved = r["flops"] / (r["ms"] * 1e-3) / 1e12
+    peak = BF16X3_EQUIV_PEAK_TFLOPS if bf16x3 else F32_MFMA_PEAK_TFLOPS
     traffic = None
     tp = os.path.join(ROOT, "profiles", "traffic.json")       # HBM bytes/launch from separate rocprofv3 --pmc passes
     if os.path.exists(tp):
@@ -157,8 +159,10 @@ def roofline_pass(work, steps=2):
         except Exception:
             traffic = None
     all_ms = sum(v["ms"] for v in rows.values())
-    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "kernel": names[kid],
+    return {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(achieved / peak, 4), "traffic": traffic, "kernel": names[kid],
+            "peak_note": ("2500 TFLOP/s dense bf16 MFMA / 3 products per fp32-equivalent FMA" if bf16x3
+                          else "f32-input MFMA v_mfma_f32_32x32x2_f32"),
             "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2), "launches_per_step": r["launches"] // steps,
             "gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3),
             "share_of_gemm_time": round(r["ms"] / all_ms, 3),
@@ -203,6 +207,9 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "scg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default=os.environ.get("RGM_BENCH_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
+                    help="GEMM arithmetic: bf16x3 split (default; fp32-grade: 2.5e-6 latent error on the 50-step golden, "
+                         "parity suite runs in both modes) or exact fp32 MFMA")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -217,6 +224,8 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from rgm import native as R
+    R.set_gemm_precision(args.precision)
     torch.manual_seed(0)
     batch = args.batch or (16 if args.workload == "c2" else 4)
     work = (C2Workload if args.workload == "c2" else SCGWorkload)(device, batch)
@@ -254,7 +263,9 @@ def main():
             "metric": "denoising steps/sec (whole node), DiTRotary_XL_8 4x128x16",
             "value": round(units / dt, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "dtype": "f32" if args.precision == "fp32" else "f32 via bf16x3 split (3 bf16 MFMA per product, fp32 accumulate)",
+            "data": "synthetic",
             "config": {"workload": work.name, "batch_per_gpu": batch, "sample_steps_per_s": round(units * batch / dt, 2),
                        "weights": "synthetic random-init (rgm.synth seed 1; adaLN/final layers re-randomised)",
                        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),

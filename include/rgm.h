@@ -91,8 +91,16 @@ int rgm_layernorm_modulate(const float* x, float* out, int M, int D, float eps, 
 int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const float* sin_tab,
                          int N, int T, int heads, int hd, int rot_half, void* stream);
 
-/* Same as rgm_gemm without gate/residual but with an explicit tile shape (1: 128x128, 2: 128x64, 3: 64x64,
- * 4: 32x128, 0: auto) -- used by the parity tests and tile-selection experiments. */
+/* Arithmetic of the GEMM family (every nn.Linear / conv of the path):
+ *   0  exact fp32 products on v_mfma_f32_32x32x2_f32 (default; 157 TFLOP/s peak);
+ *   1  "bf16x3": operands split hi+lo bf16 while staged to LDS, a*b ~= ah*bh + ah*bl + al*bh on
+ *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2e-5 relative per product; 833 TFLOP/s equivalent peak).
+ * Process-wide default used by all handles; results stay within the 1e-3 latent tolerance either way (tests). */
+int rgm_set_gemm_precision(int prec);
+int rgm_get_gemm_precision(void);
+/* Same as rgm_gemm without gate/residual but with an explicit tile shape in the low 4 bits (1: 128x128,
+ * 2: 128x64, 3: 64x64, 4: 32x128, 0: auto) and an explicit precision in bits 4.. (0: library default,
+ * 1: fp32, 2: bf16x3) -- used by the parity tests and tile-selection experiments. */
 int rgm_gemm_tile(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K,
                   const float* bias, int act, int tile, void* stream);
 

@@ -35,7 +35,7 @@ extern "C" int rgm_gemm_tile(const float* A, int lda, const float* B, int ldb, f
   RGM_REQUIRE(A && B && C, "gemm: null operand");
   GemmParams g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc;
-  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.tile = tile;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.tile = tile & 15; g.prec = (tile >> 4) ? (tile >> 4) - 1 : -1;
   return gemm_launch(g, (hipStream_t)stream);
 }
 

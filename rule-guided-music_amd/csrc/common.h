@@ -105,6 +105,8 @@ struct GemmParams {
   int H = 0, W = 0, Cin = 0, logH = 0, logW = 0, ups = 0;
   // tile override for experiments: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
   int tile = 0;
+  // arithmetic: -1 library default (rgm_set_gemm_precision), 0 fp32 MFMA, 1 bf16x3 split
+  int prec = -1;
 };
 int gemm_launch(const GemmParams& p, hipStream_t stream);
 

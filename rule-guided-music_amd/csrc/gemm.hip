@@ -29,7 +29,23 @@
 
 namespace rgm {
 
-template <int BM, int BN, int WM, int WN, int ALOAD>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// fp32 -> (hi, lo) bf16 pair with x ~= hi + lo to ~2^-17 relative (both round-to-nearest-even, v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void split_bf16(const float4& v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]);
+  lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]);
+  lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// PREC 0: exact fp32 products on v_mfma_f32_32x32x2_f32 (157 TF peak).
+// PREC 1: "bf16x3" -- every operand is split into hi+lo bf16 while it is staged to LDS and each product is
+//         a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation: relative error
+//         ~2e-5 per product instead of 6e-8, at 3/16 of the fp32-MFMA issue time per FLOP (833 TF equivalent peak).
+template <int BM, int BN, int WM, int WN, int ALOAD, int PREC>
 __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int tiles_m, int tiles_n) {
   constexpr int NT = WM * WN * 64;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -91,8 +107,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
   }
   const int cpt = (ALOAD == 1) ? (p.Cin >> 5) : 1;  // k-tiles per 3x3 tap
 
-  float4 ra[PA], rb[PB];
-  auto gload = [&](int kt) {
+  float4 ra0[PA], rb0[PB];
+  auto gload = [&](int kt, float4 (&ra)[PA], float4 (&rb)[PB]) {
     if (ALOAD == 0) {
 #pragma unroll
       for (int i = 0; i < PA; ++i)
@@ -114,15 +130,40 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
     for (int i = 0; i < PB; ++i)
       rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(Bb + b_off[i] + kt * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
   };
-  auto lstore = [&](int buf) {
+  // PREC 1 LDS image (same bytes as fp32): per operand tile [hi rows | lo rows], a row = 32 bf16 = 64 B = 4 chunks of
+  // 16 B (8 k each); chunk' = chunk ^ ((row >> 2) & 3) keeps the 16-lane ds_read_b128 groups conflict-free.
+  const int bsw = (srow >> 2) & 3;
+  auto lstore = [&](int buf, const float4 (&ra)[PA], const float4 (&rb)[PB]) {
     float* Ad = As + buf * BM * 32;
     float* Bd = Bs + buf * BN * 32;
+    if (PREC == 0) {
 #pragma unroll
-    for (int i = 0; i < PA; ++i)
-      *reinterpret_cast<float4*>(Ad + (srow + i * RPP) * 32 + ((slot ^ ssw) << 2)) = ra[i];
+      for (int i = 0; i < PA; ++i)
+        *reinterpret_cast<float4*>(Ad + (srow + i * RPP) * 32 + ((slot ^ ssw) << 2)) = ra[i];
 #pragma unroll
-    for (int i = 0; i < PB; ++i)
-      *reinterpret_cast<float4*>(Bd + (srow + i * RPP) * 32 + ((slot ^ ssw) << 2)) = rb[i];
+      for (int i = 0; i < PB; ++i)
+        *reinterpret_cast<float4*>(Bd + (srow + i * RPP) * 32 + ((slot ^ ssw) << 2)) = rb[i];
+    } else {
+      char* Ah = reinterpret_cast<char*>(Ad);
+      char* Bh = reinterpret_cast<char*>(Bd);
+      const int coff = ((((slot >> 1) ^ bsw) << 4) + ((slot & 1) << 3));
+#pragma unroll
+      for (int i = 0; i < PA; ++i) {
+        bf16x4 hi, lo;
+        split_bf16(ra[i], hi, lo);
+        const int ro = (srow + i * RPP) * 64 + coff;
+        *reinterpret_cast<bf16x4*>(Ah + ro) = hi;
+        *reinterpret_cast<bf16x4*>(Ah + BM * 64 + ro) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < PB; ++i) {
+        bf16x4 hi, lo;
+        split_bf16(rb[i], hi, lo);
+        const int ro = (srow + i * RPP) * 64 + coff;
+        *reinterpret_cast<bf16x4*>(Bh + ro) = hi;
+        *reinterpret_cast<bf16x4*>(Bh + BN * 64 + ro) = lo;
+      }
+    }
   };
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -139,32 +180,88 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int KT = p.K >> 5;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < KT) gload(kt + 1);
+  auto compute = [&](int buf) {
     const float* Asb = As + buf * BM * 32;
     const float* Bsb = Bs + buf * BN * 32;
+    if (PREC == 0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      f32x4 a[TM], b[TN];
-      const int so = ((2 * j + hh) ^ rsw) << 2;
+      for (int j = 0; j < 4; ++j) {
+        f32x4 a[TM], b[TN];
+        const int so = ((2 * j + hh) ^ rsw) << 2;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Asb + (arow0 + i * 32 + l31) * 32 + so);
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(Asb + (arow0 + i * 32 + l31) * 32 + so);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const f32x4*>(Bsb + (bcol0 + i * 32 + l31) * 32 + so);
+        for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const f32x4*>(Bsb + (bcol0 + i * 32 + l31) * 32 + so);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int im = 0; im < TM; ++im)
+#pragma unroll
+            for (int in = 0; in < TN; ++in)
+              acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+      }
+    } else {
+      const char* Ah = reinterpret_cast<const char*>(Asb);
+      const char* Bh = reinterpret_cast<const char*>(Bsb);
+      const int rq = (l31 >> 2) & 3;
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {          // two k-steps of 16 per 32-wide K tile; lane half hh holds 8 of the 16
+        const int co = ((2 * st + hh) ^ rq) << 4;
+        bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ro = (arow0 + i * 32 + l31) * 64 + co;
+          ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro);
+          al[i] = *reinterpret_cast<const bf16x8*>(Ah + BM * 64 + ro);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int ro = (bcol0 + i * 32 + l31) * 64 + co;
+          bh[i] = *reinterpret_cast<const bf16x8*>(Bh + ro);
+          bl[i] = *reinterpret_cast<const bf16x8*>(Bh + BN * 64 + ro);
+        }
 #pragma unroll
         for (int im = 0; im < TM; ++im)
 #pragma unroll
-          for (int in = 0; in < TN; ++in)
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[im][s], b[in][s], acc[im][in], 0, 0, 0);
+          for (int in = 0; in < TN; ++in) {
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[im], bh[in], acc[im][in], 0, 0, 0);
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bh[in], acc[im][in], 0, 0, 0);
+          }
+      }
     }
-    if (kt + 1 < KT) lstore(buf ^ 1);
+  };
+  if (PREC == 0) {
+    // fp32 MFMA: a K-tile is 32 MFMAs x 64 cycles per wave -- one tile of prefetch hides the global latency
+    gload(0, ra0, rb0);
+    lstore(0, ra0, rb0);
     __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < KT) gload(kt + 1, ra0, rb0);
+      compute(buf);
+      if (kt + 1 < KT) lstore(buf ^ 1, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    // bf16x3: a K-tile is only ~12 MFMAs x 32 cycles per wave, shorter than an L2/HBM round trip, so the loads run
+    // TWO tiles ahead in two register sets (the compiler's counted vmcnt waits for the older set only).
+    float4 ra1[PA], rb1[PB];
+    gload(0, ra0, rb0);
+    if (KT > 1) gload(1, ra1, rb1);
+    lstore(0, ra0, rb0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; kt += 2) {
+      if (kt + 2 < KT) gload(kt + 2, ra0, rb0);
+      compute(0);
+      if (kt + 1 < KT) lstore(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= KT) break;
+      if (kt + 3 < KT) gload(kt + 3, ra1, rb1);
+      compute(1);
+      if (kt + 2 < KT) lstore(0, ra0, rb0);
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -203,6 +300,7 @@ struct ProfRec {
   double flops;
 };
 static bool g_prof_on = false;
+static int g_default_prec = 0;   // 0 fp32 MFMA (parity default), 1 bf16x3
 static std::vector<ProfRec> g_prof;
 
 template <int BM, int BN, int WM, int WN>
@@ -214,14 +312,22 @@ static int launch_cfg(const GemmParams& p, hipStream_t s, int tile_id) {
   if (g_prof_on) {
     RGM_CHECK_HIP(hipEventCreate(&rec.a));
     RGM_CHECK_HIP(hipEventCreate(&rec.b));
-    rec.tile = tile_id + (p.aload ? 10 : 0);
+    rec.tile = tile_id + (p.aload ? 10 : 0) + ((p.prec < 0 ? g_default_prec : p.prec) ? 20 : 0);
     rec.flops = 2.0 * p.M * (double)p.N * p.K * p.batch;
     RGM_CHECK_HIP(hipEventRecord(rec.a, s));
   }
-  if (p.aload == 0)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0>), grid, block, lds, s, p, tm, tn);
-  else
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1>), grid, block, lds, s, p, tm, tn);
+  const int prec = p.prec < 0 ? g_default_prec : p.prec;
+  if (prec == 0) {
+    if (p.aload == 0)
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 0>), grid, block, lds, s, p, tm, tn);
+    else
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, 0>), grid, block, lds, s, p, tm, tn);
+  } else {
+    if (p.aload == 0)
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 1>), grid, block, lds, s, p, tm, tn);
+    else
+      hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 1, 1>), grid, block, lds, s, p, tm, tn);
+  }
   RGM_LAUNCH_CHECK();
   if (g_prof_on) {
     RGM_CHECK_HIP(hipEventRecord(rec.b, s));
@@ -243,13 +349,20 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm: operands must be 16-byte aligned with ld%%4==0");
   int tile = p.tile;
+  const int prec = p.prec < 0 ? g_default_prec : p.prec;
   if (tile == 0) {
     if (p.M <= 64) tile = 4;
-    else {
-      // pick the tile that wastes the fewest CU-rounds; smaller tiles pay more L2->LDS traffic
-      const double e1 = wave_eff(p.M, p.N, 128, 128, p.batch);
-      const double e2 = wave_eff(p.M, p.N, 128, 64, p.batch) * 0.96;
-      const double e3 = wave_eff(p.M, p.N, 64, 64, p.batch) * 0.92;
+    else if (prec == 1) {
+      // bf16x3: the MFMA work per byte staged is 5x shorter than fp32, so operand reuse (tile area) matters more
+      // than the last CU-round.  Measured on MI355X (tools/gemm_sweep.py): 128x64 wins from M~2k up (187-245 TF),
+      // 64x64 below (small grids), 128x128 only pays at M >= 16k.
+      const long long work = (long long)p.M * p.N * p.batch;
+      tile = work >= (long long)16384 * 4096 ? 1 : (work >= (long long)2048 * 1152 ? 2 : 3);
+    } else {
+      // fp32: pick the tile that wastes the fewest CU-rounds; smaller tiles pay more L2->LDS traffic
+      const double e1 = wave_eff(p.M, p.N, 128, 128, p.batch) * 0.90;
+      const double e2 = wave_eff(p.M, p.N, 128, 64, p.batch) * 0.98;
+      const double e3 = wave_eff(p.M, p.N, 64, 64, p.batch) * 0.96;
       tile = 1;
       double best = e1;
       if (e2 > best) { best = e2; tile = 2; }
@@ -271,6 +384,14 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
 
 // Profiling hooks: with profiling on, every GEMM launch is bracketed by two hipEvents on ITS stream.
 // kernel ids: 1..4 = dense tiles (128x128, 128x64, 64x64, 32x128), 11..14 = the same tiles with the implicit-conv loader.
+// Default arithmetic of every GEMM that does not ask for one explicitly: 0 = exact fp32 MFMA, 1 = bf16x3 split.
+extern "C" int rgm_set_gemm_precision(int prec) {
+  RGM_REQUIRE(prec == 0 || prec == 1, "set_gemm_precision: %d (0 = fp32, 1 = bf16x3)", prec);
+  rgm::g_default_prec = prec;
+  return RGM_OK;
+}
+extern "C" int rgm_get_gemm_precision(void) { return rgm::g_default_prec; }
+
 extern "C" int rgm_prof_enable(int on) {
   rgm::g_prof_on = on != 0;
   return RGM_OK;

@@ -59,6 +59,8 @@ def _load():
         "rgm_dit_grad_workspace_bytes": (sz, [vp, i32, i32]),
         "rgm_dit_cls_value_and_grad": (C.c_int, [vp, vp, vp, vp, i32, f32, vp, vp, i32, i32, vp, sz, vp]),
         "rgm_rotary_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "rgm_set_gemm_precision": (C.c_int, [i32]),
+        "rgm_get_gemm_precision": (C.c_int, []),
         "rgm_prof_enable": (C.c_int, [i32]),
         "rgm_prof_reset": (C.c_int, []),
         "rgm_prof_report": (C.c_int, [i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
@@ -84,6 +86,14 @@ lib = _Lazy()
 EXPORTS = ["rgm_version", "rgm_last_error", "rgm_dit_create", "rgm_dit_destroy", "rgm_dit_set_param",
            "rgm_dit_missing_params", "rgm_dit_workspace_bytes", "rgm_dit_forward", "rgm_dit_classify",
            "rgm_gemm", "rgm_layernorm_modulate", "rgm_rotary_attention"]
+
+
+PRECISIONS = {"fp32": 0, "bf16x3": 1}
+
+
+def set_gemm_precision(name):
+    """'fp32' (exact fp32 MFMA, default) or 'bf16x3' (split-bf16, ~3x the MFMA rate, ~2e-5 relative per product)."""
+    check(lib.rgm_set_gemm_precision(PRECISIONS[name]))
 
 
 def check(status):

@@ -115,7 +115,7 @@ def main(argv=None):
                 from rgm import synth
                 arch = dict(depth=clf.depth, hidden=clf.hidden_size, heads=clf.num_heads, patch=clf.patch_size,
                             in_ch=args.in_channels, classifier=True, cls_classes=cc.num_classes[i], chord=clf.chord)
-                clf.load_state_dict(synth.dit_state_dict(3 + i, **arch))
+                clf.load_state_dict(synth.dit_state_dict(3 + i, device=device, **arch))
             else:
                 clf.load_state_dict(dist_util.load_state_dict(cc.paths[i], map_location="cpu"))
             clf.to(device)

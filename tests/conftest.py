@@ -34,3 +34,12 @@ def rel_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+@pytest.fixture(params=["fp32", "bf16x3"])
+def precision(request):
+    """Run a GPU parity test under both GEMM arithmetics (exact fp32 MFMA and the bf16x3 split)."""
+    from rgm import native as R
+    R.set_gemm_precision(request.param)
+    yield request.param
+    R.set_gemm_precision("fp32")

@@ -21,7 +21,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-def gemm(A, B, bias=None, act=0, alpha=1.0, gate=None, rows_per_gate=1, res=None, tile=None):
+def gemm(A, B, bias=None, act=0, alpha=1.0, gate=None, rows_per_gate=1, res=None, tile=None, prec=None):
     """C = epi(alpha * A @ B.T) through rgm_gemm; numpy in, numpy out."""
     M, K = A.shape
     N = B.shape[0]
@@ -32,6 +32,8 @@ def gemm(A, B, bias=None, act=0, alpha=1.0, gate=None, rows_per_gate=1, res=None
     if res is not None:
         c.copy_(dev(res))
     st = R.current_stream()
+    if prec is not None:
+        tile = (tile or 0) | ((R.PRECISIONS[prec] + 1) << 4)
     if tile is None:
         R.check(R.lib.rgm_gemm(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bb), act, alpha,
                                R.ptr(gg), gate.shape[1] if gate is not None else 0, rows_per_gate,

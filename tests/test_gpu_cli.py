@@ -1,0 +1,49 @@
+"""-m gpu: scripts/sample_rule.py end to end with synthetic weights (no checkpoints exist offline) on short chains:
+flags, YAML handling, sampler, decode, rule report and CSV outputs -- the four shipped config families."""
+import importlib.util
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import PKG
+
+pytestmark = pytest.mark.gpu
+CFG = os.path.join(PKG, "scripts", "configs")
+
+
+def _cli():
+    spec = importlib.util.spec_from_file_location("sample_rule_cli", os.path.join(PKG, "scripts", "sample_rule.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+COMMON = ["--model", "DiTRotary_B_8", "--image_size", "128", "16", "--in_channels", "4", "--scale_factor", "1.2465",
+          "--class_cond", "True", "--num_classes", "3", "--class_label", "1", "--synthetic_weights", "True", "--progress", "False"]
+
+
+@pytest.mark.parametrize("cfg,extra,rules", [
+    ("cond_table/no_guidance/uncond_ddim50.yml", [], ["pitch_hist"]),
+    ("cond_demo/demo2.yml", ["--diffusion_steps", "25"], ["pitch_hist", "note_density"]),
+    ("cond_table/single/classifier/nd.yml", ["--diffusion_steps", "25"], ["note_density"]),
+    ("cond_table/all/scg_classifier_all.yml", ["--diffusion_steps", "25"], ["pitch_hist", "note_density"]),
+    ("cond_demo/demo_long.yml", ["--diffusion_steps", "20"], ["pitch_hist", "note_density"]),
+])
+def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
+    monkeypatch.chdir(tmp_path)
+    cli = _cli()
+    res = cli.main(["--config_path", os.path.join(CFG, cfg), "--batch_size", "2", "--num_samples", "2"] + COMMON + extra)
+    out_dir = os.path.join("loggings", cli.output_dir_for(os.path.join(CFG, cfg), 1))
+    df = pd.read_csv(os.path.join(out_dir, "results.csv"))
+    assert len(df) == 2 and len(res) == 2
+    for r in rules:
+        assert {f"{r}.target_rule", f"{r}.gen_rule", f"{r}.loss"} <= set(df.columns)
+        assert np.isfinite(df[f"{r}.loss"]).all()
+    assert os.path.exists(os.path.join(out_dir, "summary.csv"))
+    rolls = sorted(f for f in os.listdir(out_dir) if f.startswith("sample_") and f.endswith(".npy"))
+    assert rolls == ["sample_0_y_1.npy", "sample_1_y_1.npy"]
+    roll = np.load(os.path.join(out_dir, rolls[0]))
+    T = 4096 if "long" in cfg else 1024
+    assert roll.shape == (3, 128, T) and roll.dtype == np.uint8 and roll.max() <= 127

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 SM = dict(depth=2, hidden=384, heads=6, patch=8, in_ch=4, out_ch=4, num_classes=3)
 
 
-def test_split_merge_and_condind_eps():
+def test_split_merge_and_condind_eps(precision):
     from gpu_util import dev, rel, load_module
     from guided_diffusion.dit import DiTRotary
     import diff_collage as dc

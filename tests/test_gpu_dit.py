@@ -22,7 +22,7 @@ def _eps_model(arch):
 
 
 @pytest.mark.parametrize("tag,depth", [("xl_d2", 2), ("xl_d28", 28)])
-def test_dit_forward_matches_reference_golden(tag, depth):
+def test_dit_forward_matches_reference_golden(tag, depth, precision):
     from gpu_util import dev, rel, load_module
     g = load_golden(f"dit_{tag}")
     arch = dict(depth=depth, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4, num_classes=3)
@@ -34,7 +34,7 @@ def test_dit_forward_matches_reference_golden(tag, depth):
     # batch invariance + unconditional call path (y=None)
     x, t = dev(g["x128"]), dev(g["t128"])
     a = m(x.repeat(3, 1, 1, 1), t.repeat(3), dev(g["y128"]).repeat(3))
-    assert torch.equal(a[:2], a[2:4]) and torch.equal(a[:2], a[4:])
+    assert torch.equal(a[:2], a[2:4]) and torch.equal(a[:2], a[4:])        # same tiles, same arithmetic: bitwise
     assert m(x, t).shape == (2, 4, 128, 16)
 
 
@@ -47,7 +47,7 @@ def test_fresh_module_outputs_zero_like_the_reference():
 
 
 @pytest.mark.parametrize("tag,depth", [("s8", 12), ("s8d2", 2)])
-def test_classifier_logits(tag, depth):
+def test_classifier_logits(tag, depth, precision):
     from gpu_util import dev, rel, load_module
     from guided_diffusion.dit import DiTRotaryClassifier
     g = load_golden("classifier")
@@ -58,7 +58,7 @@ def test_classifier_logits(tag, depth):
     assert rel(out.cpu().numpy(), g[f"{tag}.logits"]) < TOL
 
 
-def test_chord_classifier_heads():
+def test_chord_classifier_heads(precision):
     from gpu_util import dev, rel, load_module
     from guided_diffusion.dit import DiTRotaryClassifier
     g = load_golden("classifier")
@@ -113,7 +113,7 @@ def test_attention_backward_kernel_vs_oracle():
 
 
 @pytest.mark.parametrize("tag,depth", [("s8d2", 2), ("s8", 12)])
-def test_classifier_guidance_gradient_matches_autograd_golden(tag, depth):
+def test_classifier_guidance_gradient_matches_autograd_golden(tag, depth, precision):
     from gpu_util import dev, rel, load_module
     from guided_diffusion.dit import DiTRotaryClassifier
     from guided_diffusion.condition_functions import grad_nn_zt_mse
@@ -130,7 +130,7 @@ def test_classifier_guidance_gradient_matches_autograd_golden(tag, depth):
     assert rel(m(x, t).cpu().numpy(), logits.cpu().numpy()) < 1e-6
 
 
-def test_chord_classifier_guidance_gradient():
+def test_chord_classifier_guidance_gradient(precision):
     from gpu_util import dev, rel, load_module
     from guided_diffusion.dit import DiTRotaryClassifier
     from guided_diffusion.condition_functions import grad_nn_zt_chord
@@ -142,7 +142,7 @@ def test_chord_classifier_guidance_gradient():
     assert rel(grad.cpu().numpy(), g["chord.grad"]) < 5e-4
 
 
-def test_classifier_guided_p_sample_step_matches_reference():
+def test_classifier_guided_p_sample_step_matches_reference(precision):
     """BASELINE config 3 shape in miniature: p_sample on the '250' chain with composite_nn_zt guidance."""
     from functools import partial
     from types import SimpleNamespace

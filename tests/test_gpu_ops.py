@@ -41,6 +41,21 @@ def test_gemm_asymmetric_data_all_tiles(tile, M, N, K):
     assert rel(out, _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)) < 2e-6
 
 
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(200, 96, 64), (513, 1152, 1152), (4096, 32, 1152), (777, 3456, 384)])
+def test_gemm_bf16x3_split_precision(tile, M, N, K):
+    """bf16x3 mode: three bf16 MFMAs per product, fp32 accumulate -- ~1e-5 of the output scale, not bf16's 3e-3."""
+    from gpu_util import gemm, rel
+    rng = np.random.RandomState(M + N + K + 1)
+    A = rng.randn(M, K).astype(F32)
+    B = (rng.randn(N, K) * (1 + np.arange(N)[:, None] / N)).astype(F32)
+    bias = rng.randn(N).astype(F32)
+    out = gemm(A, B, bias=bias, act=0, tile=tile, prec="bf16x3")
+    ref = _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)
+    assert rel(out, ref) < 3e-5
+    assert rel(out, ref) > 1e-8 or K < 64        # and it really is the split path, not the fp32 one
+
+
 @pytest.mark.parametrize("act", [0, 1, 2])
 def test_gemm_fused_epilogues(act):
     from gpu_util import gemm, rel

@@ -61,7 +61,7 @@ def test_philox_randn_is_counter_based_and_normal():
 
 
 @pytest.mark.parametrize("tag,rs,ddim", [("ddpm", "", False), ("ddim", "ddim50", True), ("ddpm250", "250", False)])
-def test_teacher_forced_step_matches_reference(tag, rs, ddim):
+def test_teacher_forced_step_matches_reference(tag, rs, ddim, precision):
     from gpu_util import dev, rel
     g = load_golden("steps")
     m = _dit(SM, 11)
@@ -75,7 +75,7 @@ def test_teacher_forced_step_matches_reference(tag, rs, ddim):
     assert rel(out["pred_xstart"].cpu().numpy(), g[f"{tag}.pred_xstart"]) < 2e-4
 
 
-def test_vae_decoder_matches_reference_and_uint8_roll():
+def test_vae_decoder_matches_reference_and_uint8_roll(precision):
     from gpu_util import dev, rel
     from guided_diffusion.midi_util import decode_sample_for_midi
     from guided_diffusion.gaussian_diffusion import _decode
@@ -86,7 +86,7 @@ def test_vae_decoder_matches_reference_and_uint8_roll():
     u8 = decode_sample_for_midi(dev(g["lat"]), embed_model=vae, scale_factor=1.2465, threshold=-0.95)
     assert u8.shape == (1, 128, 256, 3) and u8.dtype == torch.uint8
     bad = u8.cpu().numpy() != g["u8"]
-    assert bad.mean() < 3e-4, bad.sum()          # fp32 re-association across a truncation/threshold boundary (oracle: 5/98304)
+    assert bad.mean() < (3e-4 if precision == 'fp32' else 1e-3), bad.sum()          # fp32 re-association across a truncation/threshold boundary (oracle: 5/98304)
     # the integer stage itself is bit-exact: quantise the float roll with the oracle's quantiser
     from oracle import vae_np
     roll = _decode(dev(g["lat"]), vae, scale_factor=1.2465)
@@ -147,7 +147,7 @@ def test_rule_kernels_bit_exact_counts_and_side_effects():
     assert nd.shape == (2, 64) and np.allclose(nd[:, :32] * 128, np.round(nd[:, :32] * 128)) and np.allclose(nd[:, 32:] * 5, np.round(nd[:, 32:] * 5))
 
 
-def test_scg_step_selects_the_same_candidates_as_the_reference():
+def test_scg_step_selects_the_same_candidates_as_the_reference(precision):
     from types import SimpleNamespace
     from gpu_util import dev, rel
     g = load_golden("steps")
@@ -179,7 +179,7 @@ def test_scg_select_first_max_tie_break_and_nan():
 
 
 @pytest.mark.parametrize("tag,arch,seed", [("sm", SM, 11), ("xl28", dict(depth=28, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4, num_classes=3), 1)])
-def test_end_to_end_ddim50_latents_and_uint8_roll(tag, arch, seed):
+def test_end_to_end_ddim50_latents_and_uint8_roll(tag, arch, seed, precision):
     """BASELINE config 1 on the GPU: 50 DDIM steps (eta=1), B=2, injected noise; latents within the north
     star's 1e-3, decoded uint8 piano roll equal up to re-association flips (oracle itself: ~70/786432)."""
     from gpu_util import dev, rel
@@ -197,4 +197,4 @@ def test_end_to_end_ddim50_latents_and_uint8_roll(tag, arch, seed):
     u8 = decode_sample_for_midi(lat, embed_model=_vae(2), scale_factor=1.2465, threshold=-0.95).cpu().numpy()
     bad = u8 != g["u8"]
     assert bad.mean() < 1e-3, bad.sum()
-    print(f"[{tag}] latent rel err {rel(lat.cpu().numpy(), g['latent']):.2e}; uint8 mismatches {bad.sum()} / {bad.size}")
+    print(f"[{tag} {precision}] latent rel err {rel(lat.cpu().numpy(), g['latent']):.2e}; uint8 mismatches {bad.sum()} / {bad.size}")
