@@ -34,6 +34,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // fp32 -> (hi, lo) bf16 pair with x ~= hi + lo to ~2^-17 relative (both round-to-nearest-even, v_cvt_pk_bf16_f32)
 __device__ __forceinline__ void split_bf16(const float4& v, bf16x4& hi, bf16x4& lo) {
+#ifdef RGM_EXPERIMENT_NOSPLIT   // timing experiment only (wrong numerics): what if the operands arrived pre-split?
+  const uint2 t = make_uint2(__builtin_amdgcn_perm(__float_as_uint(v.y), __float_as_uint(v.x), 0x07060302u),
+                             __builtin_amdgcn_perm(__float_as_uint(v.w), __float_as_uint(v.z), 0x07060302u));
+  hi = *reinterpret_cast<const bf16x4*>(&t);
+  lo = hi;
+  return;
+#endif
   hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
   lo[0] = (__bf16)(v.x - (float)hi[0]);
   lo[1] = (__bf16)(v.y - (float)hi[1]);
@@ -231,37 +238,18 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
       }
     }
   };
-  if (PREC == 0) {
-    // fp32 MFMA: a K-tile is 32 MFMAs x 64 cycles per wave -- one tile of prefetch hides the global latency
-    gload(0, ra0, rb0);
-    lstore(0, ra0, rb0);
+  // one K-tile of prefetch: the next tile's global loads are issued before this tile's MFMAs and written to the other
+  // LDS buffer after them.  (A two-tile-deep register prefetch was measured for bf16x3: -17 % -- the extra 24-32
+  // VGPRs cost a wave of occupancy and the kernel is not latency-bound.)
+  gload(0, ra0, rb0);
+  lstore(0, ra0, rb0);
+  __syncthreads();
+  for (int kt = 0; kt < KT; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < KT) gload(kt + 1, ra0, rb0);
+    compute(buf);
+    if (kt + 1 < KT) lstore(buf ^ 1, ra0, rb0);
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-      const int buf = kt & 1;
-      if (kt + 1 < KT) gload(kt + 1, ra0, rb0);
-      compute(buf);
-      if (kt + 1 < KT) lstore(buf ^ 1, ra0, rb0);
-      __syncthreads();
-    }
-  } else {
-    // bf16x3: a K-tile is only ~12 MFMAs x 32 cycles per wave, shorter than an L2/HBM round trip, so the loads run
-    // TWO tiles ahead in two register sets (the compiler's counted vmcnt waits for the older set only).
-    float4 ra1[PA], rb1[PB];
-    gload(0, ra0, rb0);
-    if (KT > 1) gload(1, ra1, rb1);
-    lstore(0, ra0, rb0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; kt += 2) {
-      if (kt + 2 < KT) gload(kt + 2, ra0, rb0);
-      compute(0);
-      if (kt + 1 < KT) lstore(1, ra1, rb1);
-      __syncthreads();
-      if (kt + 1 >= KT) break;
-      if (kt + 3 < KT) gload(kt + 3, ra1, rb1);
-      compute(1);
-      if (kt + 2 < KT) lstore(0, ra0, rb0);
-      __syncthreads();
-    }
   }
 
   // ---- epilogue: C/D layout col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)

@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librgm_hip.so")
+LIB_PATH = os.environ.get("RGM_LIB_PATH", os.path.join(_HERE, "librgm_hip.so"))   # override: kernel experiments only
 
 
 class RgmError(RuntimeError):

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""Run ONE GEMM configuration a few times (for rocprofv3 --pmc passes): tools/gemm_one.py M N K tilecode [iters]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rule-guided-music_amd"))
+import torch  # noqa: E402
+from rgm import native as R  # noqa: E402
+
+M, N, K, tile = (int(x) for x in sys.argv[1:5])
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
+a = torch.randn(M, K, device="cuda")
+b = torch.randn(N, K, device="cuda") * 0.03
+c = torch.empty(M, N, device="cuda")
+bias = torch.randn(N, device="cuda")
+for _ in range(iters):
+    R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, R.current_stream()))
+torch.cuda.synchronize()

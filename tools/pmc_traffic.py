@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/traffic.json.
+
+usage: tools/pmc_traffic.py <fetch_pass.db> <write_pass.db> profiles/traffic.json
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM section): the counters are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of a wide coalesced read stream -> doubled; WRITE_SIZE is used as reported.
+bench.py reads the JSON to fill roofline.traffic for its dominant kernel.
+"""
+import json
+import re
+import sqlite3
+import sys
+
+
+def per_kernel(db, counter):
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name",
+                       (counter,)).fetchall()
+    return {short(n): (v, c) for n, v, c in rows if "rgm::" in n}      # library kernels only
+
+
+def short(name):
+    m = re.search(r"rgm::([A-Za-z0-9_]+(<[^>]*>)?)", name)
+    return (m.group(1) if m else name).replace(" ", "")
+
+
+def main(fdb, wdb, out):
+    f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
+    res, detail = {}, {}
+    for k in sorted(set(f) | set(w)):
+        fb = 2.0 * f.get(k, (0, 0))[0] * 1024.0
+        wb = w.get(k, (0, 0))[0] * 1024.0
+        res[k] = round(fb + wb)
+        detail[k] = {"fetch_bytes_corrected": round(fb), "write_bytes": round(wb), "launches_sampled": f.get(k, (0, 0))[1]}
+    res["_detail"] = detail
+    res["_note"] = "bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction), separate --pmc passes"
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    for k in list(res)[:12]:
+        print(k[:60], res[k] if not isinstance(res[k], dict) else "...")
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
