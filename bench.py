@@ -128,6 +128,45 @@ class SCGWorkload:
         self.x = out["sample"]
 
 
+class C3Workload:
+    """Classifier guidance only (config[2]): p_sample on the '250' chain, batch 32, one DiTRotary-S/8-cls (note density)."""
+    name = "C3 classifier-guided DDPM step ('250' chain), DiTRotary_XL_8 + DiTRotary-S/8-cls value-and-grad, batch 32"
+
+    def __init__(self, device, batch):
+        from functools import partial
+        from types import SimpleNamespace
+        from rgm import synth
+        from guided_diffusion.dit import DiT_models
+        from guided_diffusion.condition_functions import model_fn, composite_nn_zt
+        self.B = batch
+        self.device = device
+        self.model = build_eps_model(0, device)
+        self.fn = partial(model_fn, model=self.model, num_classes=0, class_cond=False, cfg=False, w=0.)
+        clf = DiT_models["DiTRotary-S/8-cls"](input_size=[128, 16], in_channels=4, num_classes=16)
+        arch = dict(depth=12, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=16)
+        clf.load_state_dict(synth.dit_state_dict(3, device=device, **arch))
+        self.clf = clf.to(device).eval()
+        self.cond = partial(composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[self.clf],
+                            rule_names=["note_density"])
+        self.d = make_diffusion("250")
+        self.d.t_end = 0
+        self.x = self.d._draw((batch, 4, 128, 16), device)
+        self.kw = {"rule": {"note_density": torch.tensor([3.] * 16, device=device).repeat(batch, 1)}}
+        self.guid = SimpleNamespace(schedule=False, method="classifier_guidance")
+        self.k = 0
+        self.flop_per_step = batch * (DIT_GFLOP_PER_SAMPLE + 25.4) * 1e9
+
+    def step(self):
+        i = 249 - (self.k % 250)
+        self.k += 1
+        t = torch.full((self.B,), i, dtype=torch.int64, device=self.device)
+        self.d._t_host = i
+        out = self.d.p_sample(self.fn, self.x, t, clip_denoised=False, cond_fn=self.cond, model_kwargs=self.kw,
+                              guidance_kwargs=self.guid)
+        self.d._t_host = None
+        self.x = out["sample"]
+
+
 def roofline_pass(work, steps=2):
     """Dominant-kernel roofline from HIP events around every GEMM launch (its own short pass)."""
     from rgm import native as R
@@ -205,7 +244,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "scg"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default=os.environ.get("RGM_BENCH_PRECISION", "bf16x3"), choices=["fp32", "bf16x3"],
                     help="GEMM arithmetic: bf16x3 split (default; fp32-grade: 2.5e-6 latent error on the 50-step golden, "
@@ -227,8 +266,8 @@ def main():
     from rgm import native as R
     R.set_gemm_precision(args.precision)
     torch.manual_seed(0)
-    batch = args.batch or (16 if args.workload == "c2" else 4)
-    work = (C2Workload if args.workload == "c2" else SCGWorkload)(device, batch)
+    batch = args.batch or {"c2": 16, "c3": 32, "scg": 4}[args.workload]
+    work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload}[args.workload](device, batch)
     for _ in range(args.warmup):
         work.step()
 

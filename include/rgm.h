@@ -98,6 +98,14 @@ int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const
  * Process-wide default used by all handles; results stay within the 1e-3 latent tolerance either way (tests). */
 int rgm_set_gemm_precision(int prec);
 int rgm_get_gemm_precision(void);
+/* Split-row format of the bf16x3 fast path: a logical fp32 row of K values stored in the same K*4 bytes as K bf16
+ * `hi` followed by K bf16 `lo` (x ~= hi + lo).  rgm_split_rows converts (rows,K) fp32 -> split (out-of-place);
+ * rgm_gemm_split is the LDS-DMA kernel on operands already in that format (A (M,K), B (N,K) both split):
+ * C = act(A . B^T + bias), optionally written split as well (N%4==0).  tile: 0 auto, 1 128x128, 2 128x64,
+ * 3 64x64, 5 256x128. */
+int rgm_split_rows(const float* x, float* out, int64_t rows, int K, void* stream);
+int rgm_gemm_split(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias,
+                   int act, int tile, int out_split, void* stream);
 /* Same as rgm_gemm without gate/residual but with an explicit tile shape in the low 4 bits (1: 128x128,
  * 2: 128x64, 3: 64x64, 4: 32x128, 0: auto) and an explicit precision in bits 4.. (0: library default,
  * 1: fp32, 2: bf16x3) -- used by the parity tests and tile-selection experiments. */

@@ -29,7 +29,8 @@ def linear(x, w, b=None):
 
 
 def silu(x):
-    return x / (1 + np.exp(-x))
+    with np.errstate(over="ignore"):          # exp(+large) -> inf -> x/inf = -0: the correct limit
+        return x / (1 + np.exp(-x))
 
 
 def gelu_tanh(x):

@@ -107,8 +107,16 @@ struct GemmParams {
   int tile = 0;
   // arithmetic: -1 library default (rgm_set_gemm_precision), 0 fp32 MFMA, 1 bf16x3 split
   int prec = -1;
+  // gemm2 (pre-split operands): write C in split-row format (N bf16 hi | N bf16 lo per row) for the next GEMM
+  int out_split = 0;
 };
 int gemm_launch(const GemmParams& p, hipStream_t stream);
+// gemm2.hip: the same contraction on operands already in split-row format (K bf16 hi | K bf16 lo per row)
+int gemm2_launch(const GemmParams& p, hipStream_t stream);
+int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_in, int ld_out, hipStream_t s);
+void gemm2_prof(bool on);
+void gemm2_prof_reset();
+int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total_flops);
 
 // elementwise / reductions (elementwise.hip)
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,

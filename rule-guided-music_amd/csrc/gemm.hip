@@ -296,6 +296,16 @@ static int launch_cfg(const GemmParams& p, hipStream_t s, int tile_id) {
   const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
   const size_t lds = (size_t)2 * (BM + BN) * 32 * sizeof(float);
   dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64);
+  if (lds > 65536) {   // 256x128 tile: 96 KiB of dynamic LDS needs the opt-in (once per instantiation)
+    static bool done[2][2] = {{false, false}, {false, false}};
+    const int pr = (p.prec < 0 ? g_default_prec : p.prec) ? 1 : 0, al = p.aload ? 1 : 0;
+    if (!done[pr][al]) {
+      const void* fn = pr ? (al ? (const void*)gemm_kernel<BM, BN, WM, WN, 1, 1> : (const void*)gemm_kernel<BM, BN, WM, WN, 0, 1>)
+                          : (al ? (const void*)gemm_kernel<BM, BN, WM, WN, 1, 0> : (const void*)gemm_kernel<BM, BN, WM, WN, 0, 0>);
+      RGM_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done[pr][al] = true;
+    }
+  }
   ProfRec rec{};
   if (g_prof_on) {
     RGM_CHECK_HIP(hipEventCreate(&rec.a));
@@ -362,6 +372,7 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
     case 2: return launch_cfg<128, 64, 2, 2>(p, s, 2);
     case 3: return launch_cfg<64, 64, 2, 2>(p, s, 3);
     case 4: return launch_cfg<32, 128, 1, 4>(p, s, 4);
+    case 5: return launch_cfg<256, 128, 4, 2>(p, s, 5);
     default: break;
   }
   set_error("gemm: unknown tile %d", tile);

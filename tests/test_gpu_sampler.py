@@ -198,3 +198,41 @@ def test_end_to_end_ddim50_latents_and_uint8_roll(tag, arch, seed, precision):
     bad = u8 != g["u8"]
     assert bad.mean() < 1e-3, bad.sum()
     print(f"[{tag} {precision}] latent rel err {rel(lat.cpu().numpy(), g['latent']):.2e}; uint8 mismatches {bad.sum()} / {bad.size}")
+
+
+def test_sharded_scg_rank_sees_same_winner_and_rebuilds_it(monkeypatch):
+    """The multi-GPU SCG protocol on one GPU: run the step unsharded, then replay it as 'rank 1 of 2' (candidates
+    8..15 only, the other rank's log-probs supplied by a stand-in all-gather).  Same (n,B) table, same first-argmax,
+    and the winner -- even when it belongs to the other rank -- is rebuilt bit-exactly from the Philox counters."""
+    from types import SimpleNamespace
+    from gpu_util import dev
+    from rgm import scg_shard
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    g = load_golden("steps")
+    m, vae = _dit(SM, 11), _vae(2)
+    tgt = {"pitch_hist": dev(g["scg.target.pitch_hist"]), "note_density": dev(g["scg.target.note_density"])}
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    scg = {"num_samples": 16, "pitch_hist": 40., "note_density": 1.}
+
+    def run(d):
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=99)
+        out = d.p_sample(_model_fn(m), dev(g["x"]), dev(g["scg.t"]), clip_denoised=False,
+                         model_kwargs={"y": dev(g["y"]), "rule": tgt}, embed_model=vae, scale_factor=1.2465,
+                         guidance_kwargs=guid, scg_kwargs=scg)
+        return out["sample"], d.last_scg["total_log_prob"].clone(), d.last_scg["max_ind"].clone()
+
+    ref_sample, ref_total, ref_idx = run(_diffusion(""))
+    for rank in (0, 1):
+        monkeypatch.setattr(scg_shard, "partition", lambda n, r=rank: (r * n // 2, n // 2, True))
+
+        def fake_gather(local, r=rank):
+            assert torch.equal(local, ref_total[r * 8:(r + 1) * 8])            # this rank's scores == the unsharded ones
+            parts = [ref_total[:8], ref_total[8:]]
+            parts[r] = local
+            return torch.cat(parts, dim=0)
+        monkeypatch.setattr(scg_shard, "gather_totals", fake_gather)
+        s, total, idx = run(_diffusion(""))
+        assert torch.equal(idx, ref_idx) and torch.equal(total, ref_total)
+        assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt winner differs"
+    assert len(set(ref_idx.tolist())) >= 1

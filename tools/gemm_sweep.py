@@ -21,12 +21,22 @@ def bench(M, N, K, tile, iters=20):
     c = torch.empty(M, N, device="cuda")
     bias = torch.randn(N, device="cuda")
     st = R.current_stream()
+    if tile >= 100:                                   # 100 + t: pre-split operands, LDS-DMA kernel (gemm2), tile t
+        a2, b2 = torch.empty_like(a), torch.empty_like(b)
+        R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st))
+        R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), N, K, st))
+
+        def run():
+            R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), 0, tile - 100, 0, st))
+    else:
+        def run():
+            R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
     for _ in range(3):
-        R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
+        run()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
-        R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
+        run()
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
