@@ -40,7 +40,7 @@ template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                const float* __restrict__ cos_tab,
                                                                const float* __restrict__ sin_tab, int T, int heads,
-                                                               int rot_half, float* __restrict__ lse) {
+                                                               int rot_half, float* __restrict__ lse, int out_split) {
   constexpr int HDP = HD + 4;          // padded K row (floats)
   constexpr int KB = HD / 8;           // k-blocks of 8 in QK^T
   constexpr int DT = (HD + 31) / 32;   // 32-wide output-channel tiles
@@ -177,9 +177,21 @@ __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __re
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = dt * 32 + 8 * g + 4 * hh;
-          if (d < HD)
-            *reinterpret_cast<float4*>(op + d) =
-                make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+          if (d < HD) {
+            const float4 ov = make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+            if (out_split) {   // row = D bf16 hi | D bf16 lo (A operand of the pre-split proj GEMM)
+              typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+              bf16x4 hi, lo;
+              hi[0] = (__bf16)ov.x; hi[1] = (__bf16)ov.y; hi[2] = (__bf16)ov.z; hi[3] = (__bf16)ov.w;
+              lo[0] = (__bf16)(ov.x - (float)hi[0]); lo[1] = (__bf16)(ov.y - (float)hi[1]);
+              lo[2] = (__bf16)(ov.z - (float)hi[2]); lo[3] = (__bf16)(ov.w - (float)hi[3]);
+              __bf16* rp = reinterpret_cast<__bf16*>(o + ((long long)n * T + q) * D);
+              *reinterpret_cast<bf16x4*>(rp + head * HD + d) = hi;
+              *reinterpret_cast<bf16x4*>(rp + D + head * HD + d) = lo;
+            } else {
+              *reinterpret_cast<float4*>(op + d) = ov;
+            }
+          }
         }
     }
   }
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __re
 
 template <int HD, int NKT>
 static int launch_attn(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads,
-                       int rot_half, float* lse, hipStream_t s) {
+                       int rot_half, float* lse, int out_split, hipStream_t s) {
   constexpr int TP = NKT * 32;
   // V strip + K strip; channel reads of the last (partial) 32-wide tile run past a V row into the
   // next row / the K strip, which is finite data feeding discarded accumulator rows only.
@@ -198,27 +210,27 @@ static int launch_attn(const float* qkv, float* o, const float* ct, const float*
     RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse);
+  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
 int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T,
-                            int heads, int hd, int rot_half, hipStream_t s, float* lse) {
+                            int heads, int hd, int rot_half, hipStream_t s, float* lse, int out_split) {
   RGM_REQUIRE(N > 0 && T > 0 && T <= 288, "attention: T=%d out of range (1..288)", T);
   RGM_REQUIRE((2 * rot_half) % 4 == 0 && 2 * rot_half <= hd, "attention: rotary dim %d", 2 * rot_half);
   const int nkt = (T + 31) / 32;
   if (hd == 72) {
-    if (nkt <= 4) return launch_attn<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
-    if (nkt <= 8) return launch_attn<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
+    if (nkt <= 4) return launch_attn<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    if (nkt <= 8) return launch_attn<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
     set_error("attention: head_dim 72 supports T <= 256 (K+V of one head must fit the 160 KiB LDS), got %d", T);
     return RGM_ERR_INVALID;
   }
   if (hd == 64) {
-    if (nkt <= 4) return launch_attn<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
-    if (nkt <= 5) return launch_attn<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
-    if (nkt <= 8) return launch_attn<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
-    return launch_attn<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, s);
+    if (nkt <= 4) return launch_attn<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    if (nkt <= 5) return launch_attn<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    if (nkt <= 8) return launch_attn<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    return launch_attn<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
   }
   set_error("attention: head_dim %d not supported (64, 72)", hd);
   return RGM_ERR_INVALID;

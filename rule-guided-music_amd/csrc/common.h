@@ -121,9 +121,9 @@ int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total
 // elementwise / reductions (elementwise.hip)
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,
                               const float* bias, const float* shift, const float* scale, int mod_ld,
-                              int rows_per_batch, hipStream_t s);
+                              int rows_per_batch, hipStream_t s, int out_split = 0);
 int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N,
-                            int T, int heads, int hd, int rot_half, hipStream_t s, float* lse = nullptr);
+                            int T, int heads, int hd, int rot_half, hipStream_t s, float* lse = nullptr, int out_split = 0);
 // attention backward (attention_bwd.hip): dqkv (N*T, 3*heads*hd) from dO, the saved qkv / O / lse
 int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                 const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,

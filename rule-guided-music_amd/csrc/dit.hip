@@ -80,6 +80,18 @@ static void add_t_slot(rgm_dit* h, const std::string& key, int out_f, int in_f) 
   h->arena_floats += s.numel;
 }
 
+// split-row copy (gemm2.hip format) of a Linear weight [out][in]: B operand of the pre-split bf16x3 GEMM path
+static void add_s_slot(rgm_dit* h, const std::string& key, int out_f, int in_f) {
+  Slot s;
+  s.off = h->arena_floats;
+  s.numel = (size_t)out_f * in_f;
+  s.set = true;
+  s.t_rows = out_f;
+  s.t_cols = in_f;
+  h->slots[key + ".S"] = s;
+  h->arena_floats += s.numel;
+}
+
 extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
   RGM_REQUIRE(c && out, "dit_create: null argument");
   RGM_REQUIRE(c->hidden % c->heads == 0 && c->hidden % 32 == 0, "dit_create: hidden=%d heads=%d", c->hidden, c->heads);
@@ -142,6 +154,16 @@ extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
       add_slot(h, "classifier_head_key.2.bias", 25);
     }
   }
+  {
+    const int Di = c->hidden;
+    for (int i = 0; i < c->depth; ++i) {
+      const std::string b = "blocks." + std::to_string(i) + ".";
+      add_s_slot(h, b + "attn.qkv.weight", 3 * Di, Di);
+      add_s_slot(h, b + "attn.proj.weight", Di, Di);
+      add_s_slot(h, b + "mlp.fc1.weight", 4 * Di, Di);
+      add_s_slot(h, b + "mlp.fc2.weight", Di, 4 * Di);
+    }
+  }
   if (c->kind != 0) {              // classifiers are differentiated w.r.t. their input (guidance): keep W^T too
     const int Di = c->hidden;
     add_t_slot(h, "x_embedder.MLP.0.weight", 256, pc);
@@ -197,6 +219,12 @@ extern "C" int rgm_dit_set_param(rgm_dit* h, const char* key, const void* dptr, 
   if (tt != h->slots.end()) {
     const Slot& ts = tt->second;
     RGM_TRY(transpose_launch(h->arena + it->second.off, h->arena + ts.off, ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
+    RGM_CHECK_HIP(hipStreamSynchronize(0));
+  }
+  auto ss = h->slots.find(k + ".S");
+  if (ss != h->slots.end()) {
+    const Slot& sl = ss->second;
+    RGM_TRY(split_rows_launch(h->arena + it->second.off, h->arena + sl.off, sl.t_rows, sl.t_cols, sl.t_cols, sl.t_cols, 0));
     RGM_CHECK_HIP(hipStreamSynchronize(0));
   }
   if (k == "rotary_emb.freqs") {
@@ -317,9 +345,37 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
   const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
   RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, p.N, D, s));
   RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, p.N, L, D, 0, s));
+  const bool v2 = rgm_get_gemm_precision() == 2;   // bf16x3 with pre-split operands: producers emit split rows, gemm2 consumes
+  auto lin2 = [&](const float* A, const std::string& wkey, const float* bias, float* C, int N, int K, int act, int out_split,
+                  const float* gate, const float* res, int tile) {
+    GemmParams g;
+    g.tile = tile;
+    g.A = A; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
+    g.M = p.M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
+    if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
+    return gemm2_launch(g, s);
+  };
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string(i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
+    if (v2) {
+      // per-GEMM kernel choice from tools/gemm_sweep.py on MI355X (M = 4096 rows): the LDS-DMA kernel wins where its
+      // 256x128 tile fits the grid (qkv, fc2) or the GEMM is short (proj); fc1 stays on the on-the-fly 128x64 kernel.
+      const bool big = p.M >= 2048;
+      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
+      RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, big ? 5 : 0));
+      RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, nullptr, 1));
+      RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 3));
+      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 0));
+      {
+        GemmParams g;   // fc1 on the fly (prec 1), GELU fused, output written split for the DMA kernel of fc2
+        g.A = p.xm; g.lda = D; g.B = h->p(b + "mlp.fc1.weight"); g.ldb = D; g.C = p.hid; g.ldc = 4 * D;
+        g.M = p.M; g.N = 4 * D; g.K = D; g.bias = h->p(b + "mlp.fc1.bias"); g.act = 2; g.out_split = 1; g.prec = 1;
+        RGM_TRY(gemm_launch(g, s));
+      }
+      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, big ? 5 : 0));
+      continue;
+    }
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, p.M, 3 * D, D, 0, s));
     RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s));

@@ -17,7 +17,8 @@ template <int MAXV>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, float* __restrict__ out, int M, int D,
                                                      float eps, const float* __restrict__ weight,
                                                      const float* __restrict__ bias, const float* __restrict__ shift,
-                                                     const float* __restrict__ scale, int mod_ld, int rows_per_batch) {
+                                                     const float* __restrict__ scale, int mod_ld, int rows_per_batch,
+                                                     int out_split) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
@@ -57,12 +58,24 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
       const float4 sc = reinterpret_cast<const float4*>(scale + mo)[c], sh = reinterpret_cast<const float4*>(shift + mo)[c];
       y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
     }
-    orow[c] = y;
+    if (out_split) {   // split-row format for the pre-split GEMM path: D bf16 hi | D bf16 lo in the same D*4 bytes
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 hi, lo;
+      hi[0] = (__bf16)y.x; hi[1] = (__bf16)y.y; hi[2] = (__bf16)y.z; hi[3] = (__bf16)y.w;
+      lo[0] = (__bf16)(y.x - (float)hi[0]); lo[1] = (__bf16)(y.y - (float)hi[1]);
+      lo[2] = (__bf16)(y.z - (float)hi[2]); lo[3] = (__bf16)(y.w - (float)hi[3]);
+      __bf16* rp = reinterpret_cast<__bf16*>(out + (long long)row * D);
+      *reinterpret_cast<bf16x4*>(rp + c * 4) = hi;
+      *reinterpret_cast<bf16x4*>(rp + D + c * 4) = lo;
+    } else {
+      orow[c] = y;
+    }
   }
 }
 
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight, const float* bias,
-                              const float* shift, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s) {
+                              const float* shift, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s,
+                              int out_split) {
   RGM_REQUIRE(M > 0 && D > 0 && (D & 3) == 0 && D <= 2048, "layernorm: D=%d must be a multiple of 4, <= 2048", D);
   RGM_REQUIRE((scale == nullptr) == (shift == nullptr) && (weight == nullptr) == (bias == nullptr), "layernorm: shift/scale and weight/bias come in pairs");
   RGM_REQUIRE(scale == nullptr || ((mod_ld & 3) == 0 && ((uintptr_t)scale & 15) == 0 && ((uintptr_t)shift & 15) == 0), "layernorm: modulation rows must be 16-byte aligned");
@@ -70,11 +83,11 @@ int layernorm_modulate_launch(const float* x, float* out, int M, int D, float ep
   dim3 grid(cdiv(M, 4)), block(256);
   const int nv = D / 4;
   if (nv <= 128)
-    hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch);
+    hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
   else if (nv <= 320)
-    hipLaunchKernelGGL(ln_mod_kernel<5>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch);
+    hipLaunchKernelGGL(ln_mod_kernel<5>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
   else
-    hipLaunchKernelGGL(ln_mod_kernel<8>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch);
+    hipLaunchKernelGGL(ln_mod_kernel<8>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -275,7 +275,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
         else if (p.act == 4) v *= silu_grad_f(auxb[(long long)row * p.ldaux + col]);
         if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
         if (resb) v += resb[(long long)row * p.ldres + col];
-        Cb[(long long)row * p.ldc + col] = v;
+        if (p.out_split) {   // split-row output (N bf16 hi | N bf16 lo) feeding a pre-split consumer (gemm2.hip)
+          __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+          const __bf16 hi = (__bf16)v;
+          rowp[col] = hi;
+          rowp[p.N + col] = (__bf16)(v - (float)hi);
+        } else {
+          Cb[(long long)row * p.ldc + col] = v;
+        }
       }
     }
   }
@@ -314,7 +321,7 @@ static int launch_cfg(const GemmParams& p, hipStream_t s, int tile_id) {
     rec.flops = 2.0 * p.M * (double)p.N * p.K * p.batch;
     RGM_CHECK_HIP(hipEventRecord(rec.a, s));
   }
-  const int prec = p.prec < 0 ? g_default_prec : p.prec;
+  const int prec = (p.prec < 0 ? g_default_prec : p.prec) ? 1 : 0;
   if (prec == 0) {
     if (p.aload == 0)
       hipLaunchKernelGGL((gemm_kernel<BM, BN, WM, WN, 0, 0>), grid, block, lds, s, p, tm, tn);
@@ -347,7 +354,7 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm: operands must be 16-byte aligned with ld%%4==0");
   int tile = p.tile;
-  const int prec = p.prec < 0 ? g_default_prec : p.prec;
+  const int prec = (p.prec < 0 ? g_default_prec : p.prec) ? 1 : 0;
   if (tile == 0) {
     if (p.M <= 64) tile = 4;
     else if (prec == 1) {
@@ -385,7 +392,7 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
 // kernel ids: 1..4 = dense tiles (128x128, 128x64, 64x64, 32x128), 11..14 = the same tiles with the implicit-conv loader.
 // Default arithmetic of every GEMM that does not ask for one explicitly: 0 = exact fp32 MFMA, 1 = bf16x3 split.
 extern "C" int rgm_set_gemm_precision(int prec) {
-  RGM_REQUIRE(prec == 0 || prec == 1, "set_gemm_precision: %d (0 = fp32, 1 = bf16x3)", prec);
+  RGM_REQUIRE(prec >= 0 && prec <= 2, "set_gemm_precision: %d (0 = fp32, 1 = bf16x3 split on the fly, 2 = bf16x3 with pre-split operands where available)", prec);
   rgm::g_default_prec = prec;
   return RGM_OK;
 }
@@ -393,6 +400,7 @@ extern "C" int rgm_get_gemm_precision(void) { return rgm::g_default_prec; }
 
 extern "C" int rgm_prof_enable(int on) {
   rgm::g_prof_on = on != 0;
+  rgm::gemm2_prof(on != 0);
   return RGM_OK;
 }
 extern "C" int rgm_prof_reset(void) {
@@ -401,10 +409,12 @@ extern "C" int rgm_prof_reset(void) {
     (void)hipEventDestroy(r.b);
   }
   rgm::g_prof.clear();
+  rgm::gemm2_prof_reset();
   return RGM_OK;
 }
 // sums over the recorded launches of kernel id `kernel`: launches, total milliseconds, total algorithmic FLOPs (2MNK)
 extern "C" int rgm_prof_report(int kernel, int* launches, double* total_ms, double* total_flops) {
+  if (kernel >= 40) return rgm::gemm2_prof_report(kernel, launches, total_ms, total_flops);   // gemm2.hip kernels
   int n = 0;
   double ms = 0.0, fl = 0.0;
   for (auto& r : rgm::g_prof) {

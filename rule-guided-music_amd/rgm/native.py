@@ -90,7 +90,7 @@ EXPORTS = ["rgm_version", "rgm_last_error", "rgm_dit_create", "rgm_dit_destroy",
            "rgm_gemm", "rgm_layernorm_modulate", "rgm_rotary_attention"]
 
 
-PRECISIONS = {"fp32": 0, "bf16x3": 1}
+PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x3_presplit": 2}
 
 
 def set_gemm_precision(name):

@@ -36,7 +36,7 @@ def rel_err(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
-@pytest.fixture(params=["fp32", "bf16x3"])
+@pytest.fixture(params=["fp32", "bf16x3", "bf16x3_presplit"])
 def precision(request):
     """Run a GPU parity test under both GEMM arithmetics (exact fp32 MFMA and the bf16x3 split)."""
     from rgm import native as R
