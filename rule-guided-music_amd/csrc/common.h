@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../include/rgm.h"
 
 namespace rgm {
@@ -44,6 +45,21 @@ void set_error(const char* fmt, ...);
   } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// "Split row" format (pre-split bf16x3 operands, gemm2.hip): a logical fp32 row of K elements keeps its K*4 bytes;
+// every block of 32 elements becomes one 128-byte line [32 bf16 hi | 32 bf16 lo] (x ~= hi + lo, round-to-nearest each).
+// Returns the bf16 index of element `col`'s hi part within the row; its lo part is 32 further.
+__host__ __device__ __forceinline__ int split_idx(int col) { return ((col >> 5) << 6) + (col & 31); }
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- guarantees static register indexing where
+// `#pragma unroll` on a large nest is only a request
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -359,21 +359,15 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     const std::string b = "blocks." + std::to_string(i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
     if (v2) {
-      // per-GEMM kernel choice from tools/gemm_sweep.py on MI355X (M = 4096 rows): the LDS-DMA kernel wins where its
-      // 256x128 tile fits the grid (qkv, fc2) or the GEMM is short (proj); fc1 stays on the on-the-fly 128x64 kernel.
-      const bool big = p.M >= 2048;
+      // every producer (adaLN-LayerNorm, attention, fc1's GELU epilogue) writes split rows; all four GEMMs run on the
+      // LDS-DMA kernel (gemm2.hip picks the tile)
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
-      RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, big ? 5 : 0));
+      RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, 0));
       RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, nullptr, 1));
-      RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 3));
-      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 0));
-      {
-        GemmParams g;   // fc1 on the fly (prec 1), GELU fused, output written split for the DMA kernel of fc2
-        g.A = p.xm; g.lda = D; g.B = h->p(b + "mlp.fc1.weight"); g.ldb = D; g.C = p.hid; g.ldc = 4 * D;
-        g.M = p.M; g.N = 4 * D; g.K = D; g.bias = h->p(b + "mlp.fc1.bias"); g.act = 2; g.out_split = 1; g.prec = 1;
-        RGM_TRY(gemm_launch(g, s));
-      }
-      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, big ? 5 : 0));
+      RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 0));
+      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
+      RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, 2, 1, nullptr, nullptr, 0));
+      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, 0));
       continue;
     }
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));

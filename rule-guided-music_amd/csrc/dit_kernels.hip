@@ -58,15 +58,16 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
       const float4 sc = reinterpret_cast<const float4*>(scale + mo)[c], sh = reinterpret_cast<const float4*>(shift + mo)[c];
       y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
     }
-    if (out_split) {   // split-row format for the pre-split GEMM path: D bf16 hi | D bf16 lo in the same D*4 bytes
+    if (out_split) {   // split-row format (common.h split_idx) for the pre-split GEMM path
       typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 hi, lo;
       hi[0] = (__bf16)y.x; hi[1] = (__bf16)y.y; hi[2] = (__bf16)y.z; hi[3] = (__bf16)y.w;
       lo[0] = (__bf16)(y.x - (float)hi[0]); lo[1] = (__bf16)(y.y - (float)hi[1]);
       lo[2] = (__bf16)(y.z - (float)hi[2]); lo[3] = (__bf16)(y.w - (float)hi[3]);
       __bf16* rp = reinterpret_cast<__bf16*>(out + (long long)row * D);
-      *reinterpret_cast<bf16x4*>(rp + c * 4) = hi;
-      *reinterpret_cast<bf16x4*>(rp + D + c * 4) = lo;
+      const int si = split_idx(c * 4);
+      *reinterpret_cast<bf16x4*>(rp + si) = hi;
+      *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
     } else {
       orow[c] = y;
     }

@@ -275,11 +275,11 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
         else if (p.act == 4) v *= silu_grad_f(auxb[(long long)row * p.ldaux + col]);
         if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
         if (resb) v += resb[(long long)row * p.ldres + col];
-        if (p.out_split) {   // split-row output (N bf16 hi | N bf16 lo) feeding a pre-split consumer (gemm2.hip)
+        if (p.out_split) {   // split-row output (common.h split_idx) feeding a pre-split consumer (gemm2.hip)
           __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
           const __bf16 hi = (__bf16)v;
-          rowp[col] = hi;
-          rowp[p.N + col] = (__bf16)(v - (float)hi);
+          rowp[split_idx(col)] = hi;
+          rowp[split_idx(col) + 32] = (__bf16)(v - (float)hi);
         } else {
           Cb[(long long)row * p.ldc + col] = v;
         }
@@ -353,6 +353,7 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(p.aload == 0 || (p.Cin % 32 == 0 && p.K == 9 * p.Cin), "gemm: implicit conv needs Cin%%32==0, K=9*Cin");
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm: operands must be 16-byte aligned with ld%%4==0");
+  RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm: split-row output needs N%%32==0 (N=%d)", p.N);
   int tile = p.tile;
   const int prec = (p.prec < 0 ? g_default_prec : p.prec) ? 1 : 0;
   if (tile == 0) {

@@ -8,14 +8,18 @@
 // per MFMA (the split) keep the VALU pipe busier (41 %) than the matrix pipe (33 %), and the VGPR round trip
 // serialises load-wait / split / ds_write behind the MFMAs of the same wave.
 //
-// "Split row" format: a logical fp32 row of K elements occupies the same K*4 bytes -- K bf16 `hi` followed by
-// K bf16 `lo` (x ~= hi + lo, both round-to-nearest) -- so split tensors drop into fp32-sized buffers and strides.
+// "Split row" format (common.h split_idx): a logical fp32 row of K elements keeps its K*4 bytes; every block of 32
+// elements is one 128-byte line [32 bf16 hi | 32 bf16 lo] (x ~= hi + lo, both round-to-nearest) -- so split tensors
+// drop into fp32-sized buffers and strides, and one row of one 32-wide K tile is exactly one cache line (a layout
+// with separate hi / lo planes made every DMA piece touch 16 half-used lines: measured ~31 cycles per piece per CU).
 //
-// Structure: global -> LDS by `global_load_lds_dwordx4` (no VGPRs, no VALU): one wave-instruction moves 16 rows x
-// 64 B of one plane; the XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied on the
-// per-lane SOURCE address (the LDS image of a DMA is lane-linear).  3-stage LDS ring, DMA two K-tiles ahead,
+// Structure: global -> LDS by `global_load_lds_dwordx4` (no VGPRs, no VALU): one wave-instruction moves 8 rows x
+// 128 B; the XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free is applied on the per-lane
+// SOURCE address (the LDS image of a DMA is lane-linear).  3-stage LDS ring, DMA two K-tiles ahead,
 // counted `s_waitcnt vmcnt(N)` + one raw `s_barrier` per K-tile (never __syncthreads: it would drain the DMA queue).
 // Out-of-range rows (M / N tails, conv zero padding) read a zero page, so the kernel has no divergent loads.
+#include <stdlib.h>
+#include <stdint.h>
 #include <vector>
 #include "common.h"
 
@@ -29,16 +33,21 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN, int ALOAD>
+template <int BM, int BN, int WM, int WN, int ALOAD, int NSTAGE, int DBG = 0, int PIPE = 0>
 __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m,
-                                                            int tiles_n) {
+                                                            int tiles_n, int exp, long long* __restrict__ dbg = nullptr) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int STAGE = (BM + BN) * 128;        // bytes per ring stage: [A hi | A lo | B hi | B lo], 64 B per row and plane
-  constexpr int SEGS = (BM + BN) / 8;           // 1-KiB DMA segments per stage (16 rows x 64 B of one plane)
-  constexpr int SPW = SEGS / NW;                // segments per wave
-  static_assert(SEGS % NW == 0, "segments must divide evenly over the waves");
+  constexpr int STAGE = (BM + BN) * 128;        // bytes per ring stage: BM A rows then BN B rows, one 128-B line each
+  constexpr int SEGS = (BM + BN) / 8;           // 1-KiB DMA pieces per stage (8 rows x 128 B)
+  constexpr int SPW = SEGS / NW;                // pieces per wave
+  static_assert(SEGS % NW == 0, "pieces must divide evenly over the waves");
   extern __shared__ __attribute__((aligned(16))) char ring[];   // the ONLY shared object (see guide: a 2nd one forces vmcnt(0))
+  unsigned long long t_entry = 0;
+  if (DBG) {
+    t_entry = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
 
   // ---- blockIdx -> tile (same XCD-contiguous grouped raster as gemm.hip)
   const int nb = tiles_m * tiles_n;
@@ -59,51 +68,49 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
 
-  // ---- per-lane DMA sources: segment s of a stage = plane-major [A hi: BM/16][A lo: BM/16][B hi: BN/16][B lo: BN/16]
+  // ---- per-lane DMA sources.  Piece s of a stage = LDS rows 8s..8s+7; lane = (row r8, physical 16-B chunk pc).
+  // The XOR swizzle that keeps the ds_read_b128 fragment reads conflict-free (chunk ^= (row >> 1) & 7, rows are
+  // 128 B = 32 banks apart) is applied on the SOURCE side: the lane fetches logical chunk pc ^ swz of its line, so
+  // the 8 lanes of a row still cover one whole 128-B cache line.
   const char* Ab = reinterpret_cast<const char*>(p.A + (long long)z * p.sA);
   const char* Bb = reinterpret_cast<const char*>(p.B + (long long)z * p.sB);
-  const int r16 = lane >> 2;                                  // row within the 16-row segment
-  const int csrc = ((lane & 3) ^ ((r16 >> 2) & 3)) << 4;      // logical 16-B chunk this lane fetches (swizzle on the source)
+  const int r8 = lane >> 3;
   const char* src[SPW];
   int inc[SPW];                                               // bytes to advance per K-tile (0 for zero-page lanes)
+  int csrc[SPW];
   int a_y[SPW], a_x[SPW];
   long long a_img[SPW];
   bool a_row_ok[SPW], is_a[SPW];
-  int plane_off[SPW];
 #pragma unroll
   for (int i = 0; i < SPW; ++i) {
     const int s = wave + i * NW;
     const bool isA = s < BM / 8;
-    const int sp = isA ? s : s - BM / 8;
-    const int rows = isA ? BM : BN;
-    const int plane = sp >= rows / 16;
-    const int row_t = (sp - plane * (rows / 16)) * 16 + r16;  // row within the tile
+    const int row_l = s * 8 + r8;                             // LDS row within the stage
+    const int row_t = isA ? row_l : row_l - BM;               // row within the A / B tile
+    csrc[i] = ((lane & 7) ^ ((row_l >> 1) & 7)) << 4;
     is_a[i] = isA;
     if (isA) {
       const int row = m0 + row_t;
       a_row_ok[i] = row < p.M;
       if (ALOAD == 0) {
-        plane_off[i] = plane * p.K * 2;
-        src[i] = a_row_ok[i] ? Ab + (long long)row * p.lda * 4 + plane_off[i] + csrc : zero_page + csrc;
-        inc[i] = a_row_ok[i] ? 64 : 0;
+        src[i] = a_row_ok[i] ? Ab + (long long)row * p.lda * 4 + csrc[i] : zero_page + csrc[i];
+        inc[i] = a_row_ok[i] ? 128 : 0;
         a_y[i] = a_x[i] = 0;
         a_img[i] = 0;
-      } else {  // NHWC split activations: pixel row = Cin bf16 hi | Cin bf16 lo ; source recomputed per tap
-        plane_off[i] = plane * p.Cin * 2;
+      } else {  // NHWC split activations: a pixel = Cin/32 lines of [32 hi | 32 lo]; source recomputed per tap
         const int img = row >> (p.logH + p.logW);
         a_y[i] = (row >> p.logW) & (p.H - 1);
         a_x[i] = row & (p.W - 1);
         a_img[i] = (long long)img * (p.H >> p.ups) * (p.W >> p.ups) * p.Cin * 4;
-        src[i] = zero_page + csrc;
+        src[i] = zero_page + csrc[i];
         inc[i] = 0;
       }
     } else {
       const int row = n0 + row_t;
       const bool ok = row < p.N;
       a_row_ok[i] = ok;
-      plane_off[i] = plane * p.K * 2;
-      src[i] = ok ? Bb + (long long)row * p.ldb * 4 + plane_off[i] + csrc : zero_page + csrc;
-      inc[i] = ok ? 64 : 0;
+      src[i] = ok ? Bb + (long long)row * p.ldb * 4 + csrc[i] : zero_page + csrc[i];
+      inc[i] = ok ? 128 : 0;
       a_y[i] = a_x[i] = 0;
       a_img[i] = 0;
     }
@@ -121,9 +128,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
         if (!is_a[i]) continue;
         const int yy = a_y[i] + dy, xx = a_x[i] + dx;
         const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + plane_off[i] + csrc
-                    : zero_page + csrc;
-        inc[i] = ok ? 64 : 0;
+        src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
+                    : zero_page + csrc[i];
+        inc[i] = ok ? 128 : 0;
       }
     }
 #pragma unroll
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
 
   const int wr = wave / WN, wc = wave - wr * WN;
   const int arow0 = wr * TM * 32, bcol0 = wc * TN * 32;
-  const int rq = (l31 >> 2) & 3;
+  const int rq = (l31 >> 1) & 7;                 // read-side swizzle (tile row offsets are multiples of 16)
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -146,32 +153,163 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int KT = p.K >> 5;
+  // DBG: per-wave s_memtime deltas summed over the K loop (segments: DMA wait, barrier, DMA issue, read0, mfma0, read1, mfma1)
+  unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;
+  const bool rec = DBG && blockIdx.x == (gridDim.x >> 1);
+#define RGM_STAMP(i)                                               \
+  if (DBG) {                                                       \
+    __builtin_amdgcn_sched_barrier(0);                             \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             \
+    tacc[i] += now_ - tp;                                          \
+    tp = now_;                                                     \
+    __builtin_amdgcn_sched_barrier(0);                             \
+  }
+  if constexpr (PIPE) {
+    // Software-pipelined body (2-stage ring): per K-tile ONE exposed LDS round trip -- both k16 steps' fragments are
+    // requested up front into two register sets -- and the next tile's DMA pieces are issued one per two MFMAs
+    // (a burst of 8 pieces right after the barrier cost each wave ~800 cycles in the TA queue: tools/gemm_stamp.py).
+    static_assert(NSTAGE == 2, "PIPE: 2-stage ring only");
+    constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
+    auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
+      if (ALOAD == 1 && kt % cpt == 0) {
+        const int tap = kt / cpt;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int Win = p.W >> p.ups;
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+          if (!is_a[i]) continue;
+          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+          const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
+                      : zero_page + csrc[i];
+          inc[i] = ok ? 128 : 0;
+        }
+      }
+    };
+    retarget(0);
+    static_for<0, SPW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dma16(src[i], ring + (wave + i * NW) * 1024);
+      src[i] += inc[i];
+    });
+    int stage = 0;
+    if (DBG) {
+      tp = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tacc[2] = tp - t_entry;                       // prologue: entry -> K loop
+    }
+    for (int kt = 0; kt < KT; ++kt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      RGM_STAMP(0)
+      __builtin_amdgcn_s_barrier();   // tile kt is in LDS; everyone is done reading the other stage
+      RGM_STAMP(1)
+      const char* As = ring + stage * STAGE;
+      const char* Bs = As + BM * 128;
+      char* nxt = ring + (stage ^ 1) * STAGE;
+      const bool more = (kt + 1 < KT) && exp != 1;
+      bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+      static_for<0, 2>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        const int ch = ((2 * st + hh) ^ rq) << 4, cl = ((4 + 2 * st + hh) ^ rq) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ro = (arow0 + i * 32 + l31) * 128;
+          ah[st][i] = *reinterpret_cast<const bf16x8*>(As + ro + ch);
+          al[st][i] = *reinterpret_cast<const bf16x8*>(As + ro + cl);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int ro = (bcol0 + i * 32 + l31) * 128;
+          bh[st][i] = *reinterpret_cast<const bf16x8*>(Bs + ro + ch);
+          bl[st][i] = *reinterpret_cast<const bf16x8*>(Bs + ro + cl);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      if (more) retarget(kt + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (DBG) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RGM_STAMP(3)
+      }
+      static_for<0, 2 * NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int st = m / NM, t = (m % NM) / (TM * TN), im = ((m % NM) % (TM * TN)) / TN, in = (m % NM) % TN;
+        // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? al[st][im] : ah[st][im], t == 1 ? bl[st][in] : bh[st][in],
+                                                              acc[im][in], 0, 0, 0);
+        if constexpr ((m & 1) == 1 && (m >> 1) < SPW) {
+          constexpr int i = m >> 1;
+          if (more) {
+            dma16(src[i], nxt + (wave + i * NW) * 1024);
+            src[i] += inc[i];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DBG && m == NM - 1) { RGM_STAMP(4) }
+        if constexpr (DBG && m == 2 * NM - 1) { RGM_STAMP(6) }
+      });
+      stage ^= 1;
+    }
+  } else {
   issue(0, 0);
-  if (KT > 1) issue(1, 1);
+  if (NSTAGE == 3 && KT > 1) issue(1, 1);
   int stage = 0;
+  if (DBG) {
+    tp = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
   for (int kt = 0; kt < KT; ++kt) {
-    // tile kt has landed once at most the NEXT tile's SPW segments of this wave are still in flight
-    if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();   // every wave's part of tile kt is in LDS; everyone is done reading stage (kt-1)%3
-    if (kt + 2 < KT) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (kt+2)%3 == (stage+2)%3
-    const char* Ah = ring + stage * STAGE;
-    const char* Bh = Ah + BM * 128;
+    if (DBG) {   // same schedule as below, stamped
+      if (NSTAGE == 3) {
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      RGM_STAMP(0)
+      __builtin_amdgcn_s_barrier();
+      RGM_STAMP(1)
+      if (NSTAGE == 3) {
+        if (kt + 2 < KT && exp != 1) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+      } else {
+        if (kt + 1 < KT && exp != 1) issue(kt + 1, stage ^ 1);
+      }
+      RGM_STAMP(2)
+    } else if (NSTAGE == 3) {
+      // tile kt has landed once at most the NEXT tile's SPW segments of this wave are still in flight
+      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave's part of tile kt is in LDS; everyone is done reading stage (kt-1)%3
+      if (kt + 2 < KT && exp != 1) issue(kt + 2, stage == 0 ? 2 : stage - 1);   // (kt+2)%3 == (stage+2)%3
+    } else {
+      // 2-stage ring (half the LDS -> twice the co-resident workgroups): tile kt is the only DMA in flight here
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile kt is in LDS; everyone is done reading stage (kt-1)%2 = (kt+1)%2
+      if (kt + 1 < KT && exp != 1) issue(kt + 1, stage ^ 1);
+    }
+    const char* As = ring + stage * STAGE;
+    const char* Bs = As + BM * 128;
+    if (DBG || exp != 2)
 #pragma unroll
     for (int st = 0; st < 2; ++st) {
-      const int co = ((2 * st + hh) ^ rq) << 4;
+      const int ch = ((2 * st + hh) ^ rq) << 4, cl = ((4 + 2 * st + hh) ^ rq) << 4;   // hi / lo chunk of this k16 step
       bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int ro = (arow0 + i * 32 + l31) * 64 + co;
-        ah[i] = *reinterpret_cast<const bf16x8*>(Ah + ro);
-        al[i] = *reinterpret_cast<const bf16x8*>(Ah + BM * 64 + ro);
+        const int ro = (arow0 + i * 32 + l31) * 128;
+        ah[i] = *reinterpret_cast<const bf16x8*>(As + ro + ch);
+        al[i] = *reinterpret_cast<const bf16x8*>(As + ro + cl);
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i) {
-        const int ro = (bcol0 + i * 32 + l31) * 64 + co;
-        bh[i] = *reinterpret_cast<const bf16x8*>(Bh + ro);
-        bl[i] = *reinterpret_cast<const bf16x8*>(Bh + BN * 64 + ro);
+        const int ro = (bcol0 + i * 32 + l31) * 128;
+        bh[i] = *reinterpret_cast<const bf16x8*>(Bs + ro + ch);
+        bl[i] = *reinterpret_cast<const bf16x8*>(Bs + ro + cl);
+      }
+      if (DBG) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (st == 0) { RGM_STAMP(3) } else { RGM_STAMP(5) }
       }
 #pragma unroll
       for (int im = 0; im < TM; ++im)
@@ -181,44 +319,129 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bl[in], acc[im][in], 0, 0, 0);
           acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bh[in], acc[im][in], 0, 0, 0);
         }
+      if (DBG) {
+        if (st == 0) { RGM_STAMP(4) } else { RGM_STAMP(6) }
+      }
     }
-    stage = stage == 2 ? 0 : stage + 1;
+    stage = (NSTAGE == 3) ? (stage == 2 ? 0 : stage + 1) : (stage ^ 1);
   }
 
+  }   // !PIPE
+  const unsigned long long t_loop_end = tp;
   // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); optional split output
   float* __restrict__ Cb = p.C + (long long)z * p.sC;
   const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
   const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  // Vector path: the accumulators of one 32-row slab go through the (now idle) LDS ring so that every lane owns 4
+  // consecutive columns of a row -> bias / gate / residual are read and C is written 16 B per lane, a full 128-B line
+  // per 8 lanes, instead of 64 dword stores of two half-lines each (tools/gemm_stamp.py: the scalar epilogue cost
+  // 18-34k cycles per tile, a third of the tile's lifetime).
+  const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate) & 15) == 0 &&
+                   exp != 5;
+  if (vec) {
+    constexpr int WCOLS = TN * 32, LPR = WCOLS / 4, RPI = 64 / LPR;   // lanes per row, rows per wave-instruction
+    static_assert(NW * 32 * WCOLS * 4 <= NSTAGE * STAGE, "epilogue slab must fit in the ring");
+    __syncthreads();                                                  // every wave is done reading the last stage
+    float* stg = reinterpret_cast<float*>(ring) + wave * (32 * WCOLS);
+    const int lr = lane / LPR, lc = (lane % LPR) * 4;
+    const int col = n0 + bcol0 + lc;
+    const bool col_ok = col < p.N;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (biasb && col_ok) bv = *reinterpret_cast<const float4*>(biasb + col);
+    static_for<0, TM>([&](auto im_c) {
+      constexpr int im = decltype(im_c)::value;
+      static_for<0, TN>([&](auto in_c) {
+        constexpr int in = decltype(in_c)::value;
 #pragma unroll
-  for (int im = 0; im < TM; ++im) {
+        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
+      });
 #pragma unroll
-    for (int in = 0; in < TN; ++in) {
-      const int col = n0 + bcol0 + in * 32 + l31;
-      if (col >= p.N) continue;
-      const float bv = biasb ? biasb[col] : 0.f;
+      for (int j = 0; j < 32 / RPI; ++j) {
+        const int r = j * RPI + lr;
+        const int row = m0 + arow0 + im * 32 + r;
+        const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
+        if (row < p.M && col_ok) {
+          float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
+          if (p.act == 1) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m0 + arow0 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        if (row >= p.M) continue;
-        float v = acc[im][in][e] * p.alpha + bv;
-        if (p.act == 1) v = silu_f(v);
-        else if (p.act == 2) v = gelu_tanh_f(v);
-        if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
-        if (resb) v += resb[(long long)row * p.ldres + col];
-        if (p.out_split) {   // row = N bf16 hi | N bf16 lo in the same ldc*4 bytes
-          __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-          const __bf16 hi = (__bf16)v;
-          rowp[col] = hi;
-          rowp[p.N + col] = (__bf16)(v - (float)hi);
-        } else {
-          Cb[(long long)row * p.ldc + col] = v;
+            for (int q4 = 0; q4 < 4; ++q4) v[q4] = silu_f(v[q4]);
+          } else if (p.act == 2) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) v[q4] = gelu_tanh_f(v[q4]);
+          }
+          if (p.gate) {
+            const float4 g4 = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+            v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
+          }
+          if (resb) {
+            const float4 r4 = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          }
+          if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              hi[q4] = (__bf16)v[q4];
+              lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+            }
+            __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+            *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+            *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+          } else if (exp != 4) {
+            *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+          }
         }
       }
+    });
+  } else
+  static_for<0, TM>([&](auto im_c) {
+    static_for<0, TN>([&](auto in_c) {
+      constexpr int im = decltype(im_c)::value, in = decltype(in_c)::value;
+      const int col = n0 + bcol0 + in * 32 + l31;
+      if (col < p.N) {
+        const float bv = biasb ? biasb[col] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m0 + arow0 + im * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          if (row < p.M) {
+            float v = acc[im][in][e] * p.alpha + bv;
+            if (p.act == 1) v = silu_f(v);
+            else if (p.act == 2) v = gelu_tanh_f(v);
+            if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
+            if (resb) v += resb[(long long)row * p.ldres + col];
+            if (p.out_split) {   // split-row output (common.h split_idx)
+              __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+              const __bf16 hi = (__bf16)v;
+              rowp[split_idx(col)] = hi;
+              rowp[split_idx(col) + 32] = (__bf16)(v - (float)hi);
+            } else {
+              if (exp != 4) Cb[(long long)row * p.ldc + col] = v;
+              else if (v == 123.456f) Cb[0] = v;   // timing experiment: keep the math, drop the stores
+            }
+          }
+        }
+      }
+    });
+  });
+  if (DBG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (PIPE) tacc[5] = t_end - t_loop_end;       // epilogue: K loop end -> C stores retired
+    if (rec && lane == 0) {
+#pragma unroll
+      for (int i = 0; i < 7; ++i) dbg[wave * 8 + i] = (long long)tacc[i];
+      dbg[wave * 8 + 7] = KT;
     }
   }
+#undef RGM_STAMP
 }
 
 static char* g_zero_page = nullptr;
+static long long* g_dbg = nullptr;   // set by rgm_gemm2_dbg: stamped kernel variant (tools/gemm_stamp.py)
+// timing experiments only (wrong results): RGM_GEMM2_EXP=1 no DMA after the prologue, =2 DMA + barriers only
+static int g_exp = getenv("RGM_GEMM2_EXP") ? atoi(getenv("RGM_GEMM2_EXP")) : 0;
 
 struct Prof2 {
   hipEvent_t a, b;
@@ -228,17 +451,17 @@ struct Prof2 {
 static bool g2_prof_on = false;
 static std::vector<Prof2> g2_prof;
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NSTAGE = 3, int PIPE = 0>
 static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   if (!g_zero_page) {
     RGM_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
     RGM_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
   }
   const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
-  const size_t lds = (size_t)3 * (BM + BN) * 128;
+  const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
   static bool attr0 = false, attr1 = false;
-  auto k0 = gemm2_kernel<BM, BN, WM, WN, 0>;
-  auto k1 = gemm2_kernel<BM, BN, WM, WN, 1>;
+  auto k0 = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 0, PIPE>;
+  auto k1 = gemm2_kernel<BM, BN, WM, WN, 1, NSTAGE, 0, PIPE>;
   if (lds > 65536) {
     if (p.aload == 0 && !attr0) {
       RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -258,10 +481,18 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     rec.flops = 2.0 * p.M * (double)p.N * p.K * p.batch;
     RGM_CHECK_HIP(hipEventRecord(rec.a, s));
   }
-  if (p.aload == 0)
-    hipLaunchKernelGGL(k0, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn);
+  if (p.aload == 0 && g_dbg) {
+    auto kd = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 1, PIPE>;
+    static bool attrd = false;
+    if (lds > 65536 && !attrd) {
+      RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attrd = true;
+    }
+    hipLaunchKernelGGL(kd, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
+  } else if (p.aload == 0)
+    hipLaunchKernelGGL(k0, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   else
-    hipLaunchKernelGGL(k1, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn);
+    hipLaunchKernelGGL(k1, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   RGM_LAUNCH_CHECK();
   if (g2_prof_on) {
     RGM_CHECK_HIP(hipEventRecord(rec.b, s));
@@ -276,16 +507,32 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(p.aload == 0 || (p.Cin % 32 == 0 && p.K == 9 * p.Cin), "gemm2: implicit conv needs Cin%%32==0, K=9*Cin");
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm2: operands must be 16-byte aligned with ld%%4==0");
+  RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
   int tile = p.tile;
   if (tile == 0) {
+    // tools/gemm_sweep.py on MI355X: the software-pipelined 128x64 tile (3 workgroups per CU) is the best or within
+    // a few % of the best from M ~ 1k rows up to the SCG batches; small grids keep the 64x64 tile
     const long long work = (long long)p.M * p.N * p.batch;
-    tile = work >= (long long)8192 * 2048 ? 1 : (work >= (long long)1024 * 1152 ? 2 : 3);
+    tile = work >= (long long)1024 * 1152 ? 22 : 3;
   }
   switch (tile) {
     case 1: return launch2<128, 128, 2, 2>(p, s, 1);
     case 2: return launch2<128, 64, 2, 2>(p, s, 2);
     case 3: return launch2<64, 64, 2, 2>(p, s, 3);
     case 5: return launch2<256, 128, 4, 2>(p, s, 5);
+    // experimental shapes (tools/gemm_sweep.py 100+t): wave tiling / ring depth variants
+    case 6: return launch2<256, 128, 2, 2>(p, s, 6);        // 4 waves of 128x64, 3 stages (144 KB)
+    case 7: return launch2<256, 256, 2, 4, 2>(p, s, 7);     // 8 waves of 128x64, 2 stages (128 KB)
+    case 8: return launch2<256, 256, 2, 2, 2>(p, s, 8);     // 4 waves of 128x128, 2 stages (128 KB)
+    case 11: return launch2<128, 128, 2, 2, 2>(p, s, 11);   // 2 stages (64 KB): 2 workgroups per CU
+    case 12: return launch2<128, 64, 2, 2, 2>(p, s, 12);    // 2 stages (48 KB): 3 workgroups per CU
+    case 15: return launch2<256, 128, 4, 2, 2>(p, s, 15);   // 8 waves of 64x64, 2 stages (96 KB)
+    case 16: return launch2<256, 128, 2, 2, 2>(p, s, 16);   // 4 waves of 128x64, 2 stages (96 KB)
+    // software-pipelined bodies (PIPE): fragments double-buffered in registers, DMA pieces spread between the MFMAs
+    case 21: return launch2<128, 128, 2, 2, 2, 1>(p, s, 21);
+    case 22: return launch2<128, 64, 2, 2, 2, 1>(p, s, 22);
+    case 25: return launch2<256, 128, 4, 2, 2, 1>(p, s, 25);
+    case 27: return launch2<256, 256, 2, 4, 2, 1>(p, s, 27);
     default: break;
   }
   set_error("gemm2: unknown tile %d", tile);
@@ -306,8 +553,8 @@ __global__ void split_rows_kernel(const float* __restrict__ x, float* __restrict
   lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
   lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
   __bf16* rowp = reinterpret_cast<__bf16*>(out + row * ld_out);
-  *reinterpret_cast<bf16x4*>(rowp + c) = hi;
-  *reinterpret_cast<bf16x4*>(rowp + K + c) = lo;
+  *reinterpret_cast<bf16x4*>(rowp + split_idx(c)) = hi;
+  *reinterpret_cast<bf16x4*>(rowp + split_idx(c) + 32) = lo;
 }
 
 int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_in, int ld_out, hipStream_t s) {
@@ -359,4 +606,22 @@ extern "C" int rgm_gemm_split(const float* A_split, const float* B_split, float*
   g.A = A_split; g.lda = K; g.B = B_split; g.ldb = K; g.C = C; g.ldc = N;
   g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.tile = tile; g.out_split = out_split;
   return rgm::gemm2_launch(g, (hipStream_t)stream);
+}
+
+// Timing instrumentation (tools only): mode 1 = use the s_memtime-stamped kernels from now on, mode 2 = copy the
+// 8 waves x 8 counters (cycles summed over the K loop of the middle workgroup) to out64 (64 entries), mode 0 = off.
+extern "C" int rgm_gemm2_dbg(int mode, long long* out64) {
+  using namespace rgm;
+  if (mode == 1) {
+    if (!g_dbg) RGM_CHECK_HIP(hipMalloc(&g_dbg, 64 * sizeof(long long)));
+    RGM_CHECK_HIP(hipMemset(g_dbg, 0, 64 * sizeof(long long)));
+  } else if (mode == 2) {
+    RGM_REQUIRE(g_dbg && out64, "gemm2_dbg: not enabled");
+    RGM_CHECK_HIP(hipDeviceSynchronize());
+    RGM_CHECK_HIP(hipMemcpy(out64, g_dbg, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  } else {
+    if (g_dbg) (void)hipFree(g_dbg);
+    g_dbg = nullptr;
+  }
+  return RGM_OK;
 }

@@ -83,7 +83,16 @@ class PhiloxNoise:
     """Counter-based N(0,1) source: draw k covers counters [offset, offset+numel)."""
 
     def __init__(self, seed=None):
-        self.seed = int(th.initial_seed() if seed is None else seed) & 0xFFFFFFFFFFFFFFFF
+        if seed is None:
+            seed = int(th.initial_seed())
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+                # sharded SCG: every rank must draw the SAME stream (rank r scores candidates [r*n/R, (r+1)*n/R) of it
+                # and any rank may have to rebuild another rank's winner), so rank 0's seed is used everywhere
+                box = [seed]
+                dist.broadcast_object_list(box, src=0)
+                seed = int(box[0])
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.offset = 0
 
     def reserve(self, numel):

@@ -129,10 +129,10 @@ def _split(x):
 
 
 def _unsplit(t):
-    """split-row device tensor (R,K) -> numpy float64 hi+lo"""
+    """split-row device tensor (R,K) -> numpy float64 hi+lo; a row is K/32 lines of [32 bf16 hi | 32 bf16 lo] (common.h)"""
     R_, K = t.shape
-    raw = t.contiguous().view(torch.bfloat16).view(R_, 2 * K).float().cpu().numpy().astype(np.float64)
-    return raw[:, :K] + raw[:, K:]
+    raw = t.contiguous().view(torch.bfloat16).view(R_, K // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+    return (raw[:, :, 0, :] + raw[:, :, 1, :]).reshape(R_, K)
 
 
 def test_split_rows_format():
@@ -143,7 +143,7 @@ def test_split_rows_format():
     assert (np.abs(back - x) <= np.abs(x) * 2.0 ** -15.5 + 1e-38).all()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 21, 22, 25])
 @pytest.mark.parametrize("M,N,K", [(200, 96, 64), (513, 1152, 1152), (4096, 36, 1152), (777, 3456, 384), (256, 128, 32)])
 def test_gemm_split_dma_kernel(tile, M, N, K):
     """Pre-split operands + LDS-DMA staging (gemm2): same contraction, bf16x3 accuracy, every tile shape, ragged edges."""
@@ -159,7 +159,7 @@ def test_gemm_split_dma_kernel(tile, M, N, K):
     R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(c), M, N, K, R.ptr(bd), 0, tile, 0, R.current_stream()))
     torch.cuda.synchronize()
     assert rel(c.cpu().numpy(), ref) < 3e-5
-    if N % 4 == 0:                                                   # split output feeds the next GEMM directly
+    if N % 32 == 0:                                                  # split output feeds the next GEMM directly
         cs = torch.zeros((M, N), device="cuda")
         R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(cs), M, N, K, R.ptr(bd), 2, tile, 1, R.current_stream()))
         torch.cuda.synchronize()

@@ -176,3 +176,30 @@ def test_product_modules_keep_the_reference_state_dict_keys():
     from taming.models.klvae_pedal import AutoencoderKL
     v = AutoencoderKL()
     assert "decoder.up.3.upsample.conv.weight" in v.state_dict() and "post_quant_conv.bias" in v.state_dict()
+
+
+def _seed_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)                 # ranks start from DIFFERENT torch seeds, as separate processes do
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    q.put((rank, PhiloxNoise().seed))
+    dist.destroy_process_group()
+
+
+def test_noise_seed_is_shared_across_ranks_gloo():
+    """Sharded SCG needs one noise stream: PhiloxNoise adopts rank 0's seed when a process group exists."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_seed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == 1000

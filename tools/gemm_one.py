@@ -14,6 +14,14 @@ a = torch.randn(M, K, device="cuda")
 b = torch.randn(N, K, device="cuda") * 0.03
 c = torch.empty(M, N, device="cuda")
 bias = torch.randn(N, device="cuda")
+st = R.current_stream()
+if tile >= 100:                                       # pre-split operands, LDS-DMA kernel (gemm2), tile - 100
+    a2, b2 = torch.empty_like(a), torch.empty_like(b)
+    R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st))
+    R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), N, K, st))
 for _ in range(iters):
-    R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, R.current_stream()))
+    if tile >= 100:
+        R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), 0, tile - 100, 0, st))
+    else:
+        R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
 torch.cuda.synchronize()

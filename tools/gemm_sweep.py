@@ -11,13 +11,20 @@ sys.path.insert(0, os.path.join(ROOT, "rule-guided-music_amd"))
 import torch  # noqa: E402
 from rgm import native as R  # noqa: E402
 
+if os.environ.get("SWEEP_SHAPES") == "big":
+    SHAPES_OVERRIDE = [("fc1", 4096, 4608, 1152), ("fc1_scg", 16384, 4608, 1152), ("fc2_scg", 16384, 1152, 4608)]
+else:
+    SHAPES_OVERRIDE = None
 SHAPES = [("qkv", 4096, 3456, 1152), ("proj", 4096, 1152, 1152), ("fc1", 4096, 4608, 1152), ("fc2", 4096, 1152, 4608),
           ("qkv_b2", 512, 3456, 1152), ("fc2_b2", 512, 1152, 4608), ("fc1_scg", 16384, 4608, 1152), ("fc2_scg", 16384, 1152, 4608)]
 
 
-def bench(M, N, K, tile, iters=20):
+def bench(M, N, K, tile, iters=20, check=True):
     a = torch.randn(M, K, device="cuda")
     b = torch.randn(N, K, device="cuda") * 0.03
+    # SWEEP_COLD=1: cycle through enough copies of the weight matrix that every launch reads it from HBM, as a model
+    # with 28 different layers does (the default re-uses one B, which then sits in L2 / the 256 MB MALL)
+    ncopy = max(2, int(600e6 // (N * K * 4))) if os.environ.get("SWEEP_COLD") else 1
     c = torch.empty(M, N, device="cuda")
     bias = torch.randn(N, device="cuda")
     st = R.current_stream()
@@ -25,14 +32,25 @@ def bench(M, N, K, tile, iters=20):
         a2, b2 = torch.empty_like(a), torch.empty_like(b)
         R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st))
         R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), N, K, st))
+        bs = [b2] + [b2.clone() for _ in range(ncopy - 1)]
+        cnt = [0]
 
         def run():
-            R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), 0, tile - 100, 0, st))
+            cnt[0] += 1
+            R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(bs[cnt[0] % ncopy]), R.ptr(c), M, N, K, R.ptr(bias), 0, tile - 100, 0, st))
     else:
+        bs = [b] + [b.clone() for _ in range(ncopy - 1)]
+        cnt = [0]
+
         def run():
-            R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(b), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
+            cnt[0] += 1
+            R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(bs[cnt[0] % ncopy]), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
     for _ in range(3):
         run()
+    if check and not os.environ.get('RGM_GEMM2_EXP'):                                         # max |c - (a b^T + bias)| relative to the output scale
+        ref = torch.addmm(bias, a, b.t())
+        err = ((c - ref).abs().max() / ref.abs().max()).item()
+        assert err < 2e-4, f"tile {tile} wrong on {M}x{N}x{K}: rel err {err:.3e}"
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
@@ -46,8 +64,8 @@ def bench(M, N, K, tile, iters=20):
 if __name__ == "__main__":
     # arguments: tile codes; add 32 for bf16x3 (e.g. 34 = 128x64 tile in bf16x3), 16 for explicit fp32
     tiles = [int(x) for x in sys.argv[1:]] or [2, 3, 33, 34, 35]
-    bench(4096, 4608, 1152, 2, iters=50)      # warm the clocks before the first measured cell
+    bench(4096, 4608, 1152, 2, iters=50, check=False)      # warm the clocks before the first measured cell
     print(f"{'shape':10s} {'M':>6s} {'N':>5s} {'K':>5s} " + " ".join(f"tile{t}:TF/us".rjust(16) for t in tiles))
-    for name, M, N, K in SHAPES:
+    for name, M, N, K in (SHAPES_OVERRIDE or SHAPES):
         row = [bench(M, N, K, t) for t in tiles]
         print(f"{name:10s} {M:6d} {N:5d} {K:5d} " + " ".join(f"{tf:7.1f}/{us:8.1f}" for tf, us in row), flush=True)

@@ -17,6 +17,19 @@ def main(db, out):
         for name, calls, tot, avg, pct in rows:
             w.writerow([name if len(name) < 160 else name[:157] + "...", calls, f"{tot:.3f}", f"{avg:.3f}", f"{pct:.3f}"])
     print(f"{len(rows)} kernels -> {out}")
+    # per (kernel, grid) averages for the rgm GEMMs: one kernel template serves several layer shapes
+    try:
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        gx = "grid_x" if "grid_x" in cols else ("grid_size_x" if "grid_size_x" in cols else None)
+        dur = "duration" if "duration" in cols else "(end - start)"
+        if gx:
+            q = f"select name, {gx}, count(*), avg({dur}) from kernels where name like '%gemm%' group by name, {gx} order by 3 desc"
+            for name, g, n, avg in cur.execute(q):
+                print(f"  {name[:60]:60s} grid_x={g:<8} calls={n:<6} avg={avg / 1e3:9.2f} us")
+        else:
+            print("  (kernels view columns:", cols, ")")
+    except sqlite3.Error as e:
+        print("  per-grid breakdown unavailable:", e)
 
 
 if __name__ == "__main__":
