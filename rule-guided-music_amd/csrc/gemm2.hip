@@ -74,6 +74,14 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
   // the 8 lanes of a row still cover one whole 128-B cache line.
   const char* Ab = reinterpret_cast<const char*>(p.A + (long long)z * p.sA);
   const char* Bb = reinterpret_cast<const char*>(p.B + (long long)z * p.sB);
+  float* __restrict__ Cb = p.C + (long long)z * p.sC;
+  const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
+  const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  // vector epilogue (below) needs 16-B aligned rows; uniform over the workgroup
+  const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate) & 15) == 0 &&
+                   exp != 5;
+  const int KT = p.K >> 5;
+
   const int r8 = lane >> 3;
   const char* src[SPW];
   int inc[SPW];                                               // bytes to advance per K-tile (0 for zero-page lanes)
@@ -152,7 +160,6 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  const int KT = p.K >> 5;
   // DBG: per-wave s_memtime deltas summed over the K loop (segments: DMA wait, barrier, DMA issue, read0, mfma0, read1, mfma1)
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;
   const bool rec = DBG && blockIdx.x == (gridDim.x >> 1);
@@ -165,11 +172,133 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
     tp = now_;                                                     \
     __builtin_amdgcn_sched_barrier(0);                             \
   }
+  if constexpr (PIPE == 3) {
+    // Cross-iteration register pipeline: the fragments of K-tile kt+1 are requested (behind the barrier that says the
+    // tile has landed) BEFORE the second k16 step of tile kt is multiplied, into a second register set, so neither the
+    // LDS round trip nor the barrier skew is exposed -- a wave's stream is MFMA, MFMA, ... with the DMA pieces of tile
+    // kt+2 dropped in between.  3-stage ring: kt+2 is issued at the top of iteration kt (1.5-2 K-tiles of latency
+    // cover); 2-stage ring: kt+2 reuses tile kt's stage, so it is issued after the mid-iteration barrier.
+    constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
+    constexpr int P0 = (NSTAGE == 3) ? (SPW < NM / 2 ? SPW : NM / 2) : 0;   // pieces issued during step 0
+    constexpr int P1 = SPW - P0;                                             // ... during step 1
+    static_assert(P1 <= NM, "not enough MFMA slots to spread the DMA pieces");
+    struct Frags {
+      bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
+    };
+    auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
+      if (ALOAD == 1 && kt % cpt == 0) {
+        const int tap = kt / cpt;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int Win = p.W >> p.ups;
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+          if (!is_a[i]) continue;
+          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+          const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
+                      : zero_page + csrc[i];
+          inc[i] = ok ? 128 : 0;
+        }
+      }
+    };
+    auto load_frags = [&](Frags& f, const char* As) {
+      const char* Bs = As + BM * 128;
+      static_for<0, 2>([&](auto sc) {
+        constexpr int st = decltype(sc)::value;
+        const int ch = ((2 * st + hh) ^ rq) << 4, cl = ((4 + 2 * st + hh) ^ rq) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int ro = (arow0 + i * 32 + l31) * 128;
+          f.ah[st][i] = *reinterpret_cast<const bf16x8*>(As + ro + ch);
+          f.al[st][i] = *reinterpret_cast<const bf16x8*>(As + ro + cl);
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+          const int ro = (bcol0 + i * 32 + l31) * 128;
+          f.bh[st][i] = *reinterpret_cast<const bf16x8*>(Bs + ro + ch);
+          f.bl[st][i] = *reinterpret_cast<const bf16x8*>(Bs + ro + cl);
+        }
+      });
+    };
+    // one k16 step of MFMAs from registers; DMA pieces [PB, PB + PN) of the next-but-one tile dropped in between
+    auto mfma_step = [&](const Frags& f, auto stc, auto pbc, auto pnc, bool issue, char* dst) {
+      constexpr int st = decltype(stc)::value, PB = decltype(pbc)::value, PN = decltype(pnc)::value;
+      constexpr int EVERY = (PN <= NM / 2) ? 2 : 1;
+      static_for<0, NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
+        // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? f.al[st][im] : f.ah[st][im], t == 1 ? f.bl[st][in] : f.bh[st][in],
+                                                              acc[im][in], 0, 0, 0);
+        if constexpr ((m % EVERY) == EVERY - 1 && (m / EVERY) < PN) {
+          constexpr int i = PB + m / EVERY;
+          if (issue) {
+            dma16(src[i], dst + (wave + i * NW) * 1024);
+            src[i] += inc[i];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    Frags f0, f1;
+    retarget(0);
+    static_for<0, SPW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dma16(src[i], ring + (wave + i * NW) * 1024);
+      src[i] += inc[i];
+    });
+    if (KT > 1) {
+      retarget(1);
+      static_for<0, SPW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        dma16(src[i], ring + STAGE + (wave + i * NW) * 1024);
+        src[i] += inc[i];
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    load_frags(f0, ring);
+    int s1 = 1 % NSTAGE, s2 = 2 % NSTAGE;                  // ring stages of tiles kt+1, kt+2
+    if (DBG) {
+      tp = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tacc[2] = tp - t_entry;                       // prologue: entry -> K loop
+    }
+    auto iter = [&](Frags& cur, Frags& nxt, int kt) {
+      const bool more1 = kt + 1 < KT, more2 = kt + 2 < KT && exp != 1;
+      char* dst2 = ring + s2 * STAGE;
+      if (more2) retarget(kt + 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(cur, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, P0>{}, more2, dst2);
+      RGM_STAMP(4)
+      if (more1) {
+        // own pieces of tile kt+1 have landed once only the P0 just-issued pieces of tile kt+2 are outstanding
+        if (more2 && P0 > 0) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(P0) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        RGM_STAMP(0)
+        __builtin_amdgcn_s_barrier();   // tile kt+1 complete in LDS; nobody still reads tile kt's stage
+        RGM_STAMP(1)
+        load_frags(nxt, ring + s1 * STAGE);
+        if (DBG) { RGM_STAMP(3) }      // (stamping waits for the fragments: the un-stamped kernel does not)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(cur, std::integral_constant<int, 1>{}, std::integral_constant<int, P0>{}, std::integral_constant<int, P1>{}, more2, dst2);
+      RGM_STAMP(6)
+      s1 = s1 + 1 == NSTAGE ? 0 : s1 + 1;
+      s2 = s2 + 1 == NSTAGE ? 0 : s2 + 1;
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+      iter(f0, f1, kt);
+      if (kt + 1 < KT) iter(f1, f0, kt + 1);
+    }
+  } else
   if constexpr (PIPE) {
     // Software-pipelined body (2-stage ring): per K-tile ONE exposed LDS round trip -- both k16 steps' fragments are
     // requested up front into two register sets -- and the next tile's DMA pieces are issued one per two MFMAs
     // (a burst of 8 pieces right after the barrier cost each wave ~800 cycles in the TA queue: tools/gemm_stamp.py).
-    static_assert(NSTAGE == 2, "PIPE: 2-stage ring only");
+    static_assert(NSTAGE == 2, "PIPE 1: 2-stage ring only");
     constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
     auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
       if (ALOAD == 1 && kt % cpt == 0) {
@@ -329,15 +458,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
   }   // !PIPE
   const unsigned long long t_loop_end = tp;
   // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); optional split output
-  float* __restrict__ Cb = p.C + (long long)z * p.sC;
-  const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
-  const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
   // Vector path: the accumulators of one 32-row slab go through the (now idle) LDS ring so that every lane owns 4
   // consecutive columns of a row -> bias / gate / residual are read and C is written 16 B per lane, a full 128-B line
   // per 8 lanes, instead of 64 dword stores of two half-lines each (tools/gemm_stamp.py: the scalar epilogue cost
   // 18-34k cycles per tile, a third of the tile's lifetime).
-  const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate) & 15) == 0 &&
-                   exp != 5;
   if (vec) {
     constexpr int WCOLS = TN * 32, LPR = WCOLS / 4, RPI = 64 / LPR;   // lanes per row, rows per wave-instruction
     static_assert(NW * 32 * WCOLS * 4 <= NSTAGE * STAGE, "epilogue slab must fit in the ring");
@@ -481,6 +605,7 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     rec.flops = 2.0 * p.M * (double)p.N * p.K * p.batch;
     RGM_CHECK_HIP(hipEventRecord(rec.a, s));
   }
+#ifdef RGM_GEMM2_STAMPS   // make CXXFLAGS+=-DRGM_GEMM2_STAMPS: also build the s_memtime-stamped kernels (tools/gemm_stamp.py)
   if (p.aload == 0 && g_dbg) {
     auto kd = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 1, PIPE>;
     static bool attrd = false;
@@ -489,7 +614,9 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
       attrd = true;
     }
     hipLaunchKernelGGL(kd, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
-  } else if (p.aload == 0)
+  } else
+#endif
+  if (p.aload == 0)
     hipLaunchKernelGGL(k0, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   else
     hipLaunchKernelGGL(k1, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
@@ -510,29 +637,25 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
   int tile = p.tile;
   if (tile == 0) {
-    // tools/gemm_sweep.py on MI355X: the software-pipelined 128x64 tile (3 workgroups per CU) is the best or within
-    // a few % of the best from M ~ 1k rows up to the SCG batches; small grids keep the 64x64 tile
+    // tools/gemm_sweep.py on MI355X (cross-iteration pipeline, PIPE 3): 128x128 (2 workgroups per CU) once it fills
+    // at least one round of the chip, 128x64 (3 per CU) below that, 64x64 on small grids
+    const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long long work = (long long)p.M * p.N * p.batch;
-    tile = work >= (long long)1024 * 1152 ? 22 : 3;
+    tile = t128 >= 512 ? 43 : (work >= (long long)1024 * 1152 ? 44 : 46);
   }
   switch (tile) {
     case 1: return launch2<128, 128, 2, 2>(p, s, 1);
     case 2: return launch2<128, 64, 2, 2>(p, s, 2);
     case 3: return launch2<64, 64, 2, 2>(p, s, 3);
     case 5: return launch2<256, 128, 4, 2>(p, s, 5);
-    // experimental shapes (tools/gemm_sweep.py 100+t): wave tiling / ring depth variants
-    case 6: return launch2<256, 128, 2, 2>(p, s, 6);        // 4 waves of 128x64, 3 stages (144 KB)
-    case 7: return launch2<256, 256, 2, 4, 2>(p, s, 7);     // 8 waves of 128x64, 2 stages (128 KB)
-    case 8: return launch2<256, 256, 2, 2, 2>(p, s, 8);     // 4 waves of 128x128, 2 stages (128 KB)
-    case 11: return launch2<128, 128, 2, 2, 2>(p, s, 11);   // 2 stages (64 KB): 2 workgroups per CU
-    case 12: return launch2<128, 64, 2, 2, 2>(p, s, 12);    // 2 stages (48 KB): 3 workgroups per CU
-    case 15: return launch2<256, 128, 4, 2, 2>(p, s, 15);   // 8 waves of 64x64, 2 stages (96 KB)
-    case 16: return launch2<256, 128, 2, 2, 2>(p, s, 16);   // 4 waves of 128x64, 2 stages (96 KB)
     // software-pipelined bodies (PIPE): fragments double-buffered in registers, DMA pieces spread between the MFMAs
     case 21: return launch2<128, 128, 2, 2, 2, 1>(p, s, 21);
     case 22: return launch2<128, 64, 2, 2, 2, 1>(p, s, 22);
-    case 25: return launch2<256, 128, 4, 2, 2, 1>(p, s, 25);
-    case 27: return launch2<256, 256, 2, 4, 2, 1>(p, s, 27);
+    // cross-iteration register pipeline (PIPE == 3), 3- and 2-stage rings
+    case 43: return launch2<128, 128, 2, 2, 2, 3>(p, s, 43);   // 64 KB: 2 per CU
+    case 44: return launch2<128, 64, 2, 2, 2, 3>(p, s, 44);    // 48 KB: 3 per CU
+    case 45: return launch2<256, 128, 4, 2, 2, 3>(p, s, 45);   // 96 KB, 8 waves
+    case 46: return launch2<64, 64, 2, 2, 3, 3>(p, s, 46);     // 48 KB: 3 per CU
     default: break;
   }
   set_error("gemm2: unknown tile %d", tile);
@@ -613,6 +736,9 @@ extern "C" int rgm_gemm_split(const float* A_split, const float* B_split, float*
 extern "C" int rgm_gemm2_dbg(int mode, long long* out64) {
   using namespace rgm;
   if (mode == 1) {
+#ifndef RGM_GEMM2_STAMPS
+    RGM_REQUIRE(false, "gemm2_dbg: library built without -DRGM_GEMM2_STAMPS (make EXTRA=-DRGM_GEMM2_STAMPS)");
+#endif
     if (!g_dbg) RGM_CHECK_HIP(hipMalloc(&g_dbg, 64 * sizeof(long long)));
     RGM_CHECK_HIP(hipMemset(g_dbg, 0, 64 * sizeof(long long)));
   } else if (mode == 2) {

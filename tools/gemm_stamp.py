@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """s_memtime profile of the gemm2 K loop (middle workgroup): tools/gemm_stamp.py M N K tile [tile ...]
 
+Needs the stamped kernels: (cd rule-guided-music_amd/csrc && touch gemm2.hip && make EXTRA=-DRGM_GEMM2_STAMPS)
+
 Prints, per wave, the average cycles per K-tile spent in each segment of the loop body:
   dma_wait | barrier | dma_issue | read0 (8 ds_read + wait) | mfma0 (issue) | read1 | mfma1
 """
