@@ -177,15 +177,28 @@ def roofline_pass(work, steps=2):
     torch.cuda.synchronize()
     R.check(R.lib.rgm_prof_enable(0))
     rows = {}
-    for kid in (1, 2, 3, 4, 5, 11, 12, 13, 14, 15, 21, 22, 23, 24, 25, 31, 32, 33, 34, 35, 41, 42, 43, 45, 51, 52, 53, 55):
+    for kid in range(1, 140):
         n, ms, fl = C.c_int(), C.c_double(), C.c_double()
         R.check(R.lib.rgm_prof_report(kid, C.byref(n), C.byref(ms), C.byref(fl)))
         if n.value:
             rows[kid] = dict(launches=n.value, ms=ms.value, flops=fl.value)
     R.check(R.lib.rgm_prof_reset())
+    # kernel ids (csrc/gemm.hip, gemm2.hip): < 40 gemm_kernel<BM,BN,WM,WN,ALOAD,PREC> = tile + 10*ALOAD + 20*PREC;
+    # >= 40 gemm2_kernel<BM,BN,WM,WN,ALOAD,NSTAGE,0,PIPE> = 40 + tile + 10*ALOAD (tiles: gemm2_launch)
     tiles = {1: "128,128,2,2", 2: "128,64,2,2", 3: "64,64,2,2", 4: "32,128,1,4", 5: "256,128,4,2"}
-    names = {k: (f"gemm_kernel<{tiles[k % 10]},{(k // 10) % 2},{k // 20}>" if k < 40              # <BM,BN,WM,WN,ALOAD,PREC>
-                 else f"gemm2_kernel<{tiles[k % 10]},{(k // 10) % 2}>") for k in rows}             # pre-split + LDS-DMA
+    g2 = {1: (1, 3, 0), 2: (2, 3, 0), 3: (3, 3, 0), 5: (5, 3, 0), 21: (1, 2, 1), 22: (2, 2, 1),
+          43: (1, 2, 3), 44: (2, 2, 3), 45: (5, 2, 3), 46: (3, 3, 3)}
+
+    def kname(k):
+        if k < 40:
+            return f"gemm_kernel<{tiles[k % 10]},{(k // 10) % 2},{k // 20}>"
+        t = k - 40
+        aload = 0
+        if t not in g2 and (t - 10) in g2:
+            t, aload = t - 10, 1
+        shape, nstage, pipe = g2[t]
+        return f"gemm2_kernel<{tiles[shape]},{aload},{nstage},0,{pipe}>"
+    names = {k: kname(k) for k in rows}
     kid = max(rows, key=lambda k: rows[k]["ms"])
     r = rows[kid]
     bf16x3 = kid >= 20
@@ -247,7 +260,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default=os.environ.get("RGM_BENCH_PRECISION", "bf16x3"), choices=["fp32", "bf16x3", "bf16x3_presplit"],
+    ap.add_argument("--precision", default=os.environ.get("RGM_BENCH_PRECISION", "bf16x3_presplit"), choices=["fp32", "bf16x3", "bf16x3_presplit"],
                     help="GEMM arithmetic: bf16x3 split (default; fp32-grade: 2.5e-6 latent error on the 50-step golden, "
                          "parity suite runs in both modes) or exact fp32 MFMA")
     args = ap.parse_args()

@@ -70,7 +70,7 @@ def main(argv=None):
     args = create_argparser().parse_args(argv)
     args.dir = output_dir_for(args.config_path, args.class_label)
     from rgm import native as _native
-    _native.set_gemm_precision(args.gemm_precision)      # "bf16x3" (fast, fp32-grade) or "fp32" (exact fp32 MFMA)
+    _native.set_gemm_precision(args.gemm_precision)      # "bf16x3_presplit" / "bf16x3" (fast, fp32-grade) or "fp32" (exact fp32 MFMA)
     comm = dist_util.setup_dist(port=args.port)
     logger.configure(args=args, comm=comm)
     config = midi_util.load_config(args.config_path)
@@ -208,7 +208,7 @@ def create_argparser():
         cfg=False, w=4., classifier_scale=1.0, record=False, save_files=True, training=False, deterministic=False,
         port=None,
         # additions of this implementation
-        synthetic_weights=False, progress=True, gemm_precision="bf16x3",
+        synthetic_weights=False, progress=True, gemm_precision="bf16x3_presplit",
     )
     defaults.update(model_and_diffusion_defaults())
     parser = argparse.ArgumentParser()

@@ -19,6 +19,10 @@ SHAPES = [("qkv", 4096, 3456, 1152), ("proj", 4096, 1152, 1152), ("fc1", 4096, 4
           ("qkv_b2", 512, 3456, 1152), ("fc2_b2", 512, 1152, 4608), ("fc1_scg", 16384, 4608, 1152), ("fc2_scg", 16384, 1152, 4608)]
 
 
+ACT = int(os.environ.get('SWEEP_ACT', '0'))      # epilogue variants (gemm2 tiles only): 2 = GELU
+SPLIT = int(os.environ.get('SWEEP_SPLIT', '0'))  # 1 = split-row output
+
+
 def bench(M, N, K, tile, iters=20, check=True):
     a = torch.randn(M, K, device="cuda")
     b = torch.randn(N, K, device="cuda") * 0.03
@@ -37,7 +41,7 @@ def bench(M, N, K, tile, iters=20, check=True):
 
         def run():
             cnt[0] += 1
-            R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(bs[cnt[0] % ncopy]), R.ptr(c), M, N, K, R.ptr(bias), 0, tile - 100, 0, st))
+            R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(bs[cnt[0] % ncopy]), R.ptr(c), M, N, K, R.ptr(bias), ACT, tile - 100, SPLIT, st))
     else:
         bs = [b] + [b.clone() for _ in range(ncopy - 1)]
         cnt = [0]
@@ -47,7 +51,7 @@ def bench(M, N, K, tile, iters=20, check=True):
             R.check(R.lib.rgm_gemm_tile(R.ptr(a), K, R.ptr(bs[cnt[0] % ncopy]), K, R.ptr(c), N, M, N, K, R.ptr(bias), 0, tile, st))
     for _ in range(3):
         run()
-    if check and not os.environ.get('RGM_GEMM2_EXP'):                                         # max |c - (a b^T + bias)| relative to the output scale
+    if check and not os.environ.get('RGM_GEMM2_EXP') and not ACT and not SPLIT:                                         # max |c - (a b^T + bias)| relative to the output scale
         ref = torch.addmm(bias, a, b.t())
         err = ((c - ref).abs().max() / ref.abs().max()).item()
         assert err < 2e-4, f"tile {tile} wrong on {M}x{N}x{K}: rel err {err:.3e}"

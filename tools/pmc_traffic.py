@@ -27,13 +27,19 @@ def short(name):
 def main(fdb, wdb, out):
     f, w = per_kernel(fdb, "FETCH_SIZE"), per_kernel(wdb, "WRITE_SIZE")
     res, detail = {}, {}
+    try:                                              # merge into an existing file (other kernels measured earlier)
+        res = json.load(open(out))
+        detail = res.get("_detail", {})
+    except (OSError, ValueError):
+        pass
     for k in sorted(set(f) | set(w)):
         fb = 2.0 * f.get(k, (0, 0))[0] * 1024.0
         wb = w.get(k, (0, 0))[0] * 1024.0
         res[k] = round(fb + wb)
         detail[k] = {"fetch_bytes_corrected": round(fb), "write_bytes": round(wb), "launches_sampled": f.get(k, (0, 0))[1]}
     res["_detail"] = detail
-    res["_note"] = "bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction), separate --pmc passes"
+    res.setdefault("_note", "")
+    res["_note_formula"] = "bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 FETCH_SIZE half-count correction), separate --pmc passes"
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     for k in list(res)[:12]:
         print(k[:60], res[k] if not isinstance(res[k], dict) else "...")
