@@ -642,6 +642,9 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long long work = (long long)p.M * p.N * p.batch;
     tile = t128 >= 512 ? 43 : (work >= (long long)1024 * 1152 ? 44 : 46);
+    // implicit-conv loader: the per-piece pixel bookkeeping pushes the cross-iteration pipeline at 128x128 over 256
+    // registers (one wave per SIMD) -> the single-set pipeline (PIPE 1) there
+    if (p.aload && tile == 43) tile = 21;
   }
   switch (tile) {
     case 1: return launch2<128, 128, 2, 2>(p, s, 1);

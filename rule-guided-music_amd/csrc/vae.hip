@@ -108,7 +108,7 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, float* __res
 // y = act((x - mean) * rstd * gamma + beta), act = swish (1) or identity (0); NHWC float4 pass
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, long long total4, int P, int C,
-                                int swish) {
+                                int swish, int out_split) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int q = C >> 2;
@@ -126,7 +126,18 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
   if (swish) {
     o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
   }
-  reinterpret_cast<float4*>(y)[i] = o;
+  if (out_split) {   // split-row pixels (common.h split_idx) for the pre-split conv GEMM
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+    hi[0] = (__bf16)o.x; hi[1] = (__bf16)o.y; hi[2] = (__bf16)o.z; hi[3] = (__bf16)o.w;
+    lo[0] = (__bf16)(o.x - (float)hi[0]); lo[1] = (__bf16)(o.y - (float)hi[1]);
+    lo[2] = (__bf16)(o.z - (float)hi[2]); lo[3] = (__bf16)(o.w - (float)hi[3]);
+    __bf16* px = reinterpret_cast<__bf16*>(y + (i / q) * C);
+    *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4)) = hi;
+    *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4) + 32) = lo;
+  } else {
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
 }
 
 // rows softmax, one wave per row, cols <= 1024 and % 4 == 0
@@ -230,6 +241,7 @@ struct VSlot {
   bool set = false;
   int conv3 = 0;  // 1: repack [co][ci][3][3] -> [co][9][ci]
   int cout = 0, cin = 0;
+  bool derived = false;  // "<key>.S": split-row copy of a 3x3 weight for the pre-split conv GEMM (gemm2.hip), not a parameter
 };
 
 struct rgm_vae {
@@ -252,6 +264,15 @@ static void vslot(rgm_vae* h, const std::string& key, size_t numel, int conv3 = 
   h->slots[key] = s;
   h->arena_floats += (numel + 3) / 4 * 4;
   if (numel > h->stage_floats) h->stage_floats = numel;
+  if (conv3 && cin % 32 == 0) {
+    VSlot d;
+    d.off = h->arena_floats;
+    d.numel = numel;
+    d.derived = true;
+    d.set = true;
+    h->slots[key + ".S"] = d;
+    h->arena_floats += (numel + 3) / 4 * 4;
+  }
 }
 
 static void res_slots(rgm_vae* h, const std::string& p, int cin, int cout) {
@@ -317,12 +338,16 @@ extern "C" void rgm_vae_destroy(rgm_vae* h) {
   delete h;
 }
 
-extern "C" int rgm_vae_has_param(rgm_vae* h, const char* key) { return h && key && h->slots.count(key) ? 1 : 0; }
+extern "C" int rgm_vae_has_param(rgm_vae* h, const char* key) {
+  if (!h || !key) return 0;
+  auto it = h->slots.find(key);
+  return it != h->slots.end() && !it->second.derived ? 1 : 0;
+}
 
 extern "C" int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, const int64_t* shape, int ndim) {
   RGM_REQUIRE(h && key && dptr, "vae_set_param: null argument");
   auto it = h->slots.find(key);
-  RGM_REQUIRE(it != h->slots.end(), "vae_set_param: unknown key '%s'", key);
+  RGM_REQUIRE(it != h->slots.end() && !it->second.derived, "vae_set_param: unknown key '%s'", key);
   size_t numel = 1;
   for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
   VSlot& s = it->second;
@@ -331,6 +356,9 @@ extern "C" int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, 
     RGM_CHECK_HIP(hipMemcpy(h->stage, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
     hipLaunchKernelGGL(repack_conv3_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, 0, h->stage, h->arena + s.off, s.cout, s.cin);
     RGM_LAUNCH_CHECK();
+    auto sp = h->slots.find(std::string(key) + ".S");
+    if (sp != h->slots.end())   // rows = cout, K = 9*cin: the 32-blocks of a split row never straddle a tap (cin % 32 == 0)
+      RGM_TRY(split_rows_launch(h->arena + s.off, h->arena + sp->second.off, s.cout, 9 * s.cin, 9 * s.cin, 9 * s.cin, 0));
     RGM_CHECK_HIP(hipStreamSynchronize(0));
   } else {
     RGM_CHECK_HIP(hipMemcpy(h->arena + s.off, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
@@ -384,9 +412,10 @@ struct Ctx {
   VPlan p;
   int M;
   hipStream_t s;
+  int split = 0;   // bf16x3_presplit: GroupNorm writes split rows, the 3x3 convs run on gemm2.hip
 };
 
-int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish) {
+int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish, int out_split = 0) {
   hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_CHUNKS, c.M), dim3(256), 0, c.s, x, c.p.part, P, C, GN_CHUNKS);
   RGM_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, c.p.stats, c.M, GN_CHUNKS,
@@ -394,7 +423,7 @@ int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string
   RGM_LAUNCH_CHECK();
   const long long total4 = (long long)c.M * P * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, y, c.p.stats,
-                     c.h->p(key + ".weight"), c.h->p(key + ".bias"), total4, P, C, swish);
+                     c.h->p(key + ".weight"), c.h->p(key + ".bias"), total4, P, C, swish, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
@@ -406,14 +435,16 @@ int ilog2(int v) {
 }
 
 // out[M*H*W, Cout] = conv3x3(in NHWC [M, H>>ups, W>>ups, Cin]) + bias (+ res)
-int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const std::string& key, int ups, const float* res) {
+// in_split: `in` holds split-row pixels (group_norm(..., out_split=1) or split_rows) -> pre-split LDS-DMA kernel
+int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const std::string& key, int ups, const float* res,
+          int in_split = 0) {
   GemmParams g;
-  g.A = in; g.B = c.h->p(key + ".weight"); g.ldb = 9 * Cin; g.C = out; g.ldc = Cout;
+  g.A = in; g.B = c.h->p(key + (in_split ? ".weight.S" : ".weight")); g.ldb = 9 * Cin; g.C = out; g.ldc = Cout;
   g.M = c.M * H * H; g.N = Cout; g.K = 9 * Cin; g.lda = Cin;
   g.bias = c.h->p(key + ".bias");
   g.res = res; g.ldres = Cout;
   g.aload = 1; g.H = H; g.W = H; g.Cin = Cin; g.logH = ilog2(H); g.logW = ilog2(H); g.ups = ups;
-  return gemm_launch(g, c.s);
+  return in_split ? gemm2_launch(g, c.s) : gemm_launch(g, c.s);
 }
 
 int conv1(Ctx& c, const float* in, float* out, int rows, int Cin, int Cout, const std::string& key, const float* res) {
@@ -427,13 +458,13 @@ int conv1(Ctx& c, const float* in, float* out, int rows, int Cin, int Cout, cons
 // x (cur) -> result buffer; uses the two other rotating buffers as scratch. Returns which buffer holds the result.
 int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout, const std::string& key) {
   const int P = H * H;
-  RGM_TRY(group_norm(c, cur, t1, P, Cin, key + "norm1", 1));
-  RGM_TRY(conv3(c, t1, t2, H, Cin, Cout, key + "conv1", 0, nullptr));
-  RGM_TRY(group_norm(c, t2, t1, P, Cout, key + "norm2", 1));
+  RGM_TRY(group_norm(c, cur, t1, P, Cin, key + "norm1", 1, c.split));
+  RGM_TRY(conv3(c, t1, t2, H, Cin, Cout, key + "conv1", 0, nullptr, c.split));
+  RGM_TRY(group_norm(c, t2, t1, P, Cout, key + "norm2", 1, c.split));
   if (Cin == Cout) {
-    RGM_TRY(conv3(c, t1, cur, H, Cout, Cout, key + "conv2", 0, cur));  // in place: out = conv2(.) + x
+    RGM_TRY(conv3(c, t1, cur, H, Cout, Cout, key + "conv2", 0, cur, c.split));  // in place: out = conv2(.) + x
   } else {
-    RGM_TRY(conv3(c, t1, t2, H, Cout, Cout, key + "conv2", 0, nullptr));
+    RGM_TRY(conv3(c, t1, t2, H, Cout, Cout, key + "conv2", 0, nullptr, c.split));
     RGM_TRY(conv1(c, cur, t1, c.M * P, Cin, Cout, key + "nin_shortcut", t2));  // t1 = nin(x) + h
     std::swap(cur, t1);
   }
@@ -459,7 +490,7 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
     return RGM_ERR_STATE;
   }
   const int M = Nb * S;
-  Ctx c{h, vplan(M, ws), M, s};
+  Ctx c{h, vplan(M, ws), M, s, rgm_get_gemm_precision() == 2 ? 1 : 0};
   if (!ws || c.p.bytes > ws_bytes) {
     set_error("vae_decode: workspace %zu bytes < required %zu", ws_bytes, c.p.bytes);
     return RGM_ERR_WORKSPACE;
@@ -508,7 +539,12 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
     }
     if (lvl != 0) {
       H *= 2;
-      RGM_TRY(conv3(c, cur, t1, H, C, C, d + "up." + std::to_string(lvl) + ".upsample.conv", 1, nullptr));
+      if (c.split) {   // the upsample conv reads the raw residual stream: one HBM pass turns it into split rows
+        RGM_TRY(split_rows_launch(cur, t2, (long long)c.M * (H / 2) * (H / 2), C, C, C, s));
+        RGM_TRY(conv3(c, t2, t1, H, C, C, d + "up." + std::to_string(lvl) + ".upsample.conv", 1, nullptr, 1));
+      } else {
+        RGM_TRY(conv3(c, cur, t1, H, C, C, d + "up." + std::to_string(lvl) + ".upsample.conv", 1, nullptr));
+      }
       std::swap(cur, t1);
     }
   }
