@@ -95,14 +95,18 @@ int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const
  *   0  exact fp32 products on v_mfma_f32_32x32x2_f32 (default; 157 TFLOP/s peak);
  *   1  "bf16x3": operands split hi+lo bf16 while staged to LDS, a*b ~= ah*bh + ah*bl + al*bh on
  *      v_mfma_f32_32x32x16_bf16 with fp32 accumulation (~2e-5 relative per product; 833 TFLOP/s equivalent peak).
- * Process-wide default used by all handles; results stay within the 1e-3 latent tolerance either way (tests). */
+ *   2  "bf16x3_presplit": same products, hi/lo split done once by the producer of each operand; the DiT backbone
+ *      GEMMs and the VAE 3x3 convs run on the LDS-DMA kernel (rgm_gemm_split), everything else as mode 1.
+ * Process-wide default used by all handles; results stay within the 1e-3 latent tolerance in every mode (tests). */
 int rgm_set_gemm_precision(int prec);
 int rgm_get_gemm_precision(void);
-/* Split-row format of the bf16x3 fast path: a logical fp32 row of K values stored in the same K*4 bytes as K bf16
- * `hi` followed by K bf16 `lo` (x ~= hi + lo).  rgm_split_rows converts (rows,K) fp32 -> split (out-of-place);
- * rgm_gemm_split is the LDS-DMA kernel on operands already in that format (A (M,K), B (N,K) both split):
- * C = act(A . B^T + bias), optionally written split as well (N%4==0).  tile: 0 auto, 1 128x128, 2 128x64,
- * 3 64x64, 5 256x128. */
+/* Split-row format of the pre-split bf16x3 path (precision 2, "bf16x3_presplit"): a logical fp32 row of K values
+ * keeps its K*4 bytes; every block of 32 values is one 128-byte line [32 bf16 hi | 32 bf16 lo] (x ~= hi + lo, both
+ * round-to-nearest; K % 32 == 0).  rgm_split_rows converts (rows,K) fp32 -> split (out-of-place); rgm_gemm_split is
+ * the LDS-DMA kernel (csrc/gemm2.hip) on operands already in that format (A (M,K), B (N,K) both split):
+ * C = act(A . B^T + bias), optionally written split as well (N % 32 == 0).  tile: 0 auto; 1 128x128, 2 128x64,
+ * 3 64x64, 5 256x128 (3-stage ring); 21 / 22 = 128x128 / 128x64 with the single-set pipeline; 43 / 44 / 45 / 46 =
+ * 128x128 / 128x64 / 256x128 / 64x64 with the cross-iteration register pipeline. */
 int rgm_split_rows(const float* x, float* out, int64_t rows, int K, void* stream);
 int rgm_gemm_split(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias,
                    int act, int tile, int out_split, void* stream);
@@ -202,12 +206,16 @@ int rgm_rotary_attention_bwd(const float* qkv, const float* o, const float* d_o,
 
 /* ------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py roofline leg): with profiling on, every GEMM launch is bracketed by two
- * hipEvents recorded on the launch stream.  kernel ids: 1..4 = dense tiles 128x128 / 128x64 / 64x64 /
- * 32x128, 11..14 = the same tiles with the implicit 3x3-conv loader.
+ * hipEvents recorded on the launch stream.  kernel ids: gemm.hip = tile (1..5: 128x128 / 128x64 / 64x64 /
+ * 32x128 / 256x128) + 10 with the implicit 3x3-conv loader + 20 in bf16x3; gemm2.hip = 40 + tile (as in
+ * rgm_gemm_split) + 10 with the conv loader.
+ * rgm_gemm2_dbg: s_memtime stamps of the gemm2 K loop (tools/gemm_stamp.py; library built with
+ * -DRGM_GEMM2_STAMPS): mode 1 arm, 2 copy 64 counters to out64, 0 off.
  * ---------------------------------------------------------------------------------------------- */
 int rgm_prof_enable(int on);
 int rgm_prof_reset(void);
 int rgm_prof_report(int kernel, int* launches, double* total_ms, double* total_flops);
+int rgm_gemm2_dbg(int mode, long long* out64);
 
 /* ------------------------------------------------------------------------------------------------
  * DiffCollage long-sequence composition                   diff_collage/w_img.py, condind_long.py, condind_circle.py
