@@ -13,6 +13,7 @@
 //   * activations: caller workspace; residual stream x[N*T, D] is updated in place by the gated
 //     epilogues of proj / fc2, xm / qkv / attn / hidden are scratch strips reused by every block.
 #include <map>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <math.h>
@@ -355,8 +356,9 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
     return gemm2_launch(g, s);
   };
+  static const int dit_exp = getenv("RGM_DIT_EXP") ? atoi(getenv("RGM_DIT_EXP")) : 0;   // timing experiments only (wrong results)
   for (int i = 0; i < c.depth; ++i) {
-    const std::string b = "blocks." + std::to_string(i) + ".";
+    const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
     if (v2) {
       // every producer (adaLN-LayerNorm, attention, fc1's GELU epilogue) writes split rows; all four GEMMs run on the
@@ -366,7 +368,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, nullptr, 1));
       RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 0));
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
-      RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, 2, 1, nullptr, nullptr, 0));
+      RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr, 0));
       RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, 0));
       continue;
     }

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
             for (int q4 = 0; q4 < 4; ++q4) v[q4] = silu_f(v[q4]);
           } else if (p.act == 2) {
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] = gelu_tanh_f(v[q4]);
+            for (int q4 = 0; q4 < 4; ++q4) v[q4] = gelu_tanh_fast_f(v[q4]);
           }
           if (p.gate) {
             const float4 g4 = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
