@@ -106,7 +106,8 @@ int rgm_get_gemm_precision(void);
  * the LDS-DMA kernel (csrc/gemm2.hip) on operands already in that format (A (M,K), B (N,K) both split):
  * C = act(A . B^T + bias), optionally written split as well (N % 32 == 0).  tile: 0 auto; 1 128x128, 2 128x64,
  * 3 64x64, 5 256x128 (3-stage ring); 21 / 22 = 128x128 / 128x64 with the single-set pipeline; 43 / 44 / 45 / 46 =
- * 128x128 / 128x64 / 256x128 / 64x64 with the cross-iteration register pipeline. */
+ * 128x128 / 128x64 / 256x128 / 64x64 with the cross-iteration register pipeline; 51 / 52 = 128x128 / 128x64 with
+ * the loader/consumer split (4 MFMA waves + 4 DMA waves, 3-stage ring). */
 int rgm_split_rows(const float* x, float* out, int64_t rows, int K, void* stream);
 int rgm_gemm_split(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias,
                    int act, int tile, int out_split, void* stream);

@@ -34,7 +34,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 }
 
 template <int BM, int BN, int WM, int WN, int ALOAD, int NSTAGE, int DBG = 0, int PIPE = 0>
-__global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m,
+__global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m,
                                                             int tiles_n, int exp, long long* __restrict__ dbg = nullptr) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -81,6 +81,63 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
   const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate) & 15) == 0 &&
                    exp != 5;
   const int KT = p.K >> 5;
+
+  if constexpr (PIPE == 4) {
+    // Loader waves (waves NW..2NW-1): all the DMA of the workgroup and nothing else.  One wave issues an LDS-DMA piece
+    // only every ~70-80 cycles whatever the TA load (tools/gemm_stamp.py; the guide's "ldsdma-fill": 25 GB/s per
+    // loader wave), which is what sat between the MFMAs of the other kernels; NW loaders beside NW MFMA waves give the
+    // 40 B/clk/CU a 128x128 tile needs without touching the MFMA waves' streams.  3-stage ring: after barrier kt-1
+    // (consumers are done with tile kt-1) a loader issues its share of tile kt+2 into that stage, waits until its
+    // share of tile kt+1 has landed (vmcnt(LSEG): only the pieces just issued may still fly) and joins barrier kt.
+    constexpr int LSEG = SEGS / NW;                         // pieces per loader wave and tile
+    static_assert(NSTAGE == 3 && ALOAD == 0 && SEGS % NW == 0, "PIPE 4: dense operands, 3-stage ring");
+    if (wave >= NW) {
+      const int lw = wave - NW;
+      const int r8l = lane >> 3;
+      const char* lsrc[LSEG];
+      int linc[LSEG];
+#pragma unroll
+      for (int i = 0; i < LSEG; ++i) {
+        const int sgm = lw + i * NW;
+        const bool isA = sgm < BM / 8;
+        const int row_l = sgm * 8 + r8l;
+        const int row_t = isA ? row_l : row_l - BM;
+        const int cs = ((lane & 7) ^ ((row_l >> 1) & 7)) << 4;
+        const int row = (isA ? m0 : n0) + row_t;
+        const bool ok = isA ? row < p.M : row < p.N;
+        lsrc[i] = ok ? (isA ? Ab + (long long)row * p.lda * 4 : Bb + (long long)row * p.ldb * 4) + cs : zero_page + cs;
+        linc[i] = ok ? 128 : 0;
+      }
+      auto issue_tile = [&](char* dst) {
+        static_for<0, LSEG>([&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          dma16(lsrc[i], dst + (lw + i * NW) * 1024);
+          lsrc[i] += linc[i];
+        });
+      };
+      issue_tile(ring);
+      if (KT > 1) {
+        issue_tile(ring + STAGE);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSEG) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();                     // barrier P: tile 0 is in LDS
+      int s2 = 2;
+      for (int kt = 0; kt + 1 < KT; ++kt) {
+        if (kt + 2 < KT && exp != 1) {
+          issue_tile(ring + s2 * STAGE);
+          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSEG) : "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                   // barrier kt: tile kt+1 is in LDS
+        s2 = s2 == 2 ? 0 : s2 + 1;
+      }
+      if (vec) __syncthreads();                         // the consumers' epilogue barrier
+      return;
+    }
+  }
 
   const int r8 = lane >> 3;
   const char* src[SPW];
@@ -172,6 +229,72 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm2_kernel(GemmParams p, const 
     tp = now_;                                                     \
     __builtin_amdgcn_sched_barrier(0);                             \
   }
+  if constexpr (PIPE == 4) {
+    // Consumer waves of the loader/consumer split: MFMAs from registers, the next tile's 2*(TM+TN)*2 fragment reads
+    // dropped between the MFMAs of the second k16 step, one barrier per K-tile; no VMEM in the loop.
+    constexpr int NM = TM * TN * 3;
+    constexpr int NRD = 2 * (TM + TN) * 2;                 // ds_read_b128 per tile
+    constexpr int RPM = (NRD + NM - 1) / NM;               // reads per MFMA gap
+    struct Frags {
+      bf16x8 a[2][TM][2], b[2][TN][2];                     // [k16 step][frag][hi, lo]
+    };
+    auto read_one = [&](Frags& f, const char* As, auto jc) {
+      constexpr int j = decltype(jc)::value;               // read index: st-major, A frags (hi, lo) then B frags (hi, lo)
+      constexpr int st = j / (2 * (TM + TN)), r = j % (2 * (TM + TN));
+      constexpr int fi = r / 2, lo = r % 2;
+      const int chunk = ((4 * lo + 2 * st + hh) ^ rq) << 4;
+      if constexpr (fi < TM) {
+        f.a[st][fi][lo] = *reinterpret_cast<const bf16x8*>(As + (arow0 + fi * 32 + l31) * 128 + chunk);
+      } else {
+        f.b[st][fi - TM][lo] = *reinterpret_cast<const bf16x8*>(As + BM * 128 + (bcol0 + (fi - TM) * 32 + l31) * 128 + chunk);
+      }
+    };
+    auto mfma_step = [&](const Frags& f, auto stc, bool prefetch, Frags& nxt, const char* As_next) {
+      constexpr int st = decltype(stc)::value;
+      static_for<0, NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[st][im][t == 0 ? 1 : 0], f.b[st][in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
+        if constexpr (st == 1) {
+          if (prefetch) {
+            static_for<0, RPM>([&](auto rc) {
+              constexpr int j = m * RPM + decltype(rc)::value;
+              if constexpr (j < NRD) read_one(nxt, As_next, std::integral_constant<int, j>{});
+            });
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    Frags f0, f1;
+    __builtin_amdgcn_s_barrier();                         // barrier P (loader: tile 0 landed)
+    static_for<0, NRD>([&](auto jc) { read_one(f0, ring, jc); });
+    int s1 = 1;
+    if (DBG) {
+      tp = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tacc[2] = tp - t_entry;
+    }
+    auto iter = [&](Frags& cur, Frags& nxt, int kt) {
+      const bool more1 = kt + 1 < KT;
+      mfma_step(cur, std::integral_constant<int, 0>{}, false, nxt, nullptr);
+      RGM_STAMP(4)
+      if (more1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RGM_STAMP(0)
+        __builtin_amdgcn_s_barrier();                     // tile kt+1 in LDS; every consumer is done reading tile kt
+        RGM_STAMP(1)
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_step(cur, std::integral_constant<int, 1>{}, more1, nxt, ring + s1 * STAGE);
+      RGM_STAMP(6)
+      s1 = s1 == 2 ? 0 : s1 + 1;
+    };
+    for (int kt = 0; kt < KT; kt += 2) {
+      iter(f0, f1, kt);
+      if (kt + 1 < KT) iter(f1, f0, kt + 1);
+    }
+  } else
   if constexpr (PIPE == 3) {
     // Cross-iteration register pipeline: the fragments of K-tile kt+1 are requested (behind the barrier that says the
     // tile has landed) BEFORE the second k16 step of tile kt is multiplied, into a second register set, so neither the
@@ -585,7 +708,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
   static bool attr0 = false, attr1 = false;
   auto k0 = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 0, PIPE>;
-  auto k1 = gemm2_kernel<BM, BN, WM, WN, 1, NSTAGE, 0, PIPE>;
+  auto k1 = gemm2_kernel<BM, BN, WM, WN, PIPE == 4 ? 0 : 1, NSTAGE, 0, PIPE>;
+  RGM_REQUIRE(PIPE != 4 || p.aload == 0, "gemm2: the loader/consumer kernels take dense operands only");
   if (lds > 65536) {
     if (p.aload == 0 && !attr0) {
       RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -596,7 +720,7 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
       attr1 = true;
     }
   }
-  dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64);
+  dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64 * (PIPE == 4 ? 2 : 1));
   Prof2 rec{};
   if (g2_prof_on) {
     RGM_CHECK_HIP(hipEventCreate(&rec.a));
@@ -637,11 +761,12 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
   int tile = p.tile;
   if (tile == 0) {
-    // tools/gemm_sweep.py on MI355X (cross-iteration pipeline, PIPE 3): 128x128 (2 workgroups per CU) once it fills
-    // at least one round of the chip, 128x64 (3 per CU) below that, 64x64 on small grids
+    // tools/gemm_sweep.py on MI355X: cross-iteration pipeline (PIPE 3) at 128x128 (2 workgroups per CU) once the grid
+    // fills at least one round of the chip, at 128x64 (3 per CU) below that; grids that do not even fill the CUs
+    // once (B = 2: M = 512 rows) are latency-bound and take the loader/consumer kernel with its 3-stage ring
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
-    const long long work = (long long)p.M * p.N * p.batch;
-    tile = t128 >= 512 ? 43 : (work >= (long long)1024 * 1152 ? 44 : 46);
+    const long long t64 = (long long)cdiv(p.M, 128) * cdiv(p.N, 64) * p.batch;
+    tile = t128 >= 512 ? 43 : (t64 >= 512 || p.aload ? 44 : 52);
     // implicit-conv loader: the per-piece pixel bookkeeping pushes the cross-iteration pipeline at 128x128 over 256
     // registers (one wave per SIMD) -> the single-set pipeline (PIPE 1) there
     if (p.aload && tile == 43) tile = 21;
@@ -659,6 +784,9 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 44: return launch2<128, 64, 2, 2, 2, 3>(p, s, 44);    // 48 KB: 3 per CU
     case 45: return launch2<256, 128, 4, 2, 2, 3>(p, s, 45);   // 96 KB, 8 waves
     case 46: return launch2<64, 64, 2, 2, 3, 3>(p, s, 46);     // 48 KB: 3 per CU
+    // loader/consumer split (PIPE == 4): NW MFMA waves + NW DMA waves, 3-stage ring
+    case 51: return launch2<128, 128, 2, 2, 3, 4>(p, s, 51);   // 96 KB: 1 per CU
+    case 52: return launch2<128, 64, 2, 2, 3, 4>(p, s, 52);    // 72 KB: 2 per CU
     default: break;
   }
   set_error("gemm2: unknown tile %d", tile);
