@@ -111,6 +111,11 @@ int rgm_get_gemm_precision(void);
 int rgm_split_rows(const float* x, float* out, int64_t rows, int K, void* stream);
 int rgm_gemm_split(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias,
                    int act, int tile, int out_split, void* stream);
+/* the same with explicit row strides (elements; multiples of 32 for split rows): padded rows keep one K-slice of
+ * many rows from landing on a few L2 channels when K*4 is a multiple of 2 KiB */
+int rgm_split_rows_ld(const float* x, int ld_in, float* out, int ld_out, int64_t rows, int K, void* stream);
+int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
+                      const float* bias, int act, int tile, int out_split, void* stream);
 /* Same as rgm_gemm without gate/residual but with an explicit tile shape in the low 4 bits (1: 128x128,
  * 2: 128x64, 3: 64x64, 4: 32x128, 0: auto) and an explicit precision in bits 4.. (0: library default,
  * 1: fp32, 2: bf16x3) -- used by the parity tests and tile-selection experiments. */

@@ -1,0 +1,289 @@
+// attention_x3.hip -- the RotaryAttention core of attention.hip in bf16x3 arithmetic (the bf16x3 / bf16x3_presplit modes).
+//
+// Same algorithm, reference (guided_diffusion/dit.py:263-277, rotary-embedding-torch 0.3.2) and work decomposition
+// as attention.hip -- one workgroup per (sample, head), K and V of the head resident in LDS, single pass, scores
+// computed transposed (S^T = K . Q^T) so that the probabilities stay in registers as the B operand of
+// O^T = V^T . P^T -- but both products run on v_mfma_f32_32x32x16_bf16 with every operand split x ~= hi + lo
+// (a*b ~= al*bh + ah*bl + ah*bh, fp32 accumulate), like the GEMMs of these modes.  The fp32 kernel spends 43 of its
+// 64 us (T = 256, hd = 72) in v_mfma_f32_32x32x2_f32; the same contraction is 5.3x fewer matrix-pipe cycles here.
+//
+// LDS images (both split once while staging, 16-byte slots, odd slot strides -> conflict-free ds_read_b128 groups):
+//   K   [key][ hi: KP bf16 | lo: KP bf16 | pad ]      KP = hd rounded up to 16 (zeros beyond hd), A operand of S^T:
+//       lane (key, half) reads d = 16j + 8*half .. +7 of both planes;
+//   V^T [d][ hi: TP bf16 | lo: TP bf16 | pad ]        keys PERMUTED inside every 32-group so that the 8 keys a lane's
+//       probabilities cover in one k16 step (C/D layout of S^T: register r <-> key (r&3) + 8*(r>>2) + 4*half) are 16
+//       contiguous bytes: position 16*h2 + 8*half + j  <->  key (j&3) + 8*(2*h2 + (j>>2)) + 4*half.
+#include "common.h"
+
+namespace rgm {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float exp_neg_x3(float x) {   // exp(x), x <= 0, no range-check compares (see attention.hip)
+  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
+  x = fmaxf(x, -104.0f);
+  const float t = x * L2E_HI;
+  float r = fmaf(x, L2E_HI, -t);
+  r = fmaf(x, L2E_LO, r);
+  const float e = __builtin_amdgcn_exp2f(t);
+  return fmaf(e, r * 0.693147182464599609375f, e);
+}
+
+__device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hi[i] = (__bf16)v[i];
+    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+  }
+}
+
+template <int HD, int NKT>
+__global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
+                                                                  const float* __restrict__ cos_tab,
+                                                                  const float* __restrict__ sin_tab, int T, int heads, int rot_half,
+                                                                  int out_split) {
+  constexpr int KP = (HD + 15) / 16 * 16;   // padded contraction length of QK^T
+  constexpr int KS = KP / 16;               // k16 steps of QK^T
+  constexpr int DT = (HD + 31) / 32;        // 32-wide output-channel tiles
+  constexpr int TP = NKT * 32;              // padded key count
+  constexpr int KROW = KP * 4 + 16;         // bytes per K row  (KP*4/16 is even -> +1 slot makes the stride odd)
+  constexpr int VROW = TP * 4 + 16;         // bytes per V^T row (TP*4/16 = 8*NKT is even)
+  static_assert((KROW / 16) % 2 == 1 && (VROW / 16) % 2 == 1, "slot strides must be odd");
+  extern __shared__ __attribute__((aligned(16))) char smem3[];
+  char* Ks = smem3;                         // [TP][KROW]
+  char* Vt = smem3 + TP * KROW;             // [HD][VROW]
+
+  const int n = blockIdx.x / heads, head = blockIdx.x - n * heads;
+  const int D = heads * HD, D3 = 3 * D;
+  const float* base = qkv + (long long)n * T * D3 + head * HD;
+  const int tid = threadIdx.x;
+  const int R = 2 * rot_half;
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+  // ---- stage K (rotated, split) and V (split, transposed, keys permuted); padded keys / channels are zeros
+  constexpr int CPR = KP / 4;               // float4 chunks per padded K row
+  for (int c = tid; c < TP * CPR; c += 512) {
+    const int key = c / CPR, ch = c - key * CPR, d0 = ch * 4;   // consecutive lanes -> one row's chunks (coalesced global reads)
+    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+    if (key < T && d0 < HD) {
+      const float* rowp = base + (long long)key * D3;
+      kv = *reinterpret_cast<const float4*>(rowp + D + d0);
+      vv = *reinterpret_cast<const float4*>(rowp + 2 * D + d0);
+      if (d0 < R) {
+        const int pi = key * rot_half + (d0 >> 1);
+        const float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
+        const float x0 = kv.x, x1 = kv.y, x2 = kv.z, x3 = kv.w;
+        kv.x = x0 * c0 - x1 * s0;
+        kv.y = x1 * c0 + x0 * s0;
+        kv.z = x2 * c1 - x3 * s1;
+        kv.w = x3 * c1 + x2 * s1;
+      }
+    }
+    {
+      bf16x4 hi, lo;
+      hi[0] = (__bf16)kv.x; hi[1] = (__bf16)kv.y; hi[2] = (__bf16)kv.z; hi[3] = (__bf16)kv.w;
+      lo[0] = (__bf16)(kv.x - (float)hi[0]); lo[1] = (__bf16)(kv.y - (float)hi[1]);
+      lo[2] = (__bf16)(kv.z - (float)hi[2]); lo[3] = (__bf16)(kv.w - (float)hi[3]);
+      char* kr = Ks + key * KROW + d0 * 2;
+      *reinterpret_cast<bf16x4*>(kr) = hi;
+      *reinterpret_cast<bf16x4*>(kr + KP * 2) = lo;
+    }
+    if (d0 < HD) {
+      // key -> position inside its 32-group: key = (j&3) + 8*(2*h2 + (j>>2)) + 4*half  <->  pos = 16*h2 + 8*half + j
+      const int k32 = key & 31;
+      const int half = (k32 >> 2) & 1, blk = k32 >> 3;                 // blk = 2*h2 + (j>>2)
+      const int pos = (key & ~31) + 16 * (blk >> 1) + 8 * half + 4 * (blk & 1) + (k32 & 3);
+      const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const __bf16 hi = (__bf16)vs[i];
+        char* vr = Vt + (d0 + i) * VROW + pos * 2;
+        *reinterpret_cast<__bf16*>(vr) = hi;
+        *reinterpret_cast<__bf16*>(vr + TP * 2) = (__bf16)(vs[i] - (float)hi);
+      }
+    }
+  }
+  __syncthreads();
+
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const float scale = rsqrtf((float)HD);
+  const int nqt = (T + 31) >> 5;
+
+  for (int qt = wave; qt < nqt; qt += 8) {
+    const int q = qt * 32 + l31;
+    const int qc = min(q, T - 1);
+    // ---- Q fragments: lane (query l31, half hh) holds Q[q][16j + 8hh .. +7], rotated, pre-scaled, split
+    bf16x8 qh[KS], ql[KS];
+    {
+      const float* qp = base + (long long)qc * D3;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d0 = 16 * j + 8 * hh + 4 * u;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (d0 < HD) {
+            v = *reinterpret_cast<const float4*>(qp + d0);
+            if (d0 < R) {
+              const int pi = qc * rot_half + (d0 >> 1);
+              const float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
+              const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+              v.x = x0 * c0 - x1 * s0;
+              v.y = x1 * c0 + x0 * s0;
+              v.z = x2 * c1 - x3 * s1;
+              v.w = x3 * c1 + x2 * s1;
+            }
+          }
+          v8[4 * u] = v.x * scale; v8[4 * u + 1] = v.y * scale; v8[4 * u + 2] = v.z * scale; v8[4 * u + 3] = v.w * scale;
+        }
+        split8(v8, qh[j], ql[j]);
+      }
+    }
+    // ---- S^T[key][query] = K . Q^T
+    f32x16 sacc[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) sacc[kt][e] = 0.f;
+      const char* kp = Ks + (kt * 32 + l31) * KROW + 16 * hh;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 32 * j);
+        const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + 32 * j + KP * 2);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[j], sacc[kt], 0, 0, 0);
+      }
+    }
+    // ---- softmax over keys: register e of tile kt is key kt*32 + (e&3) + 8*(e>>2) + 4*hh
+    float mx = -INFINITY;
+    const int ktr = T >> 5, tr = T & 31;   // ragged tile index / valid keys in it (wave-uniform)
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      if (kt * 32 >= T) {                  // tile entirely past the sequence
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kt][e] = -INFINITY;
+      } else if (kt == ktr) {              // the one ragged tile: 16 lane masks shared by all kt
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          if ((e & 3) + 8 * (e >> 2) + 4 * hh >= tr) sacc[kt][e] = -INFINITY;
+      }
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const float pv = exp_neg_x3(sacc[kt][e] - mx);
+        sacc[kt][e] = pv;
+        sum += pv;
+      }
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    // ---- O^T[d][query] = V^T . P^T ; A operand = V^T rows (d = lane&31), B operand = the probability registers, split
+    f32x16 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[dt][e] = 0.f;
+    int vrow[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) vrow[dt] = min(dt * 32 + l31, HD - 1) * VROW + 16 * hh;   // rows >= hd: discarded outputs
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+        float p8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p8[j] = sacc[kt][8 * h2 + j];
+        bf16x8 ph, pl;
+        split8(p8, ph, pl);
+        const int koff = (kt * 32 + 16 * h2) * 2;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vt + vrow[dt] + koff);
+          const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vt + vrow[dt] + koff + TP * 2);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[dt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the V^T reads of later key tiles from being hoisted (spills)
+    }
+    // ---- store: lane = query (row), registers 4g..4g+3 = 4 consecutive channels
+    if (q < T) {
+      float* op = o + ((long long)n * T + q) * D + head * HD;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * hh;
+          if (d < HD) {
+            const float4 ov = make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+            if (out_split) {   // split-row format (common.h split_idx): A operand of the pre-split proj GEMM
+              bf16x4 hi, lo;
+              hi[0] = (__bf16)ov.x; hi[1] = (__bf16)ov.y; hi[2] = (__bf16)ov.z; hi[3] = (__bf16)ov.w;
+              lo[0] = (__bf16)(ov.x - (float)hi[0]); lo[1] = (__bf16)(ov.y - (float)hi[1]);
+              lo[2] = (__bf16)(ov.z - (float)hi[2]); lo[3] = (__bf16)(ov.w - (float)hi[3]);
+              __bf16* rp = reinterpret_cast<__bf16*>(o + ((long long)n * T + q) * D);
+              const int si = split_idx(head * HD + d);      // d % 4 == 0: the 4 elements share a 32-block
+              *reinterpret_cast<bf16x4*>(rp + si) = hi;
+              *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
+            } else {
+              *reinterpret_cast<float4*>(op + d) = ov;
+            }
+          }
+        }
+    }
+  }
+}
+
+template <int HD, int NKT>
+static int launch_attn_x3(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,
+                          int out_split, hipStream_t s) {
+  constexpr int KP = (HD + 15) / 16 * 16, TP = NKT * 32;
+  const size_t lds = (size_t)TP * (KP * 4 + 16) + (size_t)HD * (TP * 4 + 16);
+  static bool attr_set = false;
+  auto kern = rotary_attention_x3_kernel<HD, NKT>;
+  if (!attr_set) {
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, out_split);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// same contract as rotary_attention_launch (attention.hip) without the log-sum-exp output
+int rotary_attention_x3_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads,
+                               int hd, int rot_half, hipStream_t s, int out_split) {
+  RGM_REQUIRE(N > 0 && T > 0 && T <= 288, "attention: T=%d out of range (1..288)", T);
+  RGM_REQUIRE((2 * rot_half) % 4 == 0 && 2 * rot_half <= hd, "attention: rotary dim %d", 2 * rot_half);
+  const int nkt = (T + 31) / 32;
+  if (hd == 72) {
+    if (nkt <= 4) return launch_attn_x3<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    if (nkt <= 8) return launch_attn_x3<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    set_error("attention: head_dim 72 supports T <= 256 (K+V of one head must fit the 160 KiB LDS), got %d", T);
+    return RGM_ERR_INVALID;
+  }
+  if (hd == 64) {
+    if (nkt <= 4) return launch_attn_x3<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    if (nkt <= 5) return launch_attn_x3<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    if (nkt <= 8) return launch_attn_x3<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    return launch_attn_x3<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+  }
+  set_error("attention: head_dim %d not supported (64, 72)", hd);
+  return RGM_ERR_INVALID;
+}
+
+int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
+                         int rot_half, hipStream_t s, int out_split) {
+  if (rgm_get_gemm_precision() != 0) return rotary_attention_x3_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, out_split);
+  return rotary_attention_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, nullptr, out_split);
+}
+
+}  // namespace rgm

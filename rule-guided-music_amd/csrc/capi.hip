@@ -49,5 +49,5 @@ extern "C" int rgm_layernorm_modulate(const float* x, float* out, int M, int D, 
 extern "C" int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T,
                                     int heads, int hd, int rot_half, void* stream) {
   RGM_REQUIRE(qkv && o && cos_tab && sin_tab, "attention: null tensor");
-  return rotary_attention_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream);
+  return rotary_attention_fwd(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream);
 }

@@ -135,6 +135,9 @@ struct GemmParams {
 int gemm_launch(const GemmParams& p, hipStream_t stream);
 // gemm2.hip: the same contraction on operands already in split-row format (K bf16 hi | K bf16 lo per row)
 int gemm2_launch(const GemmParams& p, hipStream_t stream);
+int gemm3_launch(const GemmParams& p, hipStream_t stream, int tile);   // persistent loader/consumer kernel (gemm3.hip)
+int gemm2_prof_begin(int id, double flops, hipStream_t s);
+void gemm2_prof_end(int idx, hipStream_t s);
 int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_in, int ld_out, hipStream_t s);
 void gemm2_prof(bool on);
 void gemm2_prof_reset();
@@ -146,6 +149,12 @@ int layernorm_modulate_launch(const float* x, float* out, int M, int D, float ep
                               int rows_per_batch, hipStream_t s, int out_split = 0);
 int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N,
                             int T, int heads, int hd, int rot_half, hipStream_t s, float* lse = nullptr, int out_split = 0);
+// the same forward in bf16x3 arithmetic (attention_x3.hip); no log-sum-exp output
+int rotary_attention_x3_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads,
+                               int hd, int rot_half, hipStream_t s, int out_split = 0);
+// forward attention of the inference paths: fp32 MFMA in fp32 mode, bf16x3 otherwise (rgm_set_gemm_precision)
+int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
+                         int rot_half, hipStream_t s, int out_split = 0);
 // attention backward (attention_bwd.hip): dqkv (N*T, 3*heads*hd) from dO, the saved qkv / O / lse
 int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                 const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,

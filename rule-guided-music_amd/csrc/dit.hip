@@ -365,7 +365,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       // LDS-DMA kernel (gemm2.hip picks the tile)
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
       RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, 0));
-      RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, nullptr, 1));
+      RGM_TRY(rotary_attention_fwd(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, 1));
       RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 0));
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
       RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr, 0));
@@ -374,7 +374,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     }
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, p.M, 3 * D, D, 0, s));
-    RGM_TRY(rotary_attention_launch(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s));
+    RGM_TRY(rotary_attention_fwd(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s));
     RGM_TRY(lin_gated(p.ao, D, h->p(b + "attn.proj.weight"), h->p(b + "attn.proj.bias"), p.x, p.M, D, D, m + 2 * D, L, T, s));
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "mlp.fc1.weight"), h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, p.M, 4 * D, D, 2, s));

@@ -787,6 +787,10 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     // loader/consumer split (PIPE == 4): NW MFMA waves + NW DMA waves, 3-stage ring
     case 51: return launch2<128, 128, 2, 2, 3, 4>(p, s, 51);   // 96 KB: 1 per CU
     case 52: return launch2<128, 64, 2, 2, 3, 4>(p, s, 52);    // 72 KB: 2 per CU
+    // persistent loader/consumer kernel (gemm3.hip)
+    case 61:
+    case 62:
+    case 63: return gemm3_launch(p, s, tile);
     default: break;
   }
   set_error("gemm2: unknown tile %d", tile);
@@ -820,6 +824,20 @@ int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_
 }
 
 void gemm2_prof(bool on) { g2_prof_on = on; }
+// shared with gemm3.hip: bracket one launch with two events on its stream (no-ops while profiling is off)
+int gemm2_prof_begin(int id, double flops, hipStream_t s) {
+  if (!g2_prof_on) return -1;
+  Prof2 rec{};
+  if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return -1;
+  rec.tile = id;
+  rec.flops = flops;
+  (void)hipEventRecord(rec.a, s);
+  g2_prof.push_back(rec);
+  return (int)g2_prof.size() - 1;
+}
+void gemm2_prof_end(int idx, hipStream_t s) {
+  if (idx >= 0 && idx < (int)g2_prof.size()) (void)hipEventRecord(g2_prof[idx].b, s);
+}
 void gemm2_prof_reset() {
   for (auto& r : g2_prof) {
     (void)hipEventDestroy(r.a);
@@ -881,4 +899,18 @@ extern "C" int rgm_gemm2_dbg(int mode, long long* out64) {
     g_dbg = nullptr;
   }
   return RGM_OK;
+}
+
+// Strided variants: rows of A / B / C / the split image may be padded (ld in elements, ld % 32 == 0 for split rows).
+// A row stride that is a multiple of 2 KiB puts one K-slice of many rows on few L2 channels; +32 elements avoids it.
+extern "C" int rgm_split_rows_ld(const float* x, int ld_in, float* out, int ld_out, int64_t rows, int K, void* stream) {
+  return rgm::split_rows_launch(x, out, rows, K, ld_in, ld_out, (hipStream_t)stream);
+}
+extern "C" int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
+                                 const float* bias, int act, int tile, int out_split, void* stream) {
+  RGM_REQUIRE(A_split && B_split && C, "gemm_split_ld: null operand");
+  rgm::GemmParams g;
+  g.A = A_split; g.lda = lda; g.B = B_split; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.tile = tile; g.out_split = out_split;
+  return rgm::gemm2_launch(g, (hipStream_t)stream);
 }

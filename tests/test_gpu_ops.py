@@ -143,7 +143,7 @@ def test_split_rows_format():
     assert (np.abs(back - x) <= np.abs(x) * 2.0 ** -15.5 + 1e-38).all()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 21, 22, 43, 44, 45, 46, 51, 52])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 21, 22, 43, 44, 45, 46, 51, 52, 61, 62, 63])
 @pytest.mark.parametrize("M,N,K", [(200, 96, 64), (513, 1152, 1152), (4096, 36, 1152), (777, 3456, 384), (256, 128, 32)])
 def test_gemm_split_dma_kernel(tile, M, N, K):
     """Pre-split operands + LDS-DMA staging (gemm2): same contraction, bf16x3 accuracy, every tile shape, ragged edges."""

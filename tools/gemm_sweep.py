@@ -20,7 +20,8 @@ SHAPES = [("qkv", 4096, 3456, 1152), ("proj", 4096, 1152, 1152), ("fc1", 4096, 4
 
 
 ACT = int(os.environ.get('SWEEP_ACT', '0'))      # epilogue variants (gemm2 tiles only): 2 = GELU
-SPLIT = int(os.environ.get('SWEEP_SPLIT', '0'))  # 1 = split-row output
+SPLIT = int(os.environ.get('SWEEP_SPLIT', '0'))
+PAD = int(os.environ.get('SWEEP_PAD', '0'))  # 1 = split-row output
 
 
 def bench(M, N, K, tile, iters=20, check=True):
@@ -33,15 +34,17 @@ def bench(M, N, K, tile, iters=20, check=True):
     bias = torch.randn(N, device="cuda")
     st = R.current_stream()
     if tile >= 100:                                   # 100 + t: pre-split operands, LDS-DMA kernel (gemm2), tile t
-        a2, b2 = torch.empty_like(a), torch.empty_like(b)
-        R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st))
-        R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), N, K, st))
+        ld = K + PAD                                  # SWEEP_PAD: row padding (elements) of the split operands
+        a2, b2 = torch.zeros(M, ld, device="cuda"), torch.zeros(N, ld, device="cuda")
+        R.check(R.lib.rgm_split_rows_ld(R.ptr(a), K, R.ptr(a2), ld, M, K, st))
+        R.check(R.lib.rgm_split_rows_ld(R.ptr(b), K, R.ptr(b2), ld, N, K, st))
         bs = [b2] + [b2.clone() for _ in range(ncopy - 1)]
         cnt = [0]
 
         def run():
             cnt[0] += 1
-            R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(bs[cnt[0] % ncopy]), R.ptr(c), M, N, K, R.ptr(bias), ACT, tile - 100, SPLIT, st))
+            R.check(R.lib.rgm_gemm_split_ld(R.ptr(a2), ld, R.ptr(bs[cnt[0] % ncopy]), ld, R.ptr(c), N, M, N, K, R.ptr(bias), ACT,
+                                            tile - 100, SPLIT, st))
     else:
         bs = [b] + [b.clone() for _ in range(ncopy - 1)]
         cnt = [0]
