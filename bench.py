@@ -103,7 +103,7 @@ class SCGWorkload:
         self.model = build_eps_model(3, device)
         self.fn = partial(model_fn, model=self.model, num_classes=3, class_cond=True, cfg=False, w=0.)
         self.vae = AutoencoderKL()
-        self.vae.load_state_dict(synth.vae_state_dict(2, device=device))
+        self.vae.load_state_dict(synth.vae_state_dict(2, device=device), strict=False)   # decoder slice; the encoder keeps its init
         self.vae = self.vae.to(device).eval()
         self.d = make_diffusion("")
         self.d.t_end = 0

@@ -149,6 +149,10 @@ int rgm_scg_candidates(const float* mean, const float* g, const float* noise, fl
 /* _predict_xstart_from_eps (:359-364) times out_scale (the 1/scale_factor of _decode :1350). */
 int rgm_xstart_from_eps(const float* x, const float* eps, const int64_t* t, const float* const* tables_host,
                         float out_scale, float* out, int N, int E, void* stream);
+/* Replacement-based conditioning of the editing path (p_mean_variance :293-298): x0 = clip(predict_xstart(x, eps)),
+ * x0r = mask*gt + (1-mask)*x0, eps_out = predict_eps_from_xstart(x, x0r).  gt, mask (N,E) like x; eps_out may alias eps. */
+int rgm_edit_replace_eps(const float* x, const float* eps, const float* gt, const float* mask, const int64_t* t,
+                         const float* const* tables_host, int clip_denoised, float* eps_out, int N, int E, void* stream);
 /* scg_sample selection (:539-554): max_ind[b] = first argmax_k total[k][b]; out[b] = cand[max_ind[b]][b].
  * cand and out may both be NULL (index only); max_ind may be NULL. */
 int rgm_scg_select(const float* cand, const float* total_logp, float* out, int64_t* max_ind, int n, int B, int E,
@@ -162,11 +166,13 @@ typedef struct rgm_vae rgm_vae;
 int rgm_vae_create(rgm_vae** out);
 void rgm_vae_destroy(rgm_vae* h);
 /* key as in the Lightning checkpoint's ["state_dict"] ("decoder.*", "post_quant_conv.*"; klvae_pedal.py:50-59).
- * 3x3 conv weights are repacked to [cout][tap][cin] on the device.  Other prefixes (encoder., loss., quant_conv.)
- * are not part of the decode path: query with rgm_vae_has_param and skip them (strict=False semantics). */
+ * 3x3 conv weights are repacked to [cout][tap][cin] on the device.  "encoder.*" / "quant_conv.*" are optional (only
+ * rgm_vae_encode needs them); other prefixes (loss.) are not ours: query with rgm_vae_has_param and skip them
+ * (strict=False semantics). */
 int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, const int64_t* shape, int ndim);
 int rgm_vae_has_param(rgm_vae* h, const char* key);
-int rgm_vae_missing_params(rgm_vae* h);
+int rgm_vae_missing_params(rgm_vae* h);            /* decoder + post_quant_conv parameters still unset (what decode needs) */
+int rgm_vae_encoder_missing_params(rgm_vae* h);    /* encoder + quant_conv parameters still unset (what encode needs) */
 size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M /* number of 16x16 latent squares */);
 /* AutoencoderKL.decode(z): z (M,4,16,16) -> out (M,3,128,128). */
 int rgm_vae_decode(rgm_vae* h, const float* z, float* out, int M, void* ws, size_t ws_bytes, void* stream);
@@ -175,6 +181,10 @@ int rgm_vae_decode(rgm_vae* h, const float* z, float* out, int M, void* ws, size
  * truncating cast of decode_sample_for_midi (midi_util.py:59-63) (may be NULL). */
 int rgm_vae_decode_latent(rgm_vae* h, const float* latent, float inv_scale, float* roll, uint8_t* roll_u8,
                           float threshold, int N, int H, void* ws, size_t ws_bytes, void* stream);
+/* AutoencoderKL.encode_save(x, range_fix=False) (klvae_pedal.py:61-68; Encoder.forward model.py:404-433 incl. the
+ * stride-2 Downsample convs :56-75, then quant_conv): x (M,3,128,128) piano-roll tiles in [-1,1] -> moments
+ * (M,8,16,16) = mean (channels 0..3) | logvar (4..7).  Workspace as for decode with the same M. */
+int rgm_vae_encode(rgm_vae* h, const float* x, float* moments, int M, void* ws, size_t ws_bytes, void* stream);
 /* midi_util.py:59-63 on an existing roll: (B,3,128,T) float32 -> (B,128,T,3) uint8. */
 int rgm_quantise_roll(const float* roll, uint8_t* out_u8, int B, int T, float threshold, void* stream);
 

@@ -116,9 +116,17 @@ def posterior_mean(S, x0, x, t):
     return S.ex(S.posterior_mean_coef1, t) * x0 + S.ex(S.posterior_mean_coef2, t) * x
 
 
-def p_mean_variance(S, model, x, t, clip_denoised, model_kwargs):
-    """:252-357; `model(x, t_mapped, **kw)` is any callable returning eps (float32)."""
+def p_mean_variance(S, model, x, t, clip_denoised, model_kwargs, edit=None):
+    """:252-357; `model(x, t_mapped, **kw)` is any callable returning eps (float32).
+
+    edit = dict(gt, mask, l_start, l_end) is the replacement-based conditioning of scripts/edit.py (:293-298)."""
     eps = model(x, S.map_t(t), **model_kwargs).astype(F32)
+    if edit is not None:
+        x0e = xstart_from_eps(S, x, t, eps)
+        if clip_denoised:
+            x0e = np.clip(x0e, -1, 1)
+        x0e = edit["mask"] * edit["gt"] + (1 - edit["mask"]) * x0e
+        eps = eps_from_xstart(S, x, t, x0e).astype(F32)
     x0 = xstart_from_eps(S, x, t, eps)
     if clip_denoised:
         x0 = np.clip(x0, -1, 1)
@@ -141,7 +149,7 @@ def decode_latent(z, decode_fn, scale_factor):
 
 
 def scg_sample(S, model, t, mean_pred, g_coeff, decode_fn, scale_factor, model_kwargs, scg_kwargs,
-               noise, func_dict, loss_dict, wrap_t=True, return_aux=False):
+               noise, func_dict, loss_dict, wrap_t=True, return_aux=False, edit=None):
     """:491-554 (dc.base<=0 branch).  `noise` has shape (n,B,C,H,W) -- the randn_like draw of :512.
 
     wrap_t=False reproduces the p_sample quirk (model passed unwrapped).
@@ -154,6 +162,8 @@ def scg_sample(S, model, t, mean_pred, g_coeff, decode_fn, scale_factor, model_k
     y_rep = np.tile(np.asarray(model_kwargs["y"]), n)
     eps = model(cand, S.map_t(t_rep) if wrap_t else t_rep, y=y_rep).astype(F32)
     x0 = xstart_from_eps(S, cand, t_rep, eps)
+    if edit is not None:                                             # :520-522 only the editable rows are decoded
+        x0 = np.ascontiguousarray(x0[:, :, edit["l_start"]:edit["l_end"], :])
     if decode_fn is not None:
         x0 = decode_latent(x0, decode_fn, scale_factor)
     total = np.zeros(n * B, dtype=F32)
@@ -174,7 +184,7 @@ def scg_sample(S, model, t, mean_pred, g_coeff, decode_fn, scale_factor, model_k
 
 def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwargs=None,
              guidance=None, scg_kwargs=None, decode_fn=None, scale_factor=1.0, t_end=0,
-             func_dict=None, loss_dict=None, return_aux=False):
+             func_dict=None, loss_dict=None, return_aux=False, edit=None):
     """:635-735.  `guidance` = dict(schedule,t_start,t_end,interval) or None.
 
     noise: (B,...) for the plain / unguided-SCG draw, (n,B,...) for the SCG draw, None when
@@ -187,10 +197,15 @@ def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwa
             if guidance["schedule"] else True
     else:
         use_g = False
-    out = p_mean_variance(S, model, x, t, clip_denoised, model_kwargs)
+    out = p_mean_variance(S, model, x, t, clip_denoised, model_kwargs, edit=edit)
     aux = {"mean_unguided": out["mean"]}
     if cond_fn is not None and (use_g or scg_kwargs is not None):
-        grad = cond_fn(x, S.map_t(t), **model_kwargs).astype(F32)   # :404 (cond_fn is wrapped)
+        if edit is None:
+            grad = cond_fn(x, S.map_t(t), **model_kwargs).astype(F32)   # :404 (cond_fn is wrapped)
+        else:                                                        # :408-414 gradient on the editable rows only
+            ls, le = edit["l_start"], edit["l_end"]
+            grad = np.zeros_like(x)
+            grad[:, :, ls:le, :] = cond_fn(np.ascontiguousarray(x[:, :, ls:le, :]), S.map_t(t), **model_kwargs).astype(F32)
         out["mean"] = (out["mean"] + out["variance"] * grad).astype(F32)
         aux["grad"] = grad
     g = np.exp(F32(0.5) * out["log_variance"]).astype(F32)
@@ -201,7 +216,7 @@ def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwa
         if use_g:
             sample = scg_sample(S, model, t, out["mean"], g, decode_fn, scale_factor, model_kwargs,
                                 scg_kwargs, noise, func_dict, loss_dict, wrap_t=False,
-                                return_aux=return_aux)
+                                return_aux=return_aux, edit=edit)
             if return_aux:
                 sample, a2 = sample
                 aux.update(a2)
@@ -217,7 +232,7 @@ def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwa
 
 def ddim_sample(S, model, x, t, noise, eta=0.0, clip_denoised=False, cond_fn=None, model_kwargs=None,
                 guidance=None, scg_kwargs=None, decode_fn=None, scale_factor=1.0, t_end=0,
-                func_dict=None, loss_dict=None, return_aux=False):
+                func_dict=None, loss_dict=None, return_aux=False, edit=None):
     """:881-976."""
     model_kwargs = model_kwargs or {}
     t = np.asarray(t)
@@ -226,7 +241,7 @@ def ddim_sample(S, model, x, t, noise, eta=0.0, clip_denoised=False, cond_fn=Non
             if guidance["schedule"] else True
     else:
         use_g = False
-    out = p_mean_variance(S, model, x, t, clip_denoised, model_kwargs)
+    out = p_mean_variance(S, model, x, t, clip_denoised, model_kwargs, edit=edit)
     if cond_fn is not None and use_g:                                # condition_score :467-489
         ab = S.ex(S.alphas_cumprod, t)
         eps = eps_from_xstart(S, x, t, out["pred_xstart"])
@@ -246,7 +261,7 @@ def ddim_sample(S, model, x, t, noise, eta=0.0, clip_denoised=False, cond_fn=Non
         if use_g:
             sample = scg_sample(S, model, t, mean_pred, sigma, decode_fn, scale_factor, model_kwargs,
                                 scg_kwargs, noise, func_dict, loss_dict, wrap_t=True,
-                                return_aux=return_aux)
+                                return_aux=return_aux, edit=edit)
             if return_aux:
                 sample, a2 = sample
                 aux.update(a2)

@@ -8,6 +8,10 @@ Test infrastructure (see oracle/__init__.py).  Restates:
   taming/modules/diffusionmodules/model.py:168-192       AttnBlock.forward
   taming/modules/diffusionmodules/model.py:506-537       Decoder.forward
   guided_diffusion/midi_util.py:42-64                    decode_sample_for_midi (uint8 quantisation)
+  taming/modules/diffusionmodules/model.py:56-75         Downsample (zero pad (0,1,0,1) + conv3x3 stride 2)
+  taming/modules/diffusionmodules/model.py:404-433       Encoder.forward
+  taming/models/klvae_pedal.py:61-68                     AutoencoderKL.encode_save (encoder -> quant_conv)
+  guided_diffusion/gaussian_diffusion.py:1382-1395       _encode (tile the roll, keep the posterior mean, scale)
 Weights: dict keyed like the Lightning checkpoint's ["state_dict"] ("decoder.*", "post_quant_conv.*").
 Config (taming-transformers/configs/pr/kl/f8-all-onset.yaml): ch=128, ch_mult=(1,2,2,4),
 num_res_blocks=2, attn_resolutions=[], z_channels=4, out_ch=3, resolution=128.
@@ -87,6 +91,48 @@ def decode(sd, z, ch_mult=(1, 2, 2, 4), num_res_blocks=2):
             h = conv2d(upsample_nearest2(h), sd[f"{d}up.{lvl}.upsample.conv.weight"], sd[f"{d}up.{lvl}.upsample.conv.bias"], 1)
     h = swish(groupnorm(h, sd[d + "norm_out.weight"], sd[d + "norm_out.bias"]))
     return conv2d(h, sd[d + "conv_out.weight"], sd[d + "conv_out.bias"], 1)
+
+
+def downsample_conv(x, w, b):
+    """Downsample.forward with_conv: pad right/bottom by one zero, 3x3 conv with stride 2, no further padding."""
+    m, cin, h, wd = x.shape
+    cout = w.shape[0]
+    xh = np.pad(np.ascontiguousarray(x.transpose(0, 2, 3, 1)), ((0, 0), (0, 1), (0, 1), (0, 0)))
+    ho, wo = h // 2, wd // 2
+    out = np.zeros((m * ho * wo, cout), dtype=F32)
+    for ky in range(3):
+        for kx in range(3):
+            tap = np.ascontiguousarray(xh[:, ky:ky + 2 * ho:2, kx:kx + 2 * wo:2, :]).reshape(-1, cin)
+            out += tap @ np.ascontiguousarray(w[:, :, ky, kx].T)
+    out += b
+    return np.ascontiguousarray(out.reshape(m, ho, wo, cout).transpose(0, 3, 1, 2))
+
+
+def encode_moments(sd, x, ch_mult=(1, 2, 2, 4), num_res_blocks=2):
+    """AutoencoderKL.encode_save(x, range_fix=False): x (M,3,128,128) -> moments (M,8,16,16) = mean | logvar."""
+    e = "encoder."
+    h = conv2d(x.astype(F32), sd[e + "conv_in.weight"], sd[e + "conv_in.bias"], 1)
+    for lvl in range(len(ch_mult)):
+        for ib in range(num_res_blocks):
+            h = resnet_block(h, sd, f"{e}down.{lvl}.block.{ib}.")
+        if lvl != len(ch_mult) - 1:
+            h = downsample_conv(h, sd[f"{e}down.{lvl}.downsample.conv.weight"], sd[f"{e}down.{lvl}.downsample.conv.bias"])
+    h = resnet_block(h, sd, e + "mid.block_1.")
+    h = attn_block(h, sd, e + "mid.attn_1.")
+    h = resnet_block(h, sd, e + "mid.block_2.")
+    h = swish(groupnorm(h, sd[e + "norm_out.weight"], sd[e + "norm_out.bias"]))
+    h = conv2d(h, sd[e + "conv_out.weight"], sd[e + "conv_out.bias"], 1)
+    return conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"], 0)
+
+
+def encode_latent(sd, roll, scale_factor=1.0):
+    """_encode: roll (B,3,128,128k) -> latent (B,4,16k,16) * scale_factor."""
+    b, _, h, w = roll.shape
+    k = w // h
+    micro = np.concatenate(np.split(roll, k, axis=-1), axis=0)
+    z = encode_moments(sd, micro)[:, :4]
+    z = np.concatenate(np.split(z, k, axis=0), axis=-1)
+    return (z.transpose(0, 1, 3, 2) * F32(scale_factor)).astype(F32)
 
 
 def quantise_roll(roll, threshold=-0.95):

@@ -101,7 +101,8 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
       const int img = row >> (p.logH + p.logW);
       a_y[i] = (row >> p.logW) & (p.H - 1);
       a_x[i] = row & (p.W - 1);
-      a_off[i] = (long long)img * (p.H >> p.ups) * (p.W >> p.ups) * p.Cin + slot * 4;
+      // input plane: (H >> ups) x (W >> ups) for the (up)convolutions, 2H x 2W for the stride-2 downsample (ups == -1)
+      a_off[i] = (p.ups < 0 ? (long long)img * (2 * p.H) * (2 * p.W) : (long long)img * (p.H >> p.ups) * (p.W >> p.ups)) * p.Cin + slot * 4;
     }
   }
   long long b_off[PB];
@@ -123,14 +124,26 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
     } else {
       const int tap = kt / cpt;
       const int c0 = (kt - tap * cpt) << 5;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int Win = p.W >> p.ups;
+      if (p.ups >= 0) {   // 3x3, pad 1, optionally on the nearest-x2 upsampled input (taming Upsample, model.py:38-53)
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int Win = p.W >> p.ups;
 #pragma unroll
-      for (int i = 0; i < PA; ++i) {
-        const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-        const bool ok = a_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        const long long off = a_off[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin + c0;
-        ra[i] = ok ? *reinterpret_cast<const float4*>(Ab + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < PA; ++i) {
+          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+          const bool ok = a_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          const long long off = a_off[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin + c0;
+          ra[i] = ok ? *reinterpret_cast<const float4*>(Ab + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else {            // 3x3, stride 2, zero pad (0,1,0,1) on a 2H x 2W input (taming Downsample, model.py:56-75)
+        const int dy = tap / 3, dx = tap - (tap / 3) * 3;
+        const int Hin = 2 * p.H, Win = 2 * p.W;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+          const int yy = 2 * a_y[i] + dy, xx = 2 * a_x[i] + dx;
+          const bool ok = a_ok[i] && yy < Hin && xx < Win;
+          const long long off = a_off[i] + ((long long)yy * Win + xx) * p.Cin + c0;
+          ra[i] = ok ? *reinterpret_cast<const float4*>(Ab + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
       }
     }
 #pragma unroll

@@ -149,6 +149,23 @@ __global__ void xstart_from_eps_kernel(const float* __restrict__ x, const float*
   out[i] = (tb.sqrt_recip_ac[ti] * x[i] - tb.sqrt_recipm1_ac[ti] * eps[i]) * out_scale;
 }
 
+// Replacement-based conditioning of scripts/edit.py (p_mean_variance :293-298): the x0 estimate is overwritten by the
+// ground-truth latent where mask == 1 and the eps estimate recomputed from it:
+//   x0 = clip(c1*x - c2*eps);  x0r = mask*gt + (1-mask)*x0;  eps' = (c1*x - x0r) / c2
+__global__ void edit_replace_eps_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ gt,
+                                        const float* __restrict__ mask, const int64_t* __restrict__ t, StepTables tb, int clip,
+                                        float* __restrict__ out, long long total, int E) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int ti = (int)t[i / E];
+  const float c1 = tb.sqrt_recip_ac[ti], c2 = tb.sqrt_recipm1_ac[ti];
+  float x0 = c1 * x[i] - c2 * eps[i];
+  if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+  const float m = mask[i];
+  const float x0r = m * gt[i] + (1.f - m) * x0;
+  out[i] = (c1 * x[i] - x0r) / c2;
+}
+
 // max_ind[b] = first argmax_k total[k][b] ; out[b][:] = cand[max_ind[b]][b][:]   (:539-554)
 __global__ void scg_select_kernel(const float* __restrict__ cand, const float* __restrict__ total, float* __restrict__ out,
                                   int64_t* __restrict__ max_ind, int n, int B, int E) {
@@ -233,6 +250,16 @@ extern "C" int rgm_xstart_from_eps(const float* x, const float* eps, const int64
   const long long total = (long long)N * E;
   hipLaunchKernelGGL(xstart_from_eps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, t,
                      make_tables(tables), out_scale, out, total, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_edit_replace_eps(const float* x, const float* eps, const float* gt, const float* mask, const int64_t* t,
+                                    const float* const* tables, int clip_denoised, float* eps_out, int N, int E, void* stream) {
+  RGM_REQUIRE(x && eps && gt && mask && t && tables && eps_out && N > 0 && E > 0, "edit_replace_eps: bad arguments");
+  const long long total = (long long)N * E;
+  hipLaunchKernelGGL(edit_replace_eps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, gt, mask,
+                     t, make_tables(tables), clip_denoised, eps_out, total, E);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

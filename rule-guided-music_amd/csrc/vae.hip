@@ -63,6 +63,42 @@ __global__ void vae_conv_in_kernel(const float* __restrict__ pq, const float* __
   out[idx] = acc;
 }
 
+// Encoder conv_in 3x3 (3 -> Cout, pad 1) on 128x128 piano-roll tiles (taming Encoder.conv_in, model.py:357-361):
+// x NCHW (M,3,128,128), weights in their checkpoint layout [Cout][3][3][3], out NHWC [M][128][128][Cout]
+__global__ void vae_enc_conv_in_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                       float* __restrict__ out, int M, int Cout) {
+  const long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x;  // over M*16384*Cout, co fastest
+  if (idx >= (long long)M * 16384 * Cout) return;
+  const int co = (int)(idx % Cout);
+  const long long pix = idx / Cout;
+  const int m = (int)(pix >> 14), y = (int)((pix >> 7) & 127), xx0 = (int)(pix & 127);
+  float acc = b[co];
+  const float* wc = w + (long long)co * 27;
+#pragma unroll
+  for (int ci = 0; ci < 3; ++ci) {
+    const float* plane = x + ((long long)m * 3 + ci) * 16384;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int yy = y + tap / 3 - 1, xx = xx0 + tap % 3 - 1;
+      if ((unsigned)yy < 128u && (unsigned)xx < 128u) acc = fmaf(plane[(yy << 7) + xx], wc[ci * 9 + tap], acc);
+    }
+  }
+  out[idx] = acc;
+}
+
+// quant_conv 1x1 (8 -> 8) on the encoder output (klvae_pedal.py:61-63): h NHWC rows [M*256][8] -> moments NCHW (M,8,16,16)
+__global__ void vae_enc_quant_kernel(const float* __restrict__ h8, const float* __restrict__ w, const float* __restrict__ b,
+                                     float* __restrict__ out, int M) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over M*8*256, pixel fastest
+  if (idx >= M * 8 * 256) return;
+  const int pix = idx & 255, co = (idx >> 8) & 7, m = idx >> 11;
+  const float* r = h8 + ((long long)m * 256 + pix) * 8;
+  float acc = b[co];
+#pragma unroll
+  for (int ci = 0; ci < 8; ++ci) acc = fmaf(r[ci], w[co * 8 + ci], acc);
+  out[idx] = acc;
+}
+
 // GroupNorm partial sums in fp64: grid (chunks, M); x NHWC [M][P][C]; part[m][chunk][32][2]
 __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ part, int P, int C,
                                                          int chunks) {
@@ -242,6 +278,7 @@ struct VSlot {
   int conv3 = 0;  // 1: repack [co][ci][3][3] -> [co][9][ci]
   int cout = 0, cin = 0;
   bool derived = false;  // "<key>.S": split-row copy of a 3x3 weight for the pre-split conv GEMM (gemm2.hip), not a parameter
+  int group = 0;         // 0: decoder + post_quant_conv (needed by decode), 1: encoder + quant_conv (needed by encode)
 };
 
 struct rgm_vae {
@@ -251,6 +288,7 @@ struct rgm_vae {
   float* stage = nullptr;  // staging for repack
   size_t stage_floats = 0;
   int ch = 128;
+  int cur_group = 0;       // group given to the slots being registered
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
 };
 
@@ -261,10 +299,11 @@ static void vslot(rgm_vae* h, const std::string& key, size_t numel, int conv3 = 
   s.conv3 = conv3;
   s.cout = cout;
   s.cin = cin;
+  s.group = h->cur_group;
   h->slots[key] = s;
   h->arena_floats += (numel + 3) / 4 * 4;
   if (numel > h->stage_floats) h->stage_floats = numel;
-  if (conv3 && cin % 32 == 0) {
+  if (conv3 && cin % 32 == 0 && h->cur_group == 0) {   // the encoder convs stay on the on-the-fly kernel
     VSlot d;
     d.off = h->arena_floats;
     d.numel = numel;
@@ -325,6 +364,39 @@ extern "C" int rgm_vae_create(rgm_vae** out) {
   vslot(h, d + "norm_out.bias", bi);
   vslot(h, d + "conv_out.weight", (size_t)3 * bi * 9, 1, 3, bi);
   vslot(h, d + "conv_out.bias", 3);
+  {  // Encoder + quant_conv (taming Encoder, model.py:342-433; klvae_pedal.py:30-31): optional, used by rgm_vae_encode
+    h->cur_group = 1;
+    const std::string e = "encoder.";
+    vslot(h, e + "conv_in.weight", (size_t)ch * 3 * 9);
+    vslot(h, e + "conv_in.bias", ch);
+    int ei = ch;
+    for (int lvl = 0; lvl < 4; ++lvl) {
+      const int eo = ch * CH_MULT[lvl];
+      for (int ib = 0; ib < 2; ++ib) {
+        res_slots(h, e + "down." + std::to_string(lvl) + ".block." + std::to_string(ib) + ".", ei, eo);
+        ei = eo;
+      }
+      if (lvl != 3) {
+        vslot(h, e + "down." + std::to_string(lvl) + ".downsample.conv.weight", (size_t)ei * ei * 9, 1, ei, ei);
+        vslot(h, e + "down." + std::to_string(lvl) + ".downsample.conv.bias", ei);
+      }
+    }
+    res_slots(h, e + "mid.block_1.", ei, ei);
+    vslot(h, e + "mid.attn_1.norm.weight", ei);
+    vslot(h, e + "mid.attn_1.norm.bias", ei);
+    for (const char* nm : {"q", "k", "v", "proj_out"}) {
+      vslot(h, e + "mid.attn_1." + nm + ".weight", (size_t)ei * ei);
+      vslot(h, e + "mid.attn_1." + nm + ".bias", ei);
+    }
+    res_slots(h, e + "mid.block_2.", ei, ei);
+    vslot(h, e + "norm_out.weight", ei);
+    vslot(h, e + "norm_out.bias", ei);
+    vslot(h, e + "conv_out.weight", (size_t)8 * ei * 9, 1, 8, ei);
+    vslot(h, e + "conv_out.bias", 8);
+    vslot(h, "quant_conv.weight", 64);
+    vslot(h, "quant_conv.bias", 8);
+    h->cur_group = 0;
+  }
   RGM_CHECK_HIP(hipMalloc(&h->arena, h->arena_floats * sizeof(float)));
   RGM_CHECK_HIP(hipMalloc(&h->stage, h->stage_floats * sizeof(float)));
   *out = h;
@@ -370,7 +442,14 @@ extern "C" int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, 
 extern "C" int rgm_vae_missing_params(rgm_vae* h) {
   if (!h) return -1;
   int n = 0;
-  for (auto& kv : h->slots) n += kv.second.set ? 0 : 1;
+  for (auto& kv : h->slots) n += (kv.second.set || kv.second.group != 0) ? 0 : 1;   // what decode needs
+  return n;
+}
+
+extern "C" int rgm_vae_encoder_missing_params(rgm_vae* h) {
+  if (!h) return -1;
+  int n = 0;
+  for (auto& kv : h->slots) n += (kv.second.set || kv.second.group != 1) ? 0 : 1;   // what encode needs
   return n;
 }
 
@@ -470,6 +549,29 @@ int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout
   }
   return RGM_OK;
 }
+
+// AttnBlock (taming model.py:140-192) on the 256 tokens of a 16x16 map, single head of width C: cur <- cur + proj(attn(norm(cur)))
+int attn_block(Ctx& c, float* cur, float* t1, const std::string& a, int C) {
+  const int M = c.M, rows = M * 256;
+  hipStream_t s = c.s;
+  RGM_TRY(group_norm(c, cur, t1, 256, C, a + "norm", 0));
+  RGM_TRY(conv1(c, t1, c.p.q, rows, C, C, a + "q", nullptr));
+  RGM_TRY(conv1(c, t1, c.p.k, rows, C, C, a + "k", nullptr));
+  RGM_TRY(conv1(c, t1, c.p.v, rows, C, C, a + "v", nullptr));
+  GemmParams g;  // scores[m] = q[m] . k[m]^T * C^-0.5
+  g.A = c.p.q; g.lda = C; g.sA = 256LL * C; g.B = c.p.k; g.ldb = C; g.sB = 256LL * C;
+  g.C = c.p.sc; g.ldc = 256; g.sC = 256LL * 256; g.M = 256; g.N = 256; g.K = C; g.batch = M;
+  g.alpha = 1.0f / sqrtf((float)C);
+  RGM_TRY(gemm_launch(g, s));
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, c.p.sc, rows, 256);
+  RGM_LAUNCH_CHECK();
+  RGM_TRY(transpose_launch(c.p.v, c.p.vt, 256, C, 256, M, s));
+  GemmParams o;  // o[m] = p[m] . v[m]  (B^T form: vt[m] is [C][256])
+  o.A = c.p.sc; o.lda = 256; o.sA = 256LL * 256; o.B = c.p.vt; o.ldb = 256; o.sB = 256LL * C;
+  o.C = t1; o.ldc = C; o.sC = 256LL * C; o.M = 256; o.N = C; o.K = 256; o.batch = M;
+  RGM_TRY(gemm_launch(o, s));
+  return conv1(c, t1, cur, rows, C, C, a + "proj_out", cur);  // x + proj_out(o), in place
+}
 }  // namespace
 
 extern "C" size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M) {
@@ -485,7 +587,7 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
   if (rgm_vae_missing_params(h) != 0) {
     std::string miss;
     for (auto& kv : h->slots)
-      if (!kv.second.set && miss.size() < 200) miss += kv.first + " ";
+      if (!kv.second.set && kv.second.group == 0 && miss.size() < 200) miss += kv.first + " ";
     set_error("vae_decode: %d parameters not set: %s", rgm_vae_missing_params(h), miss.c_str());
     return RGM_ERR_STATE;
   }
@@ -508,27 +610,7 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
     RGM_LAUNCH_CHECK();
   }
   RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, d + "mid.block_1."));
-  {  // AttnBlock on 256 tokens, single head of width 512
-    const std::string a = d + "mid.attn_1.";
-    const int rows = M * 256;
-    RGM_TRY(group_norm(c, cur, t1, 256, C, a + "norm", 0));
-    RGM_TRY(conv1(c, t1, c.p.q, rows, C, C, a + "q", nullptr));
-    RGM_TRY(conv1(c, t1, c.p.k, rows, C, C, a + "k", nullptr));
-    RGM_TRY(conv1(c, t1, c.p.v, rows, C, C, a + "v", nullptr));
-    GemmParams g;  // scores[m] = q[m] . k[m]^T * C^-0.5
-    g.A = c.p.q; g.lda = C; g.sA = 256LL * C; g.B = c.p.k; g.ldb = C; g.sB = 256LL * C;
-    g.C = c.p.sc; g.ldc = 256; g.sC = 256LL * 256; g.M = 256; g.N = 256; g.K = C; g.batch = M;
-    g.alpha = 1.0f / sqrtf((float)C);
-    RGM_TRY(gemm_launch(g, s));
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, c.p.sc, rows, 256);
-    RGM_LAUNCH_CHECK();
-    RGM_TRY(transpose_launch(c.p.v, c.p.vt, 256, C, 256, M, s));
-    GemmParams o;  // o[m] = p[m] . v[m]  (B^T form: vt[m] is [C][256])
-    o.A = c.p.sc; o.lda = 256; o.sA = 256LL * 256; o.B = c.p.vt; o.ldb = 256; o.sB = 256LL * C;
-    o.C = t1; o.ldc = C; o.sC = 256LL * C; o.M = 256; o.N = C; o.K = 256; o.batch = M;
-    RGM_TRY(gemm_launch(o, s));
-    RGM_TRY(conv1(c, t1, cur, rows, C, C, a + "proj_out", cur));  // x + proj_out(o), in place
-  }
+  RGM_TRY(attn_block(c, cur, t1, d + "mid.attn_1.", C));
   RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, d + "mid.block_2."));
   int H = 16;
   for (int lvl = 3; lvl >= 0; --lvl) {
@@ -572,6 +654,55 @@ extern "C" int rgm_quantise_roll(const float* roll, uint8_t* out_u8, int B, int 
   RGM_REQUIRE(roll && out_u8 && B > 0 && T > 0, "quantise_roll: bad arguments");
   const long long total = (long long)B * 128 * T * 3;
   hipLaunchKernelGGL(quantise_roll_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, roll, out_u8, B, T, threshold);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// Encoder forward (taming Encoder.forward, model.py:404-433, + quant_conv): x (M,3,128,128) -> moments (M,8,16,16)
+// (mean = channels 0..3, logvar = 4..7; AutoencoderKL.encode_save, klvae_pedal.py:61-68 with range_fix=False).
+extern "C" int rgm_vae_encode(rgm_vae* h, const float* x, float* moments, int M, void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && x && moments && M > 0, "vae_encode: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  if (rgm_vae_encoder_missing_params(h) != 0) {
+    std::string miss;
+    for (auto& kv : h->slots)
+      if (!kv.second.set && kv.second.group == 1 && miss.size() < 200) miss += kv.first + " ";
+    set_error("vae_encode: %d encoder parameters not set: %s", rgm_vae_encoder_missing_params(h), miss.c_str());
+    return RGM_ERR_STATE;
+  }
+  Ctx c{h, vplan(M, ws), M, s, 0};
+  if (!ws || c.p.bytes > ws_bytes) {
+    set_error("vae_encode: workspace %zu bytes < required %zu", ws_bytes, c.p.bytes);
+    return RGM_ERR_WORKSPACE;
+  }
+  const std::string e = "encoder.";
+  float *cur = c.p.b0, *t1 = c.p.b1, *t2 = c.p.b2;
+  int C = h->ch, H = 128;
+  {
+    const long long tot = (long long)M * 16384 * C;
+    hipLaunchKernelGGL(vae_enc_conv_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, x, h->p(e + "conv_in.weight"),
+                       h->p(e + "conv_in.bias"), cur, M, C);
+    RGM_LAUNCH_CHECK();
+  }
+  for (int lvl = 0; lvl < 4; ++lvl) {
+    const int eo = h->ch * CH_MULT[lvl];
+    for (int ib = 0; ib < 2; ++ib) {
+      RGM_TRY(resnet(c, cur, t1, t2, H, C, eo, e + "down." + std::to_string(lvl) + ".block." + std::to_string(ib) + "."));
+      C = eo;
+    }
+    if (lvl != 3) {   // Downsample: zero pad (0,1,0,1) + 3x3 stride 2 (model.py:56-75) = the ups == -1 loader of gemm.hip
+      H /= 2;
+      RGM_TRY(conv3(c, cur, t1, H, C, C, e + "down." + std::to_string(lvl) + ".downsample.conv", -1, nullptr));
+      std::swap(cur, t1);
+    }
+  }
+  RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, e + "mid.block_1."));
+  RGM_TRY(attn_block(c, cur, t1, e + "mid.attn_1.", C));
+  RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, e + "mid.block_2."));
+  RGM_TRY(group_norm(c, cur, t1, 256, C, e + "norm_out", 1));
+  RGM_TRY(conv3(c, t1, t2, 16, C, 8, e + "conv_out", 0, nullptr));          // [M*256][8]
+  hipLaunchKernelGGL(vae_enc_quant_kernel, dim3(cdiv(M * 8 * 256, 256)), dim3(256), 0, s, t2, h->p("quant_conv.weight"),
+                     h->p("quant_conv.bias"), moments, M);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

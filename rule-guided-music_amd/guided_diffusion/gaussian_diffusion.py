@@ -19,7 +19,7 @@ What is different underneath (design, not a translation):
     all-gather of the (n, B) rule log-probabilities per step, winners regenerated locally from the
     shared Philox counters -- see scg_shard / SURVEY 8e.
 
-Not implemented here (SURVEY 8f "next"): DPS guidance (guidance.method == 'dps'), edit_kwargs,
+Not implemented here (SURVEY 8f "next"): DPS guidance (guidance.method == 'dps'),
 learned variances, training losses.  They raise NotImplementedError instead of silently degrading.
 """
 import ctypes as C
@@ -227,6 +227,31 @@ class GaussianDiffusion:
         return ((self._per_sample(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - pred_xstart)
                 / self._per_sample(self.sqrt_recipm1_alphas_cumprod, t, x_t))
 
+    def _edit_eps(self, x, eps, t, clip_denoised, edit_kwargs):
+        """Replacement-based conditioning of scripts/edit.py (reference p_mean_variance :293-298): where mask == 1 the
+        x0 estimate is the ground-truth latent; returns the eps estimate consistent with that x0."""
+        _rgm.require_cuda(x, eps, t)
+        x, eps = x.float().contiguous(), eps.float().contiguous()
+        gt = edit_kwargs["gt"].to(x.device, th.float32).expand_as(x).contiguous()
+        mask = edit_kwargs["mask"].to(x.device, th.float32).expand_as(x).contiguous()
+        out = th.empty_like(eps)
+        N = x.shape[0]
+        with th.cuda.device(x.device):
+            _rgm.check(_rgm.lib.rgm_edit_replace_eps(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(gt), _rgm.ptr(mask),
+                                                     _rgm.ptr(t.long().contiguous()), self._tab(x.device).ptrs,
+                                                     int(bool(clip_denoised)), _rgm.ptr(out), N, x.numel() // N,
+                                                     _rgm.current_stream()))
+        return out
+
+    @staticmethod
+    def _edit_grad(cond_fn, x, ts, model_kwargs, edit_kwargs):
+        """Classifier gradient on the editable latent rows only (reference condition_mean :408-414), zero elsewhere."""
+        ls, le = int(edit_kwargs["l_start"]), int(edit_kwargs["l_end"])
+        g = cond_fn(x[:, :, ls:le, :].contiguous(), ts, **model_kwargs)
+        full = th.zeros_like(x, dtype=th.float32)
+        full[:, :, ls:le, :] = g.float()
+        return full
+
     # ------------------------------------------------------------------ one fused step
     def _step(self, kind, x, eps, grad, noise, t, clip_denoised, eta=0.0, want_g=False):
         """kind 'ddpm' | 'ddim'.  Returns (sample_or_mean, pred_xstart, g or None)."""
@@ -258,8 +283,8 @@ class GaussianDiffusion:
     def _reject_unsupported(denoised_fn, edit_kwargs, guidance_kwargs=None):
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn is not supported by the fused native step")
-        if edit_kwargs is not None:
-            raise NotImplementedError("edit_kwargs (scripts/edit.py path) is a 'next' row: SURVEY 8f.2")
+        if edit_kwargs is not None and guidance_kwargs is not None and getattr(guidance_kwargs, "method", None) == "dps":
+            raise NotImplementedError("DPS guidance needs the eps-network backward: 'next' row SURVEY 8f.1")
         if guidance_kwargs is not None and getattr(guidance_kwargs, "method", None) == "dps":
             raise NotImplementedError("DPS guidance needs the eps-network backward: 'next' row SURVEY 8f.1")
 
@@ -270,6 +295,8 @@ class GaussianDiffusion:
         model_kwargs = model_kwargs or {}
         assert t.shape == (x.shape[0],)
         eps = model(x, self._scale_timesteps(t), **model_kwargs)
+        if edit_kwargs is not None:
+            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         mean, x0, _ = self._step("ddpm", x, eps, None, None, t, clip_denoised)
         return {"mean": mean, "variance": self._per_sample(self._model_variance, t, x),
                 "log_variance": self._per_sample(self._model_log_variance, t, x), "pred_xstart": x0, "eps": eps}
@@ -278,7 +305,10 @@ class GaussianDiffusion:
                        embed_model=None, edit_kwargs=None, scale_factor=1., record=False):
         """Classifier guidance on the mean: mean + variance * grad log p(y|x_t)   (non-DPS branch)."""
         self._reject_unsupported(None, edit_kwargs, guidance_kwargs)
-        grad = cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        if edit_kwargs is None:
+            grad = cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
+        else:
+            grad = self._edit_grad(cond_fn, x, self._scale_timesteps(t), model_kwargs or {}, edit_kwargs)
         return p_mean_var["mean"].float() + p_mean_var["variance"] * grad.float()
 
     def condition_score(self, cond_fn, p_mean_var, x, t, model_kwargs=None):
@@ -330,6 +360,8 @@ class GaussianDiffusion:
         t_rep = t.repeat(nl)
         eps = model(cand, self._scale_timesteps(t_rep), y=model_kwargs["y"].repeat(nl))
         x0 = self._predict_xstart_from_eps(cand, t_rep, eps)
+        if edit_kwargs is not None:                                          # only the editable rows are decoded and scored
+            x0 = x0[:, :, int(edit_kwargs["l_start"]):int(edit_kwargs["l_end"]), :].contiguous()
         if embed_model is not None:
             x0 = _decode(x0, embed_model, scale_factor=scale_factor)
         if dc_kwargs is not None and getattr(dc_kwargs, "base", 0) > 0:
@@ -430,9 +462,14 @@ class GaussianDiffusion:
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
         eps = self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs)
+        if edit_kwargs is not None:
+            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         grad = None
         if cond_fn is not None and (use_guidance or scg_kwargs is not None):
-            grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
+            if edit_kwargs is None:
+                grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
+            else:
+                grad = self._edit_grad(self._wrap_model(cond_fn), x, self._scale_timesteps(t), model_kwargs, edit_kwargs)
         if scg_kwargs is None:
             sample, x0, _ = self._step("ddpm", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised)
         elif self._t0(t) > self.t_end:
@@ -458,6 +495,8 @@ class GaussianDiffusion:
         use_guidance = self._use_guidance(guidance_kwargs, t)
         wrapped = self._wrap_model(model)
         eps = wrapped(x, self._scale_timesteps(t), **model_kwargs)
+        if edit_kwargs is not None:
+            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         grad = None
         if cond_fn is not None and use_guidance:
             grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
@@ -492,10 +531,18 @@ class GaussianDiffusion:
         if device is None:
             device = next(model.parameters()).device
         assert isinstance(shape, (tuple, list))
-        img = noise if noise is not None else self._draw(shape, device)
+        if noise is not None:
+            img = noise
+        elif edit_kwargs is not None:   # start from the ground truth noised to `noise_level` (reference :841-844)
+            ac = float(self.alphas_cumprod[int(edit_kwargs["noise_level"]) - 1])
+            img = (ac ** 0.5) * edit_kwargs["gt"].to(device, th.float32) + ((1.0 - ac) ** 0.5) * self._draw(shape, device)
+        else:
+            img = self._draw(shape, device)
         indices = list(range(self.num_timesteps))[::-1]
         if t_end:
             indices = indices[:-t_end]
+        if edit_kwargs is not None:
+            indices = indices[self.num_timesteps - int(edit_kwargs["noise_level"]):]
         if progress:
             from tqdm.auto import tqdm
             indices = tqdm(indices)
@@ -602,7 +649,15 @@ def _extract_rule(rule_name, pred_xstart):
 
 
 def _encode(pred_xstart, embed_model, scale_factor=1.):
-    raise NotImplementedError("VAE encoder path (editing / dataset targets) is a 'next' row: SURVEY 8f.2")
+    """Piano roll (B,3,128,128k) in [-1,1] -> latent (B,4,16k,16) * scale_factor (reference :1382-1395): the roll is cut
+    into k tiles of 128 frames, each goes through the VAE encoder, the posterior mean is kept."""
+    h, w = pred_xstart.shape[-2], pred_xstart.shape[-1]
+    seq_len = w // h
+    micro = th.concat(th.chunk(pred_xstart, seq_len, dim=-1), dim=0)     # 1st second for all batch, 2nd second for all batch, ...
+    micro = embed_model.encode_save(micro, range_fix=False)
+    z = th.chunk(micro, 2, dim=1)[0] if micro.shape[1] == 8 else micro
+    z = th.concat(th.chunk(z, seq_len, dim=0), dim=-1)
+    return z.permute(0, 1, 3, 2) * scale_factor
 
 
 def guide_schedule(t, t_start=750, t_end=0, interval=1):

@@ -59,7 +59,28 @@ def decode_sample_for_midi(sample, embed_model=None, scale_factor=1., threshold=
     return out
 
 
+# note-density class boundaries / centres used to shift an extracted density by whole classes (reference midi_util.py:20-23)
+VERTICAL_ND_BOUNDS = [1.29, 2.7578125, 3.61, 4.4921875, 5.28125, 6.1171875, 7.22]
+VERTICAL_ND_CENTER = [0.56, 2.0239, 3.1839, 4.0511, 4.8867, 5.6992, 6.6686, 7.77]
+HORIZONTAL_ND_BOUNDS = [1.8, 2.6, 3.2, 3.6, 4.4, 4.8, 5.8]
+HORIZONTAL_ND_CENTER = [1.4, 2.2000, 2.9, 3.4, 4.0, 4.6, 5.3, 6.3]
+
 _MIDI_WRITER = None
+_MIDI_READER = None
+
+
+def register_midi_reader(fn):
+    """fn(path, fs) -> piano roll (3,128,T) with values in [0,127] (the reference: pretty_midi + get_full_piano_roll,
+    scripts/edit.py:170-171) -- plug in a MIDI reader for the editing CLI."""
+    global _MIDI_READER
+    _MIDI_READER = fn
+
+
+def read_midi_piano_roll(path, fs=100):
+    if _MIDI_READER is None:
+        raise RuntimeError("no MIDI reader registered (guided_diffusion.midi_util.register_midi_reader); "
+                           "pretty_midi is not vendored -- or pass a .npy piano roll")
+    return np.asarray(_MIDI_READER(path, fs), dtype=np.float32)
 
 
 def register_midi_writer(fn):

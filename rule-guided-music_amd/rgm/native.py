@@ -40,12 +40,15 @@ def _load():
         "rgm_ddim_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, i32, vp]),
         "rgm_scg_candidates": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_xstart_from_eps": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, i32, vp]),
+        "rgm_edit_replace_eps": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
         "rgm_scg_select": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_vae_create": (C.c_int, [C.POINTER(vp)]),
         "rgm_vae_destroy": (None, [vp]),
         "rgm_vae_set_param": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]),
         "rgm_vae_has_param": (C.c_int, [vp, C.c_char_p]),
         "rgm_vae_missing_params": (C.c_int, [vp]),
+        "rgm_vae_encoder_missing_params": (C.c_int, [vp]),
+        "rgm_vae_encode": (C.c_int, [vp, vp, vp, i32, vp, sz, vp]),
         "rgm_vae_workspace_bytes": (sz, [vp, i32]),
         "rgm_vae_decode": (C.c_int, [vp, vp, vp, i32, vp, sz, vp]),
         "rgm_vae_decode_latent": (C.c_int, [vp, vp, f32, vp, vp, f32, i32, i32, vp, sz, vp]),

@@ -174,9 +174,44 @@ def vae_decoder_param_shapes(ch=128, ch_mult=(1, 2, 2, 4), num_res_blocks=2, z_c
     return s
 
 
-def vae_state_dict(seed, device=None, **arch):
+def vae_encoder_param_shapes(ch=128, ch_mult=(1, 2, 2, 4), num_res_blocks=2, z_ch=4, in_ch=3, embed_dim=4):
+    """(key, shape) list of the checkpoint slice AutoencoderKL.encode reads (taming Encoder, model.py:342-402, + quant_conv)."""
+    e = "encoder."
+    s = [(e + "conv_in.weight", (ch, in_ch, 3, 3)), (e + "conv_in.bias", (ch,))]
+
+    def res(p, cin, cout):
+        r = [(p + "norm1.weight", (cin,)), (p + "norm1.bias", (cin,)),
+             (p + "conv1.weight", (cout, cin, 3, 3)), (p + "conv1.bias", (cout,)),
+             (p + "norm2.weight", (cout,)), (p + "norm2.bias", (cout,)),
+             (p + "conv2.weight", (cout, cout, 3, 3)), (p + "conv2.bias", (cout,))]
+        if cin != cout:
+            r += [(p + "nin_shortcut.weight", (cout, cin, 1, 1)), (p + "nin_shortcut.bias", (cout,))]
+        return r
+
+    bi = ch
+    for lvl in range(len(ch_mult)):
+        bo = ch * ch_mult[lvl]
+        for ib in range(num_res_blocks):
+            s += res(f"{e}down.{lvl}.block.{ib}.", bi, bo)
+            bi = bo
+        if lvl != len(ch_mult) - 1:
+            s += [(f"{e}down.{lvl}.downsample.conv.weight", (bi, bi, 3, 3)), (f"{e}down.{lvl}.downsample.conv.bias", (bi,))]
+    s += res(e + "mid.block_1.", bi, bi)
+    a = e + "mid.attn_1."
+    s += [(a + "norm.weight", (bi,)), (a + "norm.bias", (bi,))]
+    for nm in ("q", "k", "v", "proj_out"):
+        s += [(a + nm + ".weight", (bi, bi, 1, 1)), (a + nm + ".bias", (bi,))]
+    s += res(e + "mid.block_2.", bi, bi)
+    s += [(e + "norm_out.weight", (bi,)), (e + "norm_out.bias", (bi,)),
+          (e + "conv_out.weight", (2 * z_ch, bi, 3, 3)), (e + "conv_out.bias", (2 * z_ch,)),
+          ("quant_conv.weight", (2 * embed_dim, 2 * z_ch, 1, 1)), ("quant_conv.bias", (2 * embed_dim,))]
+    return s
+
+
+def vae_state_dict(seed, device=None, encoder=False, **arch):
     sd = {}
-    for key, shape in vae_decoder_param_shapes(**arch):
+    shapes = vae_decoder_param_shapes(**arch) + (vae_encoder_param_shapes() if encoder else [])
+    for key, shape in shapes:
         if "norm" in key and key.endswith(".weight"):
             sd[key] = _gen(seed, key, shape, 0.1, device) + 1.0
         elif key.endswith(".bias"):

@@ -66,19 +66,10 @@ def build_target_rules(target_rules, batch_size, device):
     return out
 
 
-def main(argv=None):
-    args = create_argparser().parse_args(argv)
-    args.dir = output_dir_for(args.config_path, args.class_label)
-    from rgm import native as _native
-    _native.set_gemm_precision(args.gemm_precision)      # "bf16x3_presplit" / "bf16x3" (fast, fp32-grade) or "fp32" (exact fp32 MFMA)
-    comm = dist_util.setup_dist(port=args.port)
-    logger.configure(args=args, comm=comm)
-    config = midi_util.load_config(args.config_path)
-    if config.sampling.use_ddim:
-        args.timestep_respacing = config.sampling.timestep_respacing
-    device = dist_util.dev()
-    rank0 = int(os.environ.get("RANK", "0")) == 0
-
+def build_pipeline(args, config, device):
+    """eps-network, diffusion, VAE, guidance cond_fn and the (possibly DiffCollage-wrapped) model_fn, as both CLIs
+    (sample_rule.py :52-137, edit.py :55-138 of the reference) set them up.  Returns a SimpleNamespace."""
+    from types import SimpleNamespace
     logger.log("creating model and diffusion...")
     model = DiT_models[args.model](input_size=args.image_size, in_channels=args.in_channels,
                                    num_classes=args.num_classes, learn_sigma=args.learn_sigma)
@@ -102,7 +93,7 @@ def main(argv=None):
         embed_model = load_model(args.vae, None if args.synthetic_weights else args.vae_path)
         if args.synthetic_weights:
             from rgm import synth
-            embed_model.load_state_dict(synth.vae_state_dict(2, device=device))
+            embed_model.load_state_dict(synth.vae_state_dict(2, device=device, encoder=True))
         embed_model.to(device)
         embed_model.eval()
 
@@ -148,6 +139,26 @@ def main(argv=None):
         gen_shape = (args.batch_size, args.in_channels, args.image_size[0], args.image_size[1])
         model_fn_used = partial(model_fn, model=model, num_classes=args.num_classes, class_cond=args.class_cond,
                                 cfg=args.cfg, w=args.w)
+
+    return SimpleNamespace(model=model, diffusion=diffusion, embed_model=embed_model, cond_fn=cond_fn_used,
+                           model_fn=model_fn_used, gen_shape=gen_shape, classifiers=classifiers)
+
+
+def main(argv=None):
+    args = create_argparser().parse_args(argv)
+    args.dir = output_dir_for(args.config_path, args.class_label)
+    from rgm import native as _native
+    _native.set_gemm_precision(args.gemm_precision)      # "bf16x3_presplit" / "bf16x3" (fast, fp32-grade) or "fp32" (exact fp32 MFMA)
+    comm = dist_util.setup_dist(port=args.port)
+    logger.configure(args=args, comm=comm)
+    config = midi_util.load_config(args.config_path)
+    if config.sampling.use_ddim:
+        args.timestep_respacing = config.sampling.timestep_respacing
+    device = dist_util.dev()
+    rank0 = int(os.environ.get("RANK", "0")) == 0
+
+    P = build_pipeline(args, config, device)
+    diffusion, embed_model, cond_fn_used, model_fn_used, gen_shape = P.diffusion, P.embed_model, P.cond_fn, P.model_fn, P.gen_shape
 
     target_rules = vars(config.target_rules)
     if any(v is None for v in list(target_rules.values())[:1]):

@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from rgm import native as _rgm
-from rgm.synth import vae_decoder_param_shapes
+from rgm.synth import vae_decoder_param_shapes, vae_encoder_param_shapes
 
 
 def _attach(root, dotted, param):
@@ -29,6 +29,26 @@ def _attach(root, dotted, param):
     mod.register_parameter(leaf, param)
 
 
+class DiagonalGaussianDistribution:
+    """Posterior of AutoencoderKL.encode (taming/modules/distributions/distributions.py:24-62): host-side view of the moments."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self):
+        return self.mean + self.std * torch.randn(self.mean.shape, device=self.parameters.device)
+
+    def mode(self):
+        return self.mean
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, ddconfig=None, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
                  colorize_nlabels=None, monitor=None):
@@ -39,7 +59,7 @@ class AutoencoderKL(nn.Module):
                 != (128, (1, 2, 2, 4), 2, 4, 3, []):
             raise NotImplementedError("the native decoder implements the kl/f8-all-onset config (ch 128, mult 1-2-2-4)")
         self.embed_dim = embed_dim
-        for key, shape in vae_decoder_param_shapes():
+        for key, shape in vae_decoder_param_shapes() + vae_encoder_param_shapes():
             p = nn.Parameter(torch.empty(shape))
             with torch.no_grad():
                 if key.endswith("weight") and len(shape) == 4:
@@ -125,10 +145,25 @@ class AutoencoderKL(nn.Module):
             return roll, u8
         return u8 if want_u8 else roll
 
-    def encode(self, *a, **k):
-        raise NotImplementedError("VAE encoder is a 'next' row (editing / dataset targets): SURVEY 8f.2")
+    @torch.no_grad()
+    def encode_save(self, x, range_fix=False):
+        """x (M,3,128,128) piano-roll tiles in [-1,1] -> moments (M,8,16,16): mean | logvar (klvae_pedal.py:61-68)."""
+        _rgm.require_cuda(x)
+        dev = self._ensure_native()
+        x = x.detach().to(torch.float32).contiguous()
+        M = x.shape[0]
+        assert tuple(x.shape[1:]) == (3, 128, 128), f"the encoder consumes (M,3,128,128) tiles, got {tuple(x.shape)}"
+        out = torch.empty((M, 8, 16, 16), dtype=torch.float32, device=dev)
+        ws, need = self._workspace(M, dev)
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_vae_encode(self._handle, _rgm.ptr(x), _rgm.ptr(out), M, _rgm.ptr(ws), need, _rgm.current_stream()))
+        if range_fix:
+            mean, logvar = torch.chunk(out, 2, dim=1)
+            out = torch.concat((torch.sigmoid(mean) * 2 - 1, logvar), dim=1)
+        return out
 
-    encode_save = encode
+    def encode(self, x, range_fix=False):
+        return DiagonalGaussianDistribution(self.encode_save(x, range_fix=range_fix))
 
     def __del__(self):
         try:

@@ -114,8 +114,8 @@ class RefVAE:
     """AutoencoderKL.decode (klvae_pedal.py:80-85) without Lightning/omegaconf: the reference's
     own Decoder class + a Conv2d(4,4,1) post_quant_conv, exactly the two modules decode() calls."""
 
-    def __init__(self, seed):
-        self.sd = synth.vae_state_dict(seed)
+    def __init__(self, seed, encoder=False):
+        self.sd = synth.vae_state_dict(seed, encoder=encoder)
         import io, contextlib
         with contextlib.redirect_stdout(io.StringIO()):
             self.decoder = rtm.Decoder(ch=128, out_ch=3, ch_mult=(1, 2, 2, 4), num_res_blocks=2,
@@ -126,9 +126,21 @@ class RefVAE:
         self.decoder.load_state_dict({k[len("decoder."):]: v for k, v in t.items() if k.startswith("decoder.")}, strict=True)
         self.pq.load_state_dict({"weight": t["post_quant_conv.weight"], "bias": t["post_quant_conv.bias"]})
         self.decoder.eval()
+        if encoder:   # the reference's own Encoder class + Conv2d(8,8,1) quant_conv: what encode_save() calls (klvae_pedal.py:61-68)
+            with contextlib.redirect_stdout(io.StringIO()):
+                self.encoder = rtm.Encoder(ch=128, out_ch=3, ch_mult=(1, 2, 2, 4), num_res_blocks=2, attn_resolutions=[],
+                                           dropout=0.0, in_channels=3, resolution=128, z_channels=4, double_z=True)
+            self.qc = torch.nn.Conv2d(8, 8, 1)
+            self.encoder.load_state_dict({k[len("encoder."):]: v for k, v in t.items() if k.startswith("encoder.")}, strict=True)
+            self.qc.load_state_dict({"weight": t["quant_conv.weight"], "bias": t["quant_conv.bias"]})
+            self.encoder.eval()
 
     def decode(self, z):
         return self.decoder(self.pq(z))
+
+    def encode_save(self, x, range_fix=False):
+        assert not range_fix
+        return self.qc(self.encoder(x))
 
 
 def np_model(sd, arch):
@@ -389,6 +401,125 @@ def g_steps(vae):
     save("steps", **out)
 
 
+def g_edit():
+    """Editing path (scripts/edit.py): VAE encoder, _encode, and teacher-forced steps with edit_kwargs."""
+    print("[edit: encoder, _encode, replacement-conditioned steps]")
+    from functools import partial
+    from types import SimpleNamespace
+    vae = RefVAE(2, encoder=True)
+    rng = np.random.RandomState(900)
+    tiles = sparse_roll(rng, 2, 128)
+    ref = vae.encode_save(torch.from_numpy(tiles)).numpy()
+    ora = ovae.encode_moments(vae.sd, tiles)
+    err("encode_save (2,3,128,128)", ora, ref)
+    roll = sparse_roll(rng, 1, 256)
+    lat = rgd._encode(torch.from_numpy(roll), vae, scale_factor=1.2465).numpy()
+    err("_encode (1,3,128,256)", ovae.encode_latent(vae.sd, roll, 1.2465), lat)
+    out = {"seed": np.array(2), "tiles": tiles, "moments": ref, "roll": roll, "latent": lat}
+
+    m, sd = ref_dit(SM, 11)
+    cm, csd = ref_cls(CLS2, 4)
+    mf = ref_model_fn(m, 3, True)
+    omf = np_model(sd, SM)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    gt = (rng.randn(B, 4, 128, 16) * 0.8).astype(F32)
+    ls, le = 32, 96                                   # editable latent rows (two 16-row squares stay fixed on each side)
+    mask = np.ones_like(gt)
+    mask[:, :, ls:le, :] = 0.
+    ek = {"gt": torch.from_numpy(gt), "mask": torch.from_numpy(mask), "l_start": ls, "l_end": le, "noise_level": 3}
+    oe = {"gt": gt, "mask": mask, "l_start": ls, "l_end": le}
+    out.update({"x": x, "y": y, "gt": gt, "mask": mask, "l_start": np.array(ls), "l_end": np.array(le)})
+
+    # ---- plain DDPM / DDIM steps with replacement
+    for tag, rs, ddim, ti, clip in (("ddpm", "", False, 600, True), ("ddim", "ddim50", True, 20, False)):
+        d = make_diffusion(rs)
+        d.t_end = 0
+        S = odf.Schedule(1000, "linear", rs)
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        kw = dict(clip_denoised=clip, model_kwargs={"y": torch.from_numpy(y)}, edit_kwargs=ek)
+        if ddim:
+            r = d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), eta=1.0, **kw)
+            o = odf.ddim_sample(S, omf, x, t, nz, eta=1.0, clip_denoised=clip, model_kwargs={"y": y}, edit=oe)
+        else:
+            r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), **kw)
+            o = odf.p_sample(S, omf, x, t, nz, clip_denoised=clip, model_kwargs={"y": y}, edit=oe)
+        err(f"edit {tag} sample", o["sample"], r["sample"].numpy())
+        err(f"edit {tag} pred_xstart", o["pred_xstart"], r["pred_xstart"].numpy())
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].numpy(),
+                    f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
+
+    # ---- classifier guidance under editing ("250" chain).  The reference multiplies the FULL-size variance by the
+    # gradient of the editable slice (:413), so it only runs when the whole latent is editable -- which is what every
+    # shipped edit config with a classifier uses (l_start 0, l_end 128); the mask is then all zeros.
+    ek_part, oe_part = ek, oe
+    ek = dict(ek_part, mask=torch.zeros_like(ek_part["mask"]), l_start=0, l_end=128)
+    oe = dict(oe_part, mask=np.zeros_like(mask), l_start=0, l_end=128)
+    torch.set_grad_enabled(True)
+    d = make_diffusion("250")
+    d.t_end = 0
+    S = odf.Schedule(1000, "linear", "250")
+    t = np.full((B,), 120, dtype=np.int64)
+    rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
+    cond = partial(rcf.composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[cm],
+                   rule_names=["note_density"])
+    g = SimpleNamespace(schedule=False, method="classifier_guidance")
+    nz = rng.randn(B, 4, 128, 16).astype(F32)
+    NQ.push(nz)
+    with torch.no_grad():
+        r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, cond_fn=cond,
+                       model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in rule.items()}},
+                       guidance_kwargs=g, edit_kwargs=ek)
+    torch.set_grad_enabled(False)
+
+    def ocond(xx, tt, y=None, rule=None):
+        return odit.grad_nn_zt_mse(csd, xx, tt, rule["note_density"], 10., depth=2, heads=6)[0]
+    o = odf.p_sample(S, omf, x, t, nz, cond_fn=ocond, model_kwargs={"y": y, "rule": rule},
+                     guidance={"schedule": False}, return_aux=True, edit=oe)
+    err("edit cls-guided sample", o["sample"], r["sample"].numpy())
+    out.update({"cg.t": t, "cg.noise": nz, "cg.rule": rule["note_density"], "cg.sample": r["sample"].numpy()})
+
+    ek, oe = ek_part, oe_part
+    # ---- SCG step scoring only the editable rows (n = 3), real decoder
+    d = make_diffusion("")
+    d.t_end = 0
+    S = odf.Schedule(1000, "linear", "")
+    n = 3
+    t = np.full((B,), 400, dtype=np.int64)
+    tgt = {"pitch_hist": np.tile(np.array([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], dtype=F32), (B, 1)),
+           "note_density": np.tile(np.array([3.] * 4 + [3.] * 4, dtype=F32), (B, 1))}
+    scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
+    g = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    nz = rng.randn(n, B, 4, 128, 16).astype(F32)
+    NQ.push(nz)
+    r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False,
+                   model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in tgt.items()}},
+                   embed_model=vae, scale_factor=1.2465, guidance_kwargs=g, scg_kwargs=scg, edit_kwargs=ek)
+    o = odf.p_sample(S, omf, x, t, nz, model_kwargs={"y": y, "rule": tgt},
+                     guidance=dict(schedule=True, t_start=750, t_end=0, interval=1), scg_kwargs=scg,
+                     decode_fn=lambda z: ovae.decode(vae.sd, z), scale_factor=1.2465,
+                     func_dict=orl.FUNC_DICT, loss_dict=orl.LOSS_DICT, return_aux=True, edit=oe)
+    err("edit scg sample", o["sample"], r["sample"].numpy())
+    print("    oracle scg max_ind", o["aux"]["max_ind"], "total_log_prob\n", o["aux"]["total_log_prob"])
+    out.update({"scg.t": t, "scg.noise": nz, "scg.sample": r["sample"].numpy(), "scg.max_ind": o["aux"]["max_ind"],
+                "scg.total_log_prob": o["aux"]["total_log_prob"], "scg.target.pitch_hist": tgt["pitch_hist"],
+                "scg.target.note_density": tgt["note_density"]})
+
+    # ---- the loop start: ground truth noised to noise_level, then noise_level ancestral steps (full chain)
+    d = make_diffusion("")
+    d.t_end = 0
+    x0n = rng.randn(B, 4, 128, 16).astype(F32)
+    steps = [rng.randn(B, 4, 128, 16).astype(F32) for _ in range(3)]
+    NQ.push(x0n, *steps)
+    r = d.p_sample_loop(mf, (B, 4, 128, 16), clip_denoised=False, model_kwargs={"y": torch.from_numpy(y)}, device="cpu",
+                        edit_kwargs=ek)
+    out.update({"loop.init_noise": x0n, "loop.noise": np.stack(steps), "loop.sample": r.numpy()})
+    save("edit", **out)
+
+
 def g_collage():
     print("[diff_collage]")
     m, sd = ref_dit(SM, 11)
@@ -486,7 +617,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -505,6 +636,8 @@ if __name__ == "__main__":
         g_steps(vae)
     if "collage" in which:
         g_collage()
+    if "edit" in which:
+        g_edit()
     if "cli" in which:
         g_cli()
     if "e2e" in which:

@@ -47,3 +47,24 @@ def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
     roll = np.load(os.path.join(out_dir, rolls[0]))
     T = 4096 if "long" in cfg else 1024
     assert roll.shape == (3, 128, T) and roll.dtype == np.uint8 and roll.max() <= 127
+
+
+def test_edit_cli_keeps_the_fixed_part_and_rewrites_the_excerpt(tmp_path, monkeypatch):
+    """scripts/edit.py end to end (synthetic weights, synthetic source, 20-step chain, noise_level from the YAML clipped to
+    the chain): the latent rows outside [l_start, l_end) are the encoded source (replacement conditioning), the
+    report covers the edited excerpt only."""
+    import torch
+    monkeypatch.chdir(tmp_path)
+    spec = importlib.util.spec_from_file_location("edit_cli", os.path.join(PKG, "scripts", "edit.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    cfg_src = os.path.join(CFG, "edit", "nd_scg_given_target.yml")
+    cfg = os.path.join(str(tmp_path), "configs", "edit", "nd_short.yml")
+    os.makedirs(os.path.dirname(cfg))
+    open(cfg, "w").write(open(cfg_src).read().replace("noise_level: 500", "noise_level: 12"))
+    res, sample = cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "20"] + COMMON)
+    assert len(res) == 2 and {"note_density.loss", "note_density.orig_rule"} <= set(res.columns)
+    assert np.isfinite(res["note_density.loss"]).all()
+    out_dir = os.path.join("loggings", "edit_demo", "edit", "nd_short_cls_1")
+    assert os.path.exists(os.path.join(out_dir, "results.csv")) and os.path.exists(os.path.join(out_dir, "gt", "sample_0_y_1.npy"))
+    assert sample.shape == (2, 128, 1024, 3) and sample.dtype == torch.uint8

@@ -23,7 +23,7 @@ def _dit(arch, seed, final_std=None, device_gen=False):
 def _vae(seed=2):
     from gpu_util import load_module
     from taming.models.klvae_pedal import AutoencoderKL
-    return load_module(AutoencoderKL(), synth.vae_state_dict(seed))
+    return load_module(AutoencoderKL(), synth.vae_state_dict(seed, encoder=True))
 
 
 def _diffusion(rs):

@@ -184,3 +184,35 @@ def test_end_to_end_ddim50_small_model():
     vsd = synth.vae_state_dict(2)
     u8 = ovae.quantise_roll(odf.decode_latent(lat, lambda z: ovae.decode(vsd, z), 1.2465))
     assert (u8 != g["u8"]).mean() < 1e-3
+
+
+def test_vae_encoder_and_encode_latent():
+    """Editing path: Encoder + quant_conv and the tiling of _encode, against the reference's outputs."""
+    g = load_golden("edit")
+    vsd = synth.vae_state_dict(int(g["seed"]), encoder=True)
+    assert rel_err(ovae.encode_moments(vsd, g["tiles"]), g["moments"]) < 2e-5
+    assert rel_err(ovae.encode_latent(vsd, g["roll"], 1.2465), g["latent"]) < 2e-5
+
+
+def test_replacement_conditioned_steps():
+    """edit_kwargs in p_sample / ddim_sample (reference p_mean_variance :293-298, condition_mean :408-414)."""
+    g = load_golden("edit")
+    sd = synth.dit_state_dict(11, **SM)
+    model = _np_model(sd, SM)
+    edit = {"gt": g["gt"], "mask": g["mask"], "l_start": int(g["l_start"]), "l_end": int(g["l_end"])}
+    for tag, rs, ddim, clip in (("ddpm", "", False, True), ("ddim", "ddim50", True, False)):
+        S = odf.Schedule(1000, "linear", rs)
+        kw = dict(clip_denoised=clip, model_kwargs={"y": g["y"]}, edit=edit)
+        o = odf.ddim_sample(S, model, g["x"], g[f"{tag}.t"], g[f"{tag}.noise"], eta=1.0, **kw) if ddim \
+            else odf.p_sample(S, model, g["x"], g[f"{tag}.t"], g[f"{tag}.noise"], **kw)
+        assert rel_err(o["sample"], g[f"{tag}.sample"]) < 1e-4, tag
+        assert rel_err(o["pred_xstart"], g[f"{tag}.pred_xstart"]) < 1e-3, tag   # c2 ~ 6 amplifies the eps noise here
+    csd = synth.dit_state_dict(4, **CLS2)
+    S = odf.Schedule(1000, "linear", "250")
+
+    def cond(xx, tt, y=None, rule=None):
+        return odit.grad_nn_zt_mse(csd, xx, tt, rule["note_density"], 10., depth=2, heads=6)[0]
+    full = dict(edit, mask=np.zeros_like(g["mask"]), l_start=0, l_end=128)
+    o = odf.p_sample(S, model, g["x"], g["cg.t"], g["cg.noise"], cond_fn=cond,
+                     model_kwargs={"y": g["y"], "rule": {"note_density": g["cg.rule"]}}, guidance={"schedule": False}, edit=full)
+    assert rel_err(o["sample"], g["cg.sample"]) < 1e-4
