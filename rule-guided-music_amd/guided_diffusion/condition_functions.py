@@ -2,7 +2,7 @@
 (guided_diffusion/condition_functions.py:17-42, :58-85, :149-174).
 
 model_fn / dc_model_fn are thin: class-conditional call, null label (= num_classes) when unconditional,
-classifier-free guidance as two forwards.  The grad_nn_zt_* guidance functions call the classifier's
+classifier-free guidance as one 2B-row forward.  The grad_nn_zt_* guidance functions call the classifier's
 fused value-and-input-gradient kernel chain (no autograd graph; weights are frozen at sampling time).
 DPS variants (nn_z0_*, rule_x0_*) are a 'next' row.
 """
@@ -14,12 +14,20 @@ def _null_labels(x, num_classes):
     return th.full((x.shape[0],), num_classes, dtype=th.int64, device=x.device)
 
 
+def _cfg_eps(model, x, t, y, num_classes, w):
+    """Classifier-free guidance (reference :22-23) as ONE forward over the conditional and the null-label copies of the
+    batch (2B rows fill the GPU better than two B-row passes; per-row results are identical) + one combine."""
+    B = x.shape[0]
+    e = model(th.cat([x, x], dim=0), th.cat([t, t], dim=0), th.cat([y.to(th.int64), _null_labels(x, num_classes)], dim=0))
+    return th.add(e[:B], e[:B] - e[B:], alpha=w)            # (1 + w) * e_cond - w * e_null
+
+
 def model_fn(x, t, y=None, rule=None, model=nn.Identity(), num_classes=3, class_cond=True, cfg=False, w=0.):
     """`rule` is a dummy argument (model_kwargs carries it for the cond_fn / SCG)."""
     if not class_cond:
         return model(x, t, _null_labels(x, num_classes))
     if cfg:
-        return (1 + w) * model(x, t, y) - w * model(x, t, _null_labels(x, num_classes))
+        return _cfg_eps(model, x, t, y, num_classes, w)
     return model(x, t, y)
 
 
@@ -29,8 +37,7 @@ def dc_model_fn(x, t, y=None, rule=None, model=nn.Identity(), num_classes=3, cla
     if not class_cond:
         return model(xt, t, _null_labels(xt, num_classes)).permute(0, 1, 3, 2)
     if cfg:
-        eps = (1 + w) * model(xt, t, y) - w * model(xt, t, _null_labels(xt, num_classes))
-        return eps.permute(0, 1, 3, 2)
+        return _cfg_eps(model, xt, t, y, num_classes, w).permute(0, 1, 3, 2)
     return model(xt, t, y).permute(0, 1, 3, 2)
 
 

@@ -170,3 +170,28 @@ def test_classifier_guided_p_sample_step_matches_reference(precision):
                      clip_denoised=False, cond_fn=cond, model_kwargs={"y": dev(g["y"]), "rule": {"note_density": dev(g["cg.rule"])}},
                      guidance_kwargs=SimpleNamespace(schedule=False, method="classifier_guidance"))
     assert rel(out["sample"].cpu().numpy(), g["cg.sample"]) < 2e-4
+
+
+def test_cfg_model_fn_is_one_batched_forward_with_the_same_result(precision):
+    """Classifier-free guidance (condition_functions.py:22-23): the 2B-row batched forward equals the two B-row passes."""
+    from functools import partial
+    from gpu_util import dev, load_module, rel
+    from guided_diffusion.condition_functions import dc_model_fn, model_fn
+    from guided_diffusion.dit import DiTRotary
+    arch = dict(depth=2, hidden=384, heads=6, patch=8, in_ch=4, out_ch=4, num_classes=3)
+    m = load_module(DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6,
+                              num_classes=3, learn_sigma=False), synth.dit_state_dict(11, **arch))
+    calls = []
+
+    def counted(x, t, y):
+        calls.append(x.shape[0])
+        return m(x, t, y)
+    rng = np.random.RandomState(5)
+    x, t, y = dev(rng.randn(3, 4, 128, 16).astype(np.float32)), dev(np.array([10, 500, 999])), dev(np.array([0, 2, 1]))
+    null = torch.full((3,), 3, dtype=torch.int64, device="cuda")
+    ref = (1 + 4.0) * m(x, t, y) - 4.0 * m(x, t, null)
+    out = model_fn(x, t, y, model=counted, num_classes=3, class_cond=True, cfg=True, w=4.0)
+    assert calls == [6]
+    assert rel(out.cpu().numpy(), ref.cpu().numpy()) < 2e-6
+    out_dc = dc_model_fn(x.permute(0, 1, 3, 2), t, y, model=counted, num_classes=3, class_cond=True, cfg=True, w=4.0)
+    assert rel(out_dc.permute(0, 1, 3, 2).cpu().numpy(), ref.cpu().numpy()) < 2e-6
