@@ -41,7 +41,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, const float* __restrict__ cos_tab,
                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half) {
-  constexpr int HDP = HD + 4, KB = HD / 8, DT = HD / 32, TP = NKT * 32;
+  constexpr int HDP = HD + 4, KB = HD / 8, DT = (HD + 31) / 32, TP = NKT * 32;   // hd = 72: the third channel tile is partial
+  // (its operand reads run past a row into the next row / the following array: finite data feeding accumulator rows that are never stored)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;              // [TP][HDP] rotated keys
   float* Vs = smem + TP * HDP;   // [TP][HDP]
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = dt * 32 + 8 * g + 4 * hh;
+          if (d >= HD) continue;
           float4 v = make_float4(dq[dt][4 * g] * scale, dq[dt][4 * g + 1] * scale, dq[dt][4 * g + 2] * scale, dq[dt][4 * g + 3] * scale);
           if (d < R) v = rotate4(v, cos_tab, sin_tab, q * rot_half + (d >> 1), true);
           *reinterpret_cast<float4*>(op + d) = v;
@@ -146,7 +148,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, const float* __restrict__ cos_tab,
                                                            const float* __restrict__ sin_tab, int T, int heads, int rot_half) {
-  constexpr int HDP = HD + 4, KB = HD / 8, DT = HD / 32, TP = NKT * 32;
+  constexpr int HDP = HD + 4, KB = HD / 8, DT = (HD + 31) / 32, TP = NKT * 32;   // hd = 72: the third channel tile is partial
+  // (its operand reads run past a row into the next row / the following array: finite data feeding accumulator rows that are never stored)
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;                   // [TP][HDP] rotated, pre-scaled queries
   float* Gs = smem + TP * HDP;        // [TP][HDP] dO
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = dt * 32 + 8 * g + 4 * hh;
+          if (d >= HD) continue;
           float4 kv = make_float4(dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
           if (d < R) kv = rotate4(kv, cos_tab, sin_tab, key * rot_half + (d >> 1), true);
           *reinterpret_cast<float4*>(op + D + d) = kv;
@@ -288,9 +292,14 @@ static int launch_bwd(const float* qkv, const float* o, const float* d_o, const 
 int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                 const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd, int rot_half,
                                 hipStream_t s) {
-  RGM_REQUIRE(hd == 64, "attention backward: head_dim %d (64 = the S/B classifier family)", hd);
+  RGM_REQUIRE(hd == 64 || hd == 72, "attention backward: head_dim %d (64 = the S/B family, 72 = XL)", hd);
   RGM_REQUIRE(T > 0 && T <= 288, "attention backward: T=%d", T);
   const int nkt = (T + 31) / 32;
+  if (hd == 72) {   // XL eps-network (DPS guidance): Q/dO resp. K/V of one head + lse/D = 157.7 KB of LDS at T = 256
+    RGM_REQUIRE(nkt <= 8, "attention backward: head_dim 72 supports T <= 256, got %d", T);
+    if (nkt <= 4) return launch_bwd<72, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
+    return launch_bwd<72, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
+  }
   if (nkt <= 4) return launch_bwd<64, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
   if (nkt <= 5) return launch_bwd<64, 5>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
   if (nkt <= 8) return launch_bwd<64, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);

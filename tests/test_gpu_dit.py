@@ -77,11 +77,11 @@ def test_attention_backward_kernel_vs_oracle():
     from rgm.synth import rotary_freqs
     from oracle import dit_np as odit
     rng = np.random.RandomState(5)
-    for N, T, heads in ((2, 257, 6), (1, 129, 6), (2, 256, 12)):
-        hd, D = 64, heads * 64
+    for N, T, heads, hd in ((2, 257, 6, 64), (1, 129, 6, 64), (2, 256, 12, 64), (2, 256, 16, 72), (1, 128, 16, 72), (1, 200, 4, 72)):
+        D = heads * hd
         qkv = rng.randn(N * T, 3 * D).astype(np.float32)
         d_o = rng.randn(N * T, D).astype(np.float32)
-        cos, sin = odit.rotary_tables(rotary_freqs(32), T)
+        cos, sin = odit.rotary_tables(rotary_freqs(hd // 2), T)
         r = qkv.reshape(N, T, 3, heads, hd)
         q, k, v = (np.ascontiguousarray(r[:, :, i].transpose(0, 2, 1, 3)) for i in range(3))
         qr, kr = odit.apply_rotary(q, cos, sin), odit.apply_rotary(k, cos, sin)
@@ -102,14 +102,14 @@ def test_attention_backward_kernel_vs_oracle():
         import ctypes as C
         lib = C.CDLL(R.LIB_PATH)
         ws = torch.empty(1, device="cuda")
-        R.check(R.lib.rgm_rotary_attention(R.ptr(qd), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, 16, R.current_stream()))
+        R.check(R.lib.rgm_rotary_attention(R.ptr(qd), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, hd // 4, R.current_stream()))
         lse_ref = (np.log(np.exp(s - s.max(-1, keepdims=True)).sum(-1)) + s.max(-1)).astype(np.float32)    # (N, heads, T)
         lse.copy_(dev(lse_ref.reshape(-1)))
         out = torch.full((N * T, 3 * D), float("nan"), device="cuda")
         R.check(R.lib.rgm_rotary_attention_bwd(R.ptr(qd), R.ptr(od), R.ptr(gd), R.ptr(lse), R.ptr(out), R.ptr(cd), R.ptr(sd_),
-                                               N, T, heads, hd, 16, R.current_stream()))
+                                               N, T, heads, hd, hd // 4, R.current_stream()))
         torch.cuda.synchronize()
-        assert rel(out.cpu().numpy(), ref) < 1e-5, (N, T, heads)
+        assert rel(out.cpu().numpy(), ref) < 1e-5, (N, T, heads, hd)
 
 
 @pytest.mark.parametrize("tag,depth", [("s8d2", 2), ("s8", 12)])
