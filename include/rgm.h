@@ -215,6 +215,16 @@ size_t rgm_dit_grad_workspace_bytes(const rgm_dit* h, int N, int H);
 int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,
                                float scale, float* logits_out, float* grad_x, int N, int H, void* ws,
                                size_t ws_bytes, void* stream);
+/* Input gradient of the eps-network -- the autograd step of DPS guidance (condition_mean, gaussian_diffusion.py:415-465:
+ * th.autograd.grad(log_probs.sum(), xt) through pred_xstart(xt, model(xt))): eps_out = model(x, t, y) (optional) and
+ * grad_x = (d eps / d x)^T g_eps, via the saved-activation forward and the same dgrad chain as the classifiers.
+ * rgm_dit_enable_grad(h) first: it keeps W^T copies of the eps-network's Linear weights (1.8 GB at XL); workspace =
+ * rgm_dit_grad_workspace_bytes(h, N, H).  Two phases that may be separate calls on the same workspace: forward
+ * (x, t [, y] given; g_eps/grad_x NULL) saves the activations and writes eps_out; backward (x NULL; g_eps, grad_x given)
+ * consumes them -- DPS forms g_eps from the classifier's gradient at x0(eps) in between. */
+int rgm_dit_enable_grad(rgm_dit* h);
+int rgm_dit_vjp(rgm_dit* h, const float* x, const int64_t* t, const int32_t* y, const float* g_eps, float* eps_out,
+                float* grad_x, int N, int H, void* ws, size_t ws_bytes, void* stream);
 /* d(qkv) of the RotaryAttention core from dO, the saved qkv, O and per-query log-sum-exp (N, heads, T); hd = 64. */
 int rgm_rotary_attention_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                              const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,

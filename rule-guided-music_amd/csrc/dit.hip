@@ -41,6 +41,7 @@ struct Slot {
   size_t numel = 0;
   bool set = false;
   int t_rows = 0, t_cols = 0, t_ld = 0;   // ".T" slots: transposed copy of a [t_cols(out)][t_rows(in)] weight, row stride t_ld
+  bool in_t = false;                      // lives in arena_t (the W^T copies an eps-network gets from rgm_dit_enable_grad)
 };
 
 struct rgm_dit {
@@ -55,8 +56,11 @@ struct rgm_dit {
   bool rotary_ready = false;
   int rot_half = 0, hd = 0;
   size_t ada_rows = 0;       // (6*depth + 2 or 0) * D
+  float* arena_t = nullptr;  // eps-network only, allocated by rgm_dit_enable_grad: W^T copies for the input-gradient (DPS)
+  size_t arena_t_floats = 0;
 
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
+  float* sp(const Slot& sl) const { return (sl.in_t ? arena_t : arena) + sl.off; }
 };
 
 static void add_slot(rgm_dit* h, const std::string& key, size_t numel) {
@@ -197,6 +201,7 @@ extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
 extern "C" void rgm_dit_destroy(rgm_dit* h) {
   if (!h) return;
   if (h->arena) (void)hipFree(h->arena);
+  if (h->arena_t) (void)hipFree(h->arena_t);
   if (h->tfreqs) (void)hipFree(h->tfreqs);
   if (h->cos_tab) (void)hipFree(h->cos_tab);
   if (h->sin_tab) (void)hipFree(h->sin_tab);
@@ -219,7 +224,7 @@ extern "C" int rgm_dit_set_param(rgm_dit* h, const char* key, const void* dptr, 
   auto tt = h->slots.find(k + ".T");
   if (tt != h->slots.end()) {
     const Slot& ts = tt->second;
-    RGM_TRY(transpose_launch(h->arena + it->second.off, h->arena + ts.off, ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
+    RGM_TRY(transpose_launch(h->arena + it->second.off, h->sp(ts), ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
     RGM_CHECK_HIP(hipStreamSynchronize(0));
   }
   auto ss = h->slots.find(k + ".S");
@@ -250,6 +255,49 @@ extern "C" int rgm_dit_missing_params(rgm_dit* h) {
   int n = 0;
   for (auto& kv : h->slots) n += kv.second.set ? 0 : 1;
   return n;
+}
+
+// W^T copies of an eps-network's Linear weights, in their own allocation, so that the input-gradient entry point
+// (rgm_dit_vjp: DPS guidance) can run its dgrad GEMMs.  Classifier handles have them from the start.  May be called
+// before or after the parameters are set; costs (4 + 4 + 1 + 3) D^2 floats per block (1.8 GB at XL depth 28).
+extern "C" int rgm_dit_enable_grad(rgm_dit* h) {
+  RGM_REQUIRE(h, "dit_enable_grad: null handle");
+  if (h->cfg.kind != 0 || h->arena_t) return RGM_OK;
+  const rgm_dit_cfg& c = h->cfg;
+  const int D = c.hidden, pc = c.in_ch * c.patch;
+  std::vector<std::string> keys;
+  auto add = [&](const std::string& key, int out_f, int in_f) {
+    const int ld = (out_f + 31) / 32 * 32;
+    Slot s;
+    s.off = h->arena_t_floats;
+    s.numel = (size_t)in_f * ld;
+    s.set = true;
+    s.t_rows = in_f; s.t_cols = out_f; s.t_ld = ld;
+    s.in_t = true;
+    h->slots[key + ".T"] = s;
+    h->arena_t_floats += s.numel;
+    keys.push_back(key);
+  };
+  add("x_embedder.MLP.0.weight", 256, pc);
+  add("x_embedder.MLP.2.weight", D, 256);
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = "blocks." + std::to_string(i) + ".";
+    add(b + "attn.qkv.weight", 3 * D, D);
+    add(b + "attn.proj.weight", D, D);
+    add(b + "mlp.fc1.weight", 4 * D, D);
+    add(b + "mlp.fc2.weight", D, 4 * D);
+  }
+  add("final_layer.linear.weight", c.patch * c.out_ch, D);
+  RGM_CHECK_HIP(hipMalloc(&h->arena_t, h->arena_t_floats * sizeof(float)));
+  RGM_CHECK_HIP(hipMemset(h->arena_t, 0, h->arena_t_floats * sizeof(float)));
+  for (auto& k : keys) {
+    const Slot& base = h->slots.at(k);
+    if (!base.set) continue;                       // set_param fills the copy when the weight arrives
+    const Slot& ts = h->slots.at(k + ".T");
+    RGM_TRY(transpose_launch(h->arena + base.off, h->sp(ts), ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
+  }
+  RGM_CHECK_HIP(hipStreamSynchronize(0));
+  return RGM_OK;
 }
 
 namespace {
@@ -469,7 +517,7 @@ extern "C" int rgm_dit_classify(rgm_dit* h, const float* x, const int64_t* t, fl
 // =====================================================================================================
 namespace {
 struct GPlan {
-  int N, H, T0, T, M0, M, L, Kp, groups;
+  int N, H, T0, T, M0, M, L, Kp, groups, cls;   // cls = 1 when row 0 of every sample is the class token (classifiers)
   float *tok_in, *zpre, *h1, *temb, *c1, *c, *cs, *mod;
   float *xs, *x1s, *qkvs, *aos, *pres, *lses;   // per-block saves (xs has depth+1 entries)
   float *xm, *hid, *dx, *dx1, *t1, *dbig, *dqkv, *dsmall;
@@ -482,7 +530,8 @@ GPlan gplan(const rgm_dit* h, int N, int H, void* ws) {
   GPlan p{};
   p.N = N; p.H = H;
   p.T0 = H * c.width / c.patch;
-  p.T = p.T0 + 1;
+  p.cls = c.kind != 0 ? 1 : 0;
+  p.T = p.T0 + p.cls;
   p.M0 = N * p.T0;
   p.M = N * p.T;
   p.L = (int)h->ada_rows;
@@ -508,7 +557,7 @@ GPlan gplan(const rgm_dit* h, int N, int H, void* ws) {
   p.dbig = w.take(M * 4 * D);
   p.dqkv = w.take(M * 3 * D);
   p.dsmall = w.take(M * D);
-  const size_t R = (size_t)N * p.groups;
+  const size_t R = (size_t)N * p.groups + (c.kind == 0 ? (size_t)p.M0 : 0);   // eps-network: pool doubles as the token-space output
   p.pool = w.take(R * D); p.pooln = w.take(R * D);
   p.z1pre = w.take(R * (D / 4)); p.z1 = w.take(R * (D / 4));
   p.logits = w.take(R * c.n_out);
@@ -525,7 +574,7 @@ int dgrad(rgm_dit* h, const std::string& wkey, const float* dY, int lda, float* 
           int act, hipStream_t s) {
   const Slot& ts = h->slots.at(wkey + ".T");
   GemmParams g;
-  g.A = dY; g.lda = lda; g.B = h->arena + ts.off; g.ldb = ts.t_ld; g.C = dX; g.ldc = ldc;
+  g.A = dY; g.lda = lda; g.B = h->sp(ts); g.ldb = ts.t_ld; g.C = dX; g.ldc = ldc;
   g.M = M; g.N = ts.t_rows; g.K = ts.t_ld;
   g.aux = aux; g.ldaux = ldaux; g.act = act;
   return gemm_launch(g, s);
@@ -533,31 +582,14 @@ int dgrad(rgm_dit* h, const std::string& wkey, const float* dY, int lda, float* 
 }  // namespace
 
 extern "C" size_t rgm_dit_grad_workspace_bytes(const rgm_dit* h, int N, int H) {
-  if (!h || h->cfg.kind == 0 || N <= 0 || H <= 0) return 0;
+  if (!h || N <= 0 || H <= 0) return 0;
   return gplan(h, N, H, nullptr).bytes;
 }
 
-// loss_kind 0: log p = -sum_k (logits - target)^2, target float (N, n_out)                  [grad_nn_zt_mse]
-// loss_kind 1: log p = -sum_windows CE(chord_logits, target), target int64 (N, H/width)     [grad_nn_zt_chord, both=False]
-// grad_x (N,in_ch,H,width) = d(sum log p)/dx * scale ; logits_out (N[,H/width], n_out) optional.
-extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,
-                                          float scale, float* logits_out, float* grad_x, int N, int H, void* ws,
-                                          size_t ws_bytes, void* stream) {
-  RGM_REQUIRE(h && h->cfg.kind != 0, "cls_value_and_grad: handle is not a classifier");
-  RGM_REQUIRE(x && t && target && grad_x, "cls_value_and_grad: null tensor");
-  RGM_REQUIRE((loss_kind == 0 && h->cfg.kind == 1) || (loss_kind == 1 && h->cfg.kind == 2),
-              "cls_value_and_grad: loss_kind %d does not match classifier kind %d", loss_kind, h->cfg.kind);
-  RGM_REQUIRE(h->hd == 64, "cls_value_and_grad: head_dim %d (the backward kernels cover the 64-wide classifier family)", h->hd);
-  Plan chk;
-  RGM_TRY(check_ready(h, N, H, (size_t)-1, (void*)256, &chk));   // shapes + parameters (its workspace test is moot here)
+// ---- the three shared pieces of the input-gradient paths (classifier guidance, eps-network VJP)
+static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_t* t, const int32_t* y, hipStream_t s) {
   const rgm_dit_cfg& c = h->cfg;
-  GPlan p = gplan(h, N, H, ws);
-  if (!ws || p.bytes > ws_bytes) {
-    set_error("cls_value_and_grad: workspace %zu bytes < required %zu", ws_bytes, p.bytes);
-    return RGM_ERR_WORKSPACE;
-  }
-  hipStream_t s = (hipStream_t)stream;
-  const int D = c.hidden, pc = c.in_ch * c.patch, T = p.T, L = p.L, M = p.M;
+  const int N = p.N, H = p.H, D = c.hidden, pc = c.in_ch * c.patch, T = p.T, L = p.L, M = p.M;
   const size_t MD = (size_t)M * D;
   // ---------------- forward, keeping what the backward needs
   RGM_TRY(patchify_launch(x, p.tok_in, N, c.in_ch, H, c.width, c.patch, s));
@@ -567,16 +599,19 @@ extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int6
     GemmParams g;
     g.A = p.h1; g.lda = 256; g.sA = (long long)p.T0 * 256;
     g.B = h->p("x_embedder.MLP.2.weight"); g.ldb = 256;
-    g.C = p.xs + D; g.ldc = D; g.sC = (long long)T * D;
+    g.C = p.xs + (size_t)p.cls * D; g.ldc = D; g.sC = (long long)T * D;
     g.M = p.T0; g.N = D; g.K = 256; g.batch = N;
     g.bias = h->p("x_embedder.MLP.2.bias");
     RGM_TRY(gemm_launch(g, s));
-    RGM_TRY(fill_cls_launch(h->p("cls_token"), p.xs, N, T, D, s));
+    if (p.cls) RGM_TRY(fill_cls_launch(h->p("cls_token"), p.xs, N, T, D, s));
   }
   RGM_TRY(timestep_sincos_launch(t, h->tfreqs, p.temb, N, 128, s));
   RGM_TRY(lin(p.temb, 256, h->p("t_embedder.mlp.0.weight"), h->p("t_embedder.mlp.0.bias"), p.c1, D, N, D, 256, 1, s));
   RGM_TRY(lin(p.c1, D, h->p("t_embedder.mlp.2.weight"), h->p("t_embedder.mlp.2.bias"), p.c, D, N, D, D, 0, s));
-  RGM_TRY(cond_finish_launch(p.c, nullptr, nullptr, p.cs, N, D, s));
+  {
+    const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
+    RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, N, D, s));
+  }
   RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, N, L, D, 0, s));
   const size_t lse_sz = (size_t)N * c.heads * T;
   for (int i = 0; i < c.depth; ++i) {
@@ -609,21 +644,15 @@ extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int6
       RGM_TRY(gemm_launch(g, s));
     }
   }
-  const float* xf = p.xs + (size_t)c.depth * MD;
-  // ---------------- head forward + loss gradient
-  const int rows = N * p.groups, per = c.kind == 2 ? p.T0 / p.groups : 1, first = c.kind == 2 ? 1 : 0;
-  RGM_TRY(pool_rows_launch(xf, p.pool, N, T, D, first, p.groups, per, s));
-  RGM_TRY(layernorm_modulate_launch(p.pool, p.pooln, rows, D, 1e-5f, h->p("norm.weight"), h->p("norm.bias"), nullptr, nullptr, 0, 1, s));
-  RGM_TRY(lin(p.pooln, D, h->p("classifier_head.0.weight"), h->p("classifier_head.0.bias"), p.z1pre, D / 4, rows, D / 4, D, 0, s));
-  RGM_TRY(act_rows_launch(p.z1pre, p.z1, (long long)rows * (D / 4), 1, s));
-  float* logits = logits_out ? logits_out : p.logits;
-  RGM_TRY(lin(p.z1, D / 4, h->p("classifier_head.2.weight"), h->p("classifier_head.2.bias"), logits, c.n_out, rows, c.n_out, D / 4, 0, s));
-  RGM_TRY(loss_grad_launch(logits, target, p.dl, rows, c.n_out, p.Kp, scale, loss_kind, s));
-  // ---------------- head backward -> gradient of the residual stream
-  RGM_TRY(dgrad(h, "classifier_head.2.weight", p.dl, p.Kp, p.dz1, D / 4, rows, p.z1pre, D / 4, 4, s));
-  RGM_TRY(dgrad(h, "classifier_head.0.weight", p.dz1, D / 4, p.dpooln, D, rows, nullptr, 0, 0, s));
-  RGM_TRY(ln_mod_bwd_launch(p.dpooln, p.pool, nullptr, p.dpool, rows, D, 1e-5f, h->p("norm.weight"), nullptr, 0, 1, s));
-  RGM_TRY(scatter_rows_launch(p.dpool, p.dx, N, T, D, first, p.groups, per, s));
+  return RGM_OK;
+}
+
+// in: p.dx = gradient of the residual stream after the last block; out: p.dx = gradient of the embedded tokens
+static int grad_blocks_backward(rgm_dit* h, const GPlan& p, hipStream_t s) {
+  const rgm_dit_cfg& c = h->cfg;
+  const int N = p.N, D = c.hidden, T = p.T, L = p.L, M = p.M;
+  const size_t MD = (size_t)M * D;
+  const size_t lse_sz = (size_t)N * c.heads * T;
   // ---------------- blocks, last to first
   for (int i = c.depth - 1; i >= 0; --i) {
     const std::string b = "blocks." + std::to_string(i) + ".";
@@ -641,12 +670,19 @@ extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int6
     RGM_TRY(dgrad(h, b + "attn.qkv.weight", p.dqkv, 3 * D, p.dsmall, D, M, nullptr, 0, 0, s));          // d m1
     RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s));         // dx = dx1 + LN'
   }
+  return RGM_OK;
+}
+
+// in: p.dx (token gradients); out: grad_x (N,in_ch,H,width)
+static int grad_embed_backward(rgm_dit* h, const GPlan& p, float* grad_x, hipStream_t s) {
+  const rgm_dit_cfg& c = h->cfg;
+  const int N = p.N, H = p.H, D = c.hidden, pc = c.in_ch * c.patch, T = p.T;
   // ---------------- patch embedder backward (token rows 1..T0 of every sample), then un-patchify
   {
     const Slot& ts = h->slots.at("x_embedder.MLP.2.weight.T");
     GemmParams g;
-    g.A = p.dx + D; g.lda = D; g.sA = (long long)T * D;
-    g.B = h->arena + ts.off; g.ldb = ts.t_ld;
+    g.A = p.dx + (size_t)p.cls * D; g.lda = D; g.sA = (long long)T * D;
+    g.B = h->sp(ts); g.ldb = ts.t_ld;
     g.C = p.dz; g.ldc = 256; g.sC = (long long)p.T0 * 256;
     g.M = p.T0; g.N = 256; g.K = D; g.batch = N;
     g.aux = p.zpre; g.ldaux = 256; g.sAux = (long long)p.T0 * 256; g.act = 4;
@@ -656,3 +692,86 @@ extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int6
   RGM_TRY(unpatchify_launch(p.dtin, grad_x, N, c.in_ch, H, c.width, s));
   return RGM_OK;
 }
+
+// loss_kind 0: log p = -sum_k (logits - target)^2, target float (N, n_out)                  [grad_nn_zt_mse]
+// loss_kind 1: log p = -sum_windows CE(chord_logits, target), target int64 (N, H/width)     [grad_nn_zt_chord, both=False]
+// grad_x (N,in_ch,H,width) = d(sum log p)/dx * scale ; logits_out (N[,H/width], n_out) optional.
+extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,
+                                          float scale, float* logits_out, float* grad_x, int N, int H, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind != 0, "cls_value_and_grad: handle is not a classifier");
+  RGM_REQUIRE(x && t && target && grad_x, "cls_value_and_grad: null tensor");
+  RGM_REQUIRE((loss_kind == 0 && h->cfg.kind == 1) || (loss_kind == 1 && h->cfg.kind == 2),
+              "cls_value_and_grad: loss_kind %d does not match classifier kind %d", loss_kind, h->cfg.kind);
+  Plan chk;
+  RGM_TRY(check_ready(h, N, H, (size_t)-1, (void*)256, &chk));   // shapes + parameters (its workspace test is moot here)
+  const rgm_dit_cfg& c = h->cfg;
+  GPlan p = gplan(h, N, H, ws);
+  if (!ws || p.bytes > ws_bytes) {
+    set_error("cls_value_and_grad: workspace %zu bytes < required %zu", ws_bytes, p.bytes);
+    return RGM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int D = c.hidden, T = p.T, M = p.M;
+  const size_t MD = (size_t)M * D;
+  RGM_TRY(grad_forward(h, p, x, t, nullptr, s));
+  const float* xf = p.xs + (size_t)c.depth * MD;
+  // ---------------- head forward + loss gradient
+  const int rows = N * p.groups, per = c.kind == 2 ? p.T0 / p.groups : 1, first = c.kind == 2 ? 1 : 0;
+  RGM_TRY(pool_rows_launch(xf, p.pool, N, T, D, first, p.groups, per, s));
+  RGM_TRY(layernorm_modulate_launch(p.pool, p.pooln, rows, D, 1e-5f, h->p("norm.weight"), h->p("norm.bias"), nullptr, nullptr, 0, 1, s));
+  RGM_TRY(lin(p.pooln, D, h->p("classifier_head.0.weight"), h->p("classifier_head.0.bias"), p.z1pre, D / 4, rows, D / 4, D, 0, s));
+  RGM_TRY(act_rows_launch(p.z1pre, p.z1, (long long)rows * (D / 4), 1, s));
+  float* logits = logits_out ? logits_out : p.logits;
+  RGM_TRY(lin(p.z1, D / 4, h->p("classifier_head.2.weight"), h->p("classifier_head.2.bias"), logits, c.n_out, rows, c.n_out, D / 4, 0, s));
+  RGM_TRY(loss_grad_launch(logits, target, p.dl, rows, c.n_out, p.Kp, scale, loss_kind, s));
+  // ---------------- head backward -> gradient of the residual stream
+  RGM_TRY(dgrad(h, "classifier_head.2.weight", p.dl, p.Kp, p.dz1, D / 4, rows, p.z1pre, D / 4, 4, s));
+  RGM_TRY(dgrad(h, "classifier_head.0.weight", p.dz1, D / 4, p.dpooln, D, rows, nullptr, 0, 0, s));
+  RGM_TRY(ln_mod_bwd_launch(p.dpooln, p.pool, nullptr, p.dpool, rows, D, 1e-5f, h->p("norm.weight"), nullptr, 0, 1, s));
+  RGM_TRY(scatter_rows_launch(p.dpool, p.dx, N, T, D, first, p.groups, per, s));
+  RGM_TRY(grad_blocks_backward(h, p, s));
+  return grad_embed_backward(h, p, grad_x, s);
+}
+
+// Input gradient of the eps-network (DPS guidance, gaussian_diffusion.py:415-465): eps = model(x, t, y) with saved
+// activations, then grad_x = (d eps / d x)^T g_eps through final layer, blocks and embedder.  eps_out may be NULL.
+extern "C" int rgm_dit_vjp(rgm_dit* h, const float* x, const int64_t* t, const int32_t* y, const float* g_eps, float* eps_out,
+                           float* grad_x, int N, int H, void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind == 0, "dit_vjp: handle is not an eps-network");
+  // two phases sharing the workspace: forward (x, t given: activations are saved, eps_out written) and backward (g_eps,
+  // grad_x given); a caller that needs eps before it can form g_eps (DPS: g_eps depends on the classifier's gradient at
+  // x0(eps)) makes two calls -- (x, t, y, NULL, eps, NULL) then (NULL, NULL, NULL, g_eps, NULL, grad_x) -- with the same N, H, ws.
+  RGM_REQUIRE((x && t) || (g_eps && grad_x), "dit_vjp: nothing to do");
+  RGM_REQUIRE(!g_eps == !grad_x, "dit_vjp: g_eps and grad_x come together");
+  RGM_REQUIRE(h->arena_t, "dit_vjp: call rgm_dit_enable_grad first (W^T copies are not kept by default)");
+  Plan chk;
+  RGM_TRY(check_ready(h, N, H, (size_t)-1, (void*)256, &chk));
+  const rgm_dit_cfg& c = h->cfg;
+  GPlan p = gplan(h, N, H, ws);
+  if (!ws || p.bytes > ws_bytes) {
+    set_error("dit_vjp: workspace %zu bytes < required %zu", ws_bytes, p.bytes);
+    return RGM_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const int D = c.hidden, L = p.L, M = p.M, po = c.patch * c.out_ch;
+  const float* xf = p.xs + (size_t)c.depth * M * D;
+  const float* mf = p.mod + (size_t)c.depth * 6 * D;          // final-layer shift | scale
+  if (x) {
+    RGM_TRY(grad_forward(h, p, x, t, y, s));
+    if (eps_out) {
+      float* tok = p.pool;                                     // (M, patch*out_ch)
+      RGM_TRY(layernorm_modulate_launch(xf, p.xm, M, D, 1e-6f, nullptr, nullptr, mf, mf + D, L, p.T, s));
+      RGM_TRY(lin(p.xm, D, h->p("final_layer.linear.weight"), h->p("final_layer.linear.bias"), tok, po, M, po, D, 0, s));
+      RGM_TRY(unpatchify_launch(tok, eps_out, N, c.out_ch, H, c.width, s));
+    }
+  }
+  if (!g_eps) return RGM_OK;
+  // final layer backward: d tok = patchify(g_eps) (unpatchify is a permutation), d xm = d tok . W, dx = LN'(d xm)
+  RGM_TRY(patchify_launch(g_eps, p.pooln, N, c.out_ch, H, c.width, c.patch, s));
+  RGM_TRY(dgrad(h, "final_layer.linear.weight", p.pooln, po, p.dsmall, D, M, nullptr, 0, 0, s));
+  RGM_TRY(ln_mod_bwd_launch(p.dsmall, xf, nullptr, p.dx, M, D, 1e-6f, nullptr, mf + D, L, p.T, s));
+  RGM_TRY(grad_blocks_backward(h, p, s));
+  return grad_embed_backward(h, p, grad_x, s);
+}
+

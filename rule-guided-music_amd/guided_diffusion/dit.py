@@ -63,6 +63,7 @@ class _NativeDiT(nn.Module):
         self._handle = None
         self._dirty = True
         self._ws = None
+        self._gws = None      # workspace of the input-gradient calls (saved activations)
         self.register_load_state_dict_post_hook(lambda m, _: setattr(m, "_dirty", True))
         self.reset_parameters()
 
@@ -174,6 +175,51 @@ class DiTRotary(_NativeDiT):
             _rgm.check(_rgm.lib.rgm_dit_forward(self._handle, _rgm.ptr(x), _rgm.ptr(t), _rgm.ptr(yy), _rgm.ptr(out),
                                                 N, H, _rgm.ptr(ws), need, _rgm.current_stream()))
         return out
+
+    def _grad_ws(self, N, H, dev):
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_dit_enable_grad(self._handle))
+        need = _rgm.lib.rgm_dit_grad_workspace_bytes(self._handle, N, H)
+        if self._gws is None or self._gws.numel() < need or self._gws.device != dev:
+            self._gws = None
+            self._gws = torch.empty(need, dtype=torch.uint8, device=dev)
+        return self._gws, need
+
+    def vjp_forward(self, x, t, y=None):
+        """eps = forward(x, t, y), keeping the activations the input-gradient needs (DPS guidance, reference
+        condition_mean :415-465).  The first call keeps W^T copies of the Linear weights on the device."""
+        _rgm.require_cuda(x, t, y)
+        N, _, H, W = x.shape
+        assert W == self.input_size[1]
+        self._ensure_native(H * W // self.patch_size)
+        x = x.detach().to(torch.float32).contiguous()
+        t = self._as_index(t, torch.int64)
+        yy = self._as_index(y, torch.int32) if (self.num_classes and y is not None) else None
+        eps = torch.empty((N, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        ws, need = self._grad_ws(N, H, x.device)
+        with torch.cuda.device(x.device):
+            _rgm.check(_rgm.lib.rgm_dit_vjp(self._handle, _rgm.ptr(x), _rgm.ptr(t), _rgm.ptr(yy), None, _rgm.ptr(eps), None,
+                                            N, H, _rgm.ptr(ws), need, _rgm.current_stream()))
+        self._vjp_shape = (N, H)
+        return eps
+
+    def vjp_backward(self, g_eps):
+        """grad_x = (d eps / d x)^T g_eps for the forward of the last vjp_forward call."""
+        _rgm.require_cuda(g_eps)
+        N, H = self._vjp_shape
+        g = g_eps.detach().to(torch.float32).contiguous()
+        assert g.shape == (N, self.out_channels, H, self.input_size[1])
+        grad = torch.empty((N, self.in_channels, H, self.input_size[1]), dtype=torch.float32, device=g.device)
+        ws, need = self._grad_ws(N, H, g.device)
+        with torch.cuda.device(g.device):
+            _rgm.check(_rgm.lib.rgm_dit_vjp(self._handle, None, None, None, _rgm.ptr(g), None, _rgm.ptr(grad), N, H, _rgm.ptr(ws),
+                                            need, _rgm.current_stream()))
+        return grad
+
+    def vjp(self, x, t, y, g_eps):
+        """(eps, (d eps / d x)^T g_eps) -- what th.autograd.grad((model(x, t, y) * g_eps).sum(), x) returns in the reference."""
+        eps = self.vjp_forward(x, t, y)
+        return eps, self.vjp_backward(g_eps)
 
 
 class DiTRotaryClassifier(_NativeDiT):

@@ -61,6 +61,8 @@ def _load():
         "rgm_collage_merge": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]),
         "rgm_dit_grad_workspace_bytes": (sz, [vp, i32, i32]),
         "rgm_dit_cls_value_and_grad": (C.c_int, [vp, vp, vp, vp, i32, f32, vp, vp, i32, i32, vp, sz, vp]),
+        "rgm_dit_enable_grad": (C.c_int, [vp]),
+        "rgm_dit_vjp": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
         "rgm_rotary_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_split_rows": (C.c_int, [vp, vp, C.c_int64, i32, vp]),
         "rgm_gemm_split": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp]),

@@ -520,6 +520,53 @@ def g_edit():
     save("edit", **out)
 
 
+def g_dps():
+    """DPS guidance: the eps-network's input gradient via the reference's autograd, and full dps steps."""
+    print("[dps: eps-network VJP (autograd), nn_z0 guided steps]")
+    from functools import partial
+    from types import SimpleNamespace
+    rng = np.random.RandomState(1100)
+    out = {}
+    torch.set_grad_enabled(True)
+    for tag, arch, seed in (("sm", SM, 11), ("xl2", XL2, 1)):
+        m, sd = ref_dit(arch, seed)
+        x = rng.randn(2, 4, 128, 16).astype(F32)
+        t = np.array([37, 812], dtype=np.int64)
+        y = np.array([2, 0], dtype=np.int64)
+        g = rng.randn(2, 4, 128, 16).astype(F32)
+        xt = torch.from_numpy(x).requires_grad_(True)
+        eps = m(xt, torch.from_numpy(t), torch.from_numpy(y))
+        gx = torch.autograd.grad((eps * torch.from_numpy(g)).sum(), xt)[0]
+        out.update({f"{tag}.x": x, f"{tag}.t": t, f"{tag}.y": y, f"{tag}.g": g, f"{tag}.eps": eps.detach().numpy(),
+                    f"{tag}.grad": gx.numpy()})
+        print(f"    {tag}: |eps| {np.abs(eps.detach().numpy()).max():.3f}  |grad_x| {np.abs(gx.numpy()).max():.3f}")
+    # ---- dps steps (condition_mean dps branch) with nn_z0_mse_dummy on the "250" chain and the full chain
+    m, sd = ref_dit(SM, 11)
+    cm, csd = ref_cls(CLS2, 4)
+    mf = ref_model_fn(m, 3, True)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
+    cond = partial(rcf.composite_nn_zt, fns=["nn_z0_mse_dummy"], classifier_scales=[1.], classifiers=[cm], rule_names=["note_density"])
+    out.update({"x": x, "y": y, "rule": rule["note_density"]})
+    for tag, rs, ti in (("dps250", "250", 130), ("dps", "", 640)):
+        d = make_diffusion(rs)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        gk = SimpleNamespace(schedule=False, method="dps", step_size=1.5, nn=True, vae=False)
+        r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, cond_fn=cond,
+                       model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in rule.items()}},
+                       guidance_kwargs=gk, embed_model=None)
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].detach().numpy(),
+                    f"{tag}.pred_xstart": r["pred_xstart"].detach().numpy()})
+        print(f"    {tag}: sample range {r['sample'].min().item():.3f} .. {r['sample'].max().item():.3f}")
+    torch.set_grad_enabled(False)
+    save("dps", **out)
+
+
 def g_collage():
     print("[diff_collage]")
     m, sd = ref_dit(SM, 11)
@@ -617,7 +664,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -638,6 +685,8 @@ if __name__ == "__main__":
         g_collage()
     if "edit" in which:
         g_edit()
+    if "dps" in which:
+        g_dps()
     if "cli" in which:
         g_cli()
     if "e2e" in which:

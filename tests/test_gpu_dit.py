@@ -195,3 +195,24 @@ def test_cfg_model_fn_is_one_batched_forward_with_the_same_result(precision):
     assert rel(out.cpu().numpy(), ref.cpu().numpy()) < 2e-6
     out_dc = dc_model_fn(x.permute(0, 1, 3, 2), t, y, model=counted, num_classes=3, class_cond=True, cfg=True, w=4.0)
     assert rel(out_dc.permute(0, 1, 3, 2).cpu().numpy(), ref.cpu().numpy()) < 2e-6
+
+
+@pytest.mark.parametrize("tag,arch,seed", [("sm", dict(depth=2, hidden=384, heads=6, patch=8, in_ch=4, out_ch=4, num_classes=3), 11),
+                                           ("xl2", dict(depth=2, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4, num_classes=3), 1)])
+def test_eps_network_input_gradient_matches_autograd_golden(tag, arch, seed, precision):
+    """DPS: (d eps / d x)^T g through the saved-activation forward + dgrad chain vs the reference's autograd,
+    at the classifier width (head_dim 64) and at XL width (head_dim 72)."""
+    from gpu_util import dev, load_module, rel
+    from guided_diffusion.dit import DiTRotary
+    g = load_golden("dps")
+    m = load_module(DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=arch["hidden"], depth=arch["depth"],
+                              num_heads=arch["heads"], num_classes=3, learn_sigma=False), synth.dit_state_dict(seed, **arch))
+    x, t, y, gg = dev(g[f"{tag}.x"]), dev(g[f"{tag}.t"]), dev(g[f"{tag}.y"]), dev(g[f"{tag}.g"])
+    eps, grad = m.vjp(x, t, y, gg)
+    assert rel(eps.cpu().numpy(), g[f"{tag}.eps"]) < 2e-4
+    assert rel(grad.cpu().numpy(), g[f"{tag}.grad"]) < 5e-4
+    assert rel(eps.cpu().numpy(), m(x, t, y).cpu().numpy()) < (1e-6 if precision == "fp32" else 3e-5)
+    # the two phases may be separate calls (DPS forms g from eps in between); the gradient is linear in g
+    m.vjp_forward(x, t, y)
+    g2 = m.vjp_backward(2.0 * gg)
+    assert rel(g2.cpu().numpy(), 2.0 * grad.cpu().numpy()) < 1e-6
