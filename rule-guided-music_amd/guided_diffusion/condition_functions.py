@@ -4,7 +4,8 @@
 model_fn / dc_model_fn are thin: class-conditional call, null label (= num_classes) when unconditional,
 classifier-free guidance as one 2B-row forward.  The grad_nn_zt_* guidance functions call the classifier's
 fused value-and-input-gradient kernel chain (no autograd graph; weights are frozen at sampling time).
-DPS variants (nn_z0_*, rule_x0_*) are a 'next' row.
+DPS variants nn_z0_* are provided (value + input gradient from the same fused chain); rule_x0_* (through the VAE decoder)
+are a 'next' row.
 """
 import torch as th
 import torch.nn as nn
@@ -61,16 +62,71 @@ def grad_nn_zt_chord(x, t, y=None, rule=None, classifier_scale=10., classifier=n
     return _value_and_grad(classifier, x, t, rule, "chord_ce", classifier_scale)
 
 
-def _dps(*a, **k):
-    raise NotImplementedError("DPS guidance (nn_z0_* / rule_x0_*) is a 'next' row: SURVEY 8f.1")
+# ---- DPS log-probabilities on the x0 estimate (reference :88-138).  Each has a `_vag` twin returning (log_probs, d sum(log_probs)/dx)
+# from the classifier's fused value-and-input-gradient chain: the sampler's DPS branch needs both (condition_mean :415-465).
+def _zeros_t(x):
+    return th.zeros(x.shape[0], dtype=th.int64, device=x.device)
+
+
+def _mse_logp(logits, rule):
+    return -((logits - rule.to(logits.dtype)) ** 2).sum(dim=-1)
+
+
+def nn_z0_mse_dummy(x, t, y=None, rule=None, classifier_scale=0.1, classifier=nn.Identity()):
+    """-MSE(classifier(x0, 0), rule) * classifier_scale; t is a dummy (the classifier sees a clean latent, t = 0)."""
+    assert rule is not None
+    return _mse_logp(classifier(x, _zeros_t(x)), rule) * classifier_scale
+
+
+def nn_z0_mse(x, rule=None, classifier=nn.Identity()):
+    return _mse_logp(classifier(x, _zeros_t(x)), rule)
+
+
+def _chord_logp(chord_logits, rule, B):
+    lp = -th.nn.functional.cross_entropy(chord_logits.reshape(-1, chord_logits.shape[-1]), rule.reshape(-1).long(), reduction="none")
+    return lp.reshape(B, -1).mean(dim=-1)
+
+
+def nn_z0_chord_dummy(x, t, y=None, rule=None, classifier_scale=0.1, classifier=nn.Identity(), both=False):
+    if both:
+        raise NotImplementedError("both=True (key + chord) is unused by the shipped configs")
+    _, chord_logits = classifier(x, _zeros_t(x))
+    return _chord_logp(chord_logits, rule, x.shape[0]) * classifier_scale
+
+
+def _nn_z0_mse_dummy_vag(x, rule, classifier_scale, classifier):
+    logits, grad = classifier.value_and_grad(x, _zeros_t(x), rule, "mse", classifier_scale)
+    return _mse_logp(logits, rule) * classifier_scale, grad
+
+
+def _nn_z0_chord_dummy_vag(x, rule, classifier_scale, classifier):
+    nw = rule.reshape(x.shape[0], -1).shape[1]                         # mean over the chord windows
+    logits, grad = classifier.value_and_grad(x, _zeros_t(x), rule, "chord_ce", classifier_scale / nw)
+    return _chord_logp(logits, rule, x.shape[0]) * classifier_scale, grad
+
+
+def _dps_rule(*a, **k):
+    raise NotImplementedError("DPS through rule(decode(x0)) (rule_x0_*) needs the VAE decoder's backward: 'next' row SURVEY 8f.1")
 
 
 function_map = {
     "grad_nn_zt_mse": grad_nn_zt_mse,
     "grad_nn_zt_chord": grad_nn_zt_chord,
-    "nn_z0_chord_dummy": _dps, "nn_z0_mse_dummy": _dps, "nn_z0_mse": _dps,
-    "rule_x0_mse_dummy": _dps, "rule_x0_mse": _dps,
+    "nn_z0_chord_dummy": nn_z0_chord_dummy, "nn_z0_mse_dummy": nn_z0_mse_dummy, "nn_z0_mse": nn_z0_mse,
+    "rule_x0_mse_dummy": _dps_rule, "rule_x0_mse": _dps_rule,
 }
+_vag_map = {"nn_z0_mse_dummy": _nn_z0_mse_dummy_vag, "nn_z0_chord_dummy": _nn_z0_chord_dummy_vag}
+
+
+def composite_nn_zt_value_and_grad(x, t, y=None, rule=None, fns=None, classifier_scales=None, classifiers=None, rule_names=None):
+    """(log_probs (B,), d sum(log_probs) / dx) of composite_nn_zt for the DPS cond_fns -- what autograd provides in the reference."""
+    lp, grad = 0, 0
+    for fn, scale, cls, name in zip(fns, classifier_scales, classifiers, rule_names):
+        if fn not in _vag_map:
+            raise NotImplementedError(f"DPS guidance with cond_fn '{fn}'")
+        a, b = _vag_map[fn](x, rule[name], scale, cls)
+        lp, grad = lp + a, grad + b
+    return lp, grad
 
 
 def composite_nn_zt(x, t, y=None, rule=None, fns=None, classifier_scales=None, classifiers=None, rule_names=None):

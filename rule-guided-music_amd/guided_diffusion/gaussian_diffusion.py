@@ -19,7 +19,7 @@ What is different underneath (design, not a translation):
     all-gather of the (n, B) rule log-probabilities per step, winners regenerated locally from the
     shared Philox counters -- see scg_shard / SURVEY 8e.
 
-Not implemented here (SURVEY 8f "next"): DPS guidance (guidance.method == 'dps'),
+Not implemented here (SURVEY 8f "next"): DPS through rule(decode(x0)) (needs the VAE decoder's backward),
 learned variances, training losses.  They raise NotImplementedError instead of silently degrading.
 """
 import ctypes as C
@@ -244,6 +244,17 @@ class GaussianDiffusion:
         return out
 
     @staticmethod
+    def _add_noise(mean, g, noise):
+        """mean + g[b] * noise (the n = 1 case of the SCG candidate expansion kernel)"""
+        mean, noise = mean.float().contiguous(), noise.float().contiguous()
+        B = mean.shape[0]
+        out = th.empty_like(mean)
+        with th.cuda.device(mean.device):
+            _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean), _rgm.ptr(g.float().contiguous()), _rgm.ptr(noise), _rgm.ptr(out),
+                                                   1, B, mean.numel() // B, _rgm.current_stream()))
+        return out
+
+    @staticmethod
     def _edit_grad(cond_fn, x, ts, model_kwargs, edit_kwargs):
         """Classifier gradient on the editable latent rows only (reference condition_mean :408-414), zero elsewhere."""
         ls, le = int(edit_kwargs["l_start"]), int(edit_kwargs["l_end"])
@@ -284,9 +295,7 @@ class GaussianDiffusion:
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn is not supported by the fused native step")
         if edit_kwargs is not None and guidance_kwargs is not None and getattr(guidance_kwargs, "method", None) == "dps":
-            raise NotImplementedError("DPS guidance needs the eps-network backward: 'next' row SURVEY 8f.1")
-        if guidance_kwargs is not None and getattr(guidance_kwargs, "method", None) == "dps":
-            raise NotImplementedError("DPS guidance needs the eps-network backward: 'next' row SURVEY 8f.1")
+            raise NotImplementedError("DPS guidance under edit_kwargs (editable-slice gradient) is not provided")
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                         cond_fn=None, embed_model=None, edit_kwargs=None):
@@ -305,11 +314,46 @@ class GaussianDiffusion:
                        embed_model=None, edit_kwargs=None, scale_factor=1., record=False):
         """Classifier guidance on the mean: mean + variance * grad log p(y|x_t)   (non-DPS branch)."""
         self._reject_unsupported(None, edit_kwargs, guidance_kwargs)
+        if getattr(guidance_kwargs, "method", None) == "dps":
+            return self._dps_mean(cond_fn, p_mean_var, x, t, model_kwargs or {}, guidance_kwargs, model, embed_model)
         if edit_kwargs is None:
             grad = cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
         else:
             grad = self._edit_grad(cond_fn, x, self._scale_timesteps(t), model_kwargs or {}, edit_kwargs)
         return p_mean_var["mean"].float() + p_mean_var["variance"] * grad.float()
+
+    def _dps_mean(self, cond_fn, p_mean_var, x, t, model_kwargs, guidance_kwargs, model, embed_model):
+        """DPS (reference :415-465): mean + step_size * d log p(rule | x0_hat(x_t)) / d x_t / sqrt(-log p), where
+        x0_hat = c1 x_t - c2 eps(x_t).  The reference differentiates through the eps-network and the classifier with
+        autograd; here d/dx_t = c1 g + (d eps/d x_t)^T (-c2 g) with g = d log p / d x0 from the classifier's fused
+        value-and-gradient chain and the eps-network's VJP (rgm_dit_vjp) -- no autograd graph."""
+        import functools
+        from . import condition_functions as cf
+        assert model is not None
+        if embed_model is not None and not getattr(guidance_kwargs, "nn", True):
+            raise NotImplementedError("DPS through rule(decode(x0)) needs the VAE decoder's backward: 'next' row SURVEY 8f.1")
+        inner_c = cond_fn.model if hasattr(cond_fn, "map_ts") else cond_fn
+        if not (isinstance(inner_c, functools.partial) and inner_c.func is cf.composite_nn_zt):
+            raise NotImplementedError("DPS guidance expects cond_fn = partial(composite_nn_zt, ...)")
+        ts = self._scale_timesteps(t)
+        inner_m = model.model if hasattr(model, "map_ts") else model
+        ts_m = model.map_ts(ts) if hasattr(model, "map_ts") else ts
+        if not (isinstance(inner_m, functools.partial) and inner_m.func is cf.model_fn):
+            raise NotImplementedError("DPS guidance expects model = partial(model_fn, model=DiTRotary, ...)")
+        mk = inner_m.keywords
+        if mk.get("cfg", False):
+            raise NotImplementedError("DPS guidance with classifier-free guidance")
+        net = mk["model"]
+        y = model_kwargs.get("y") if mk.get("class_cond", True) else cf._null_labels(x, mk.get("num_classes", 3))
+        eps = net.vjp_forward(x, ts_m, y)
+        x0 = self._predict_xstart_from_eps(x, t, eps)
+        rule_kwargs = {k: v for k, v in model_kwargs.items() if k in ("y", "rule")}
+        log_probs, g0 = cf.composite_nn_zt_value_and_grad(x0, ts, **rule_kwargs, **inner_c.keywords)
+        c1 = self._per_sample(self.sqrt_recip_alphas_cumprod, t, x)
+        c2 = self._per_sample(self.sqrt_recipm1_alphas_cumprod, t, x)
+        grad = c1 * g0 + net.vjp_backward(-c2 * g0)
+        grad = grad / th.sqrt(-log_probs.view(x.shape[0], 1, 1, 1).float() + 1e-12)
+        return p_mean_var["mean"].float() + float(guidance_kwargs.step_size) * grad.float()
 
     def condition_score(self, cond_fn, p_mean_var, x, t, model_kwargs=None):
         """Classifier guidance in eps space (Song et al. 2020), as ddim_sample applies it."""
@@ -464,6 +508,17 @@ class GaussianDiffusion:
         eps = self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
+        if cond_fn is not None and use_guidance and getattr(guidance_kwargs, "method", None) == "dps":
+            if scg_kwargs is not None:
+                raise NotImplementedError("DPS guidance combined with SCG")
+            mean, x0, g = self._step("ddpm", x, eps, None, None, t, clip_denoised, want_g=True)
+            # the reference hands the UNWRAPPED model to condition_mean (:692-697): on a re-spaced chain the DPS forward
+            # runs at the un-mapped t, like scg_sample's.  Reproduced, not fixed.
+            mean = self.condition_mean(cond_fn, {"mean": mean}, x, t, model_kwargs=model_kwargs, guidance_kwargs=guidance_kwargs,
+                                       model=model, embed_model=embed_model, scale_factor=scale_factor, record=record)
+            noise = self._draw(x.shape, x.device)
+            sample = self._add_noise(mean, g, noise) if self._t0(t) > self.t_end else mean
+            return {"sample": sample, "pred_xstart": x0}
         grad = None
         if cond_fn is not None and (use_guidance or scg_kwargs is not None):
             if edit_kwargs is None:

@@ -81,6 +81,14 @@ class _WrappedModel:
         self.original_num_steps = original_num_steps
         self._maps = {}
 
+    def map_ts(self, ts):
+        """chain index -> the timestep the wrapped model is called with"""
+        key = (str(ts.device), ts.dtype)
+        if key not in self._maps:
+            self._maps[key] = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
+        new_ts = self._maps[key][ts]
+        return new_ts.float() * (1000.0 / self.original_num_steps) if self.rescale_timesteps else new_ts
+
     def __call__(self, x, ts, **kwargs):
         key = (str(ts.device), ts.dtype)
         if key not in self._maps:

@@ -134,3 +134,28 @@ def test_edit_loop_starts_from_the_noised_ground_truth(precision):
     out = d.p_sample_loop(_model_fn(m), (2, 4, 128, 16), clip_denoised=False, model_kwargs={"y": dev(g["y"])}, device="cuda",
                           edit_kwargs=_edit_kwargs(g))
     assert rel(out.cpu().numpy(), g["loop.sample"]) < 2e-4
+
+
+@pytest.mark.parametrize("tag,rs", [("dps250", "250"), ("dps", "")])
+def test_dps_guided_step_matches_reference(tag, rs, precision):
+    """DPS guidance (reference condition_mean :415-465 with nn_z0_mse_dummy): the reference differentiates
+    x0_hat(x_t) -> classifier with autograd; here the classifier's fused gradient feeds the eps-network's VJP."""
+    from functools import partial
+    from types import SimpleNamespace
+    from gpu_util import dev, load_module, rel
+    from guided_diffusion.condition_functions import composite_nn_zt
+    from guided_diffusion.dit import DiTRotaryClassifier
+    g = load_golden("dps")
+    m = _dit(SM, 11)
+    cls_arch = dict(depth=2, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=16)
+    cm = load_module(DiTRotaryClassifier(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6,
+                                         num_classes=16), synth.dit_state_dict(4, **cls_arch))
+    d = _diffusion(rs)
+    d.t_end = 0
+    _inject(d, g[f"{tag}.noise"])
+    cond = partial(composite_nn_zt, fns=["nn_z0_mse_dummy"], classifier_scales=[1.], classifiers=[cm], rule_names=["note_density"])
+    gk = SimpleNamespace(schedule=False, method="dps", step_size=1.5, nn=True, vae=False)
+    out = d.p_sample(_model_fn(m), dev(g["x"]), dev(g[f"{tag}.t"]), clip_denoised=False, cond_fn=cond,
+                     model_kwargs={"y": dev(g["y"]), "rule": {"note_density": dev(g["rule"])}}, guidance_kwargs=gk)
+    assert rel(out["sample"].cpu().numpy(), g[f"{tag}.sample"]) < 5e-4
+    assert rel(out["pred_xstart"].cpu().numpy(), g[f"{tag}.pred_xstart"]) < 5e-4
