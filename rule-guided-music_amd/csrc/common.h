@@ -5,6 +5,7 @@
 #include <stddef.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "../../include/rgm.h"
 
@@ -50,6 +51,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // every block of 32 elements becomes one 128-byte line [32 bf16 hi | 32 bf16 lo] (x ~= hi + lo, round-to-nearest each).
 // Returns the bf16 index of element `col`'s hi part within the row; its lo part is 32 further.
 __host__ __device__ __forceinline__ int split_idx(int col) { return ((col >> 5) << 6) + (col & 31); }
+
+// Timing experiments (elimination runs that produce WRONG results: no DMA, no MFMA, no stores ...) are compiled in only
+// with -DRGM_EXPERIMENTS (make EXTRA=-DRGM_EXPERIMENTS) and then selected by environment variables; a normal build
+// ignores those variables.
+#ifdef RGM_EXPERIMENTS
+#define RGM_EXP_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define RGM_EXP_ENV(name) 0
+#endif
 
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N) -- guarantees static register indexing where
 // `#pragma unroll` on a large nest is only a request

@@ -404,7 +404,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
     return gemm2_launch(g, s);
   };
-  static const int dit_exp = getenv("RGM_DIT_EXP") ? atoi(getenv("RGM_DIT_EXP")) : 0;   // timing experiments only (wrong results)
+  static const int dit_exp = RGM_EXP_ENV("RGM_DIT_EXP");   // timing experiments (common.h): 1 = fc1 without GELU/split, 2 = block-0 weights everywhere
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;

@@ -688,7 +688,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
 static char* g_zero_page = nullptr;
 static long long* g_dbg = nullptr;   // set by rgm_gemm2_dbg: stamped kernel variant (tools/gemm_stamp.py)
 // timing experiments only (wrong results): RGM_GEMM2_EXP=1 no DMA after the prologue, =2 DMA + barriers only
-static int g_exp = getenv("RGM_GEMM2_EXP") ? atoi(getenv("RGM_GEMM2_EXP")) : 0;
+static int g_exp = RGM_EXP_ENV("RGM_GEMM2_EXP");
 
 struct Prof2 {
   hipEvent_t a, b;

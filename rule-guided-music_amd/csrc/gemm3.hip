@@ -335,7 +335,7 @@ static int launch3(const GemmParams& p, hipStream_t s, int tile_id) {
   if (gx >= 8) gx &= ~7;                                     // keep a workgroup's tiles on its XCD (coords)
   dim3 grid(gx, 1, p.batch), block(NW * 128);
   const int rec = gemm2_prof_begin(40 + tile_id, 2.0 * p.M * (double)p.N * p.K * p.batch, s);
-  static const int g3_exp = getenv("RGM_GEMM3_EXP") ? atoi(getenv("RGM_GEMM3_EXP")) : 0;   // timing experiment: 1 = DMA + barriers only
+  static const int g3_exp = RGM_EXP_ENV("RGM_GEMM3_EXP");   // timing experiment (common.h): 1 = DMA + barriers only
   hipLaunchKernelGGL(k, grid, block, lds, s, p, (const char*)g3_zero_page, tm, tn, g3_exp);
   RGM_LAUNCH_CHECK();
   gemm2_prof_end(rec, s);
