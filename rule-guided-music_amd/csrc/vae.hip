@@ -523,6 +523,7 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
   g.bias = c.h->p(key + ".bias");
   g.res = res; g.ldres = Cout;
   g.aload = 1; g.H = H; g.W = H; g.Cin = Cin; g.logH = ilog2(H); g.logW = ilog2(H); g.ups = ups;
+  if (in_split) g.tile = RGM_EXP_ENV("RGM_CONV_TILE");   // 0 = gemm2's heuristic (timing experiments: common.h)
   return in_split ? gemm2_launch(g, c.s) : gemm_launch(g, c.s);
 }
 
