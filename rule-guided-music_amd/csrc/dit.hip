@@ -412,12 +412,13 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       // every producer (adaLN-LayerNorm, attention, fc1's GELU epilogue) writes split rows; all four GEMMs run on the
       // LDS-DMA kernel (gemm2.hip picks the tile)
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
-      RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, 0));
+      RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, RGM_EXP_ENV("RGM_QKV_TILE")));
       RGM_TRY(rotary_attention_fwd(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, 1));
       RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 0));
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
-      RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr, 0));
-      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, 0));
+      RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr,
+                   RGM_EXP_ENV("RGM_FC1_TILE")));
+      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, RGM_EXP_ENV("RGM_FC2_TILE")));
       continue;
     }
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));

@@ -766,7 +766,11 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     // once (B = 2: M = 512 rows) are latency-bound and take the loader/consumer kernel with its 3-stage ring
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128) * p.batch;
     const long long t64 = (long long)cdiv(p.M, 128) * cdiv(p.N, 64) * p.batch;
-    tile = t128 >= 512 ? 43 : (t64 >= 512 || p.aload ? 44 : 52);
+    // fraction of the CU-rounds a grid fills (512 resident 128x128 workgroups, 768 of 128x64): at B = 16 fc1 has
+    // 1152 / 2304 tiles = 2.25 (75 %) / 3.0 (100 %) rounds, qkv 864 / 1728 = 1.69 (84 %) / 2.25 (75 %)
+    auto fill = [](long long tiles, long long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
+    if (t128 >= 512 && fill(t128, 512) * 1.03 >= fill(t64, 768)) tile = 43;
+    else tile = (t64 >= 512 || p.aload) ? 44 : 52;
     // implicit-conv loader: the per-piece pixel bookkeeping pushes the cross-iteration pipeline at 128x128 over 256
     // registers (one wave per SIMD) -> the single-set pipeline (PIPE 1) there
     if (p.aload && tile == 43) tile = 21;
