@@ -432,7 +432,8 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
   return RGM_OK;
 }
 
-int check_ready(rgm_dit* h, int N, int H, size_t ws_bytes, const void* ws, Plan* plan) {
+// shapes and parameters of a call (everything but the workspace)
+int check_call(rgm_dit* h, int N, int H) {
   RGM_REQUIRE(h && N > 0 && H > 0, "dit: bad arguments");
   const rgm_dit_cfg& c = h->cfg;
   RGM_REQUIRE((H * c.width) % c.patch == 0, "dit: H*W=%d not divisible by patch", H * c.width);
@@ -445,6 +446,11 @@ int check_ready(rgm_dit* h, int N, int H, size_t ws_bytes, const void* ws, Plan*
     set_error("dit: %d parameters not set: %s", rgm_dit_missing_params(h), miss.c_str());
     return RGM_ERR_STATE;
   }
+  return RGM_OK;
+}
+
+int check_ready(rgm_dit* h, int N, int H, size_t ws_bytes, const void* ws, Plan* plan) {
+  RGM_TRY(check_call(h, N, H));
   *plan = make_plan(h, N, H, const_cast<void*>(ws), ws_bytes);
   if (plan->bytes > ws_bytes || ws == nullptr) {
     set_error("dit: workspace %zu bytes < required %zu", ws_bytes, plan->bytes);
@@ -704,8 +710,7 @@ extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int6
   RGM_REQUIRE(x && t && target && grad_x, "cls_value_and_grad: null tensor");
   RGM_REQUIRE((loss_kind == 0 && h->cfg.kind == 1) || (loss_kind == 1 && h->cfg.kind == 2),
               "cls_value_and_grad: loss_kind %d does not match classifier kind %d", loss_kind, h->cfg.kind);
-  Plan chk;
-  RGM_TRY(check_ready(h, N, H, (size_t)-1, (void*)256, &chk));   // shapes + parameters (its workspace test is moot here)
+  RGM_TRY(check_call(h, N, H));
   const rgm_dit_cfg& c = h->cfg;
   GPlan p = gplan(h, N, H, ws);
   if (!ws || p.bytes > ws_bytes) {
@@ -746,8 +751,7 @@ extern "C" int rgm_dit_vjp(rgm_dit* h, const float* x, const int64_t* t, const i
   RGM_REQUIRE((x && t) || (g_eps && grad_x), "dit_vjp: nothing to do");
   RGM_REQUIRE(!g_eps == !grad_x, "dit_vjp: g_eps and grad_x come together");
   RGM_REQUIRE(h->arena_t, "dit_vjp: call rgm_dit_enable_grad first (W^T copies are not kept by default)");
-  Plan chk;
-  RGM_TRY(check_ready(h, N, H, (size_t)-1, (void*)256, &chk));
+  RGM_TRY(check_call(h, N, H));
   const rgm_dit_cfg& c = h->cfg;
   GPlan p = gplan(h, N, H, ws);
   if (!ws || p.bytes > ws_bytes) {

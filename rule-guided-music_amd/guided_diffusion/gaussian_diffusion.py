@@ -408,8 +408,21 @@ class GaussianDiffusion:
             x0 = x0[:, :, int(edit_kwargs["l_start"]):int(edit_kwargs["l_end"]), :].contiguous()
         if embed_model is not None:
             x0 = _decode(x0, embed_model, scale_factor=scale_factor)
+        def rebuild(win):
+            """candidates win[b] of every sample b, regenerated from the shared noise stream: mean + g * noise[win[b], b]"""
+            if full_noise is not None:
+                wn = th.stack([full_noise[k, b] for b, k in enumerate(win)])
+            else:
+                wn = th.stack([self.noise.fill((E,), dev, offset=base + (k * B + b) * E) for b, k in enumerate(win)])
+            wn = wn.reshape((1,) + tuple(mean_pred.shape)).contiguous()
+            res = th.empty_like(mean_pred)
+            with th.cuda.device(dev):
+                _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(wn), _rgm.ptr(res), 1, B, E,
+                                                       _rgm.current_stream()))
+            return res
+
         if dc_kwargs is not None and getattr(dc_kwargs, "base", 0) > 0:
-            return self._scg_select_segments(cand, x0, mean_pred, model_kwargs, scg_kwargs, dc_kwargs, nl, n, k0, sharded)
+            return self._scg_select_segments(cand, x0, mean_pred, model_kwargs, scg_kwargs, dc_kwargs, nl, n, sharded, rebuild)
         total, each = None, {}
         for name, target in model_kwargs["rule"].items():
             gen = _extract_rule(name, x0)
@@ -430,31 +443,26 @@ class GaussianDiffusion:
                 # another rank: rebuild it here from the shared noise stream (zero traffic, SURVEY 8e option i).
                 _rgm.check(_rgm.lib.rgm_scg_select(None, _rgm.ptr(total_all), None, _rgm.ptr(max_ind), n, B, E,
                                                    _rgm.current_stream()))
-                win = max_ind.tolist()                                         # B ints: one sync per guided step
-                if full_noise is not None:
-                    wn = th.stack([full_noise[k, b] for b, k in enumerate(win)])
-                else:
-                    wn = th.stack([self.noise.fill((E,), dev, offset=base + (k * B + b) * E) for b, k in enumerate(win)])
-                wn = wn.reshape((1,) + tuple(mean_pred.shape)).contiguous()
-                _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(wn), _rgm.ptr(out),
-                                                       1, B, E, _rgm.current_stream()))
+                out = rebuild(max_ind.tolist())                                # B ints: one sync per guided step
         if record:
             self._record_scg(t, total_all, max_ind, each, x0, nl, B, record_freq, sharded)
         self.last_scg = {"total_log_prob": total_all, "max_ind": max_ind}
         return out
 
-    def _scg_select_segments(self, cand, x0_dec, mean_pred, model_kwargs, scg_kwargs, dc_kwargs, nl, n, k0, sharded):
-        """dc.base > 0 (reference :562-592): pick the best candidate independently per time segment."""
-        if sharded:
-            raise NotImplementedError("segment-wise SCG selection is not sharded yet; set diffusion.scg_shard=False")
+    def _scg_select_segments(self, cand, x0_dec, mean_pred, model_kwargs, scg_kwargs, dc_kwargs, nl, n, sharded, rebuild):
+        """dc.base > 0 (reference :562-592): pick the best candidate independently per time segment.
+
+        Sharded: every rank scores its nl candidates on every segment, ONE all-gather of the (nl, S*B) table gives all
+        ranks the same (n, S, B) scores and hence the same per-segment winners; a segment's winner may live on another
+        rank, so `rebuild(winners)` regenerates the winning candidates from the shared noise stream (no latent traffic)."""
         B = mean_pred.shape[0]
-        cand_v = cand.view((n, B) + tuple(mean_pred.shape[1:]))
+        dev = mean_pred.device
         total_len = x0_dec.shape[-1]
         seg = dc_kwargs.base * 8
         rule_base = dc_kwargs.base // 16
-        pieces = []
-        for i, s0 in enumerate(range(0, total_len, seg)):
-            s1 = min(s0 + seg, total_len)
+        bounds = [(s0, min(s0 + seg, total_len)) for s0 in range(0, total_len, seg)]
+        totals = []
+        for i, (s0, s1) in enumerate(bounds):
             cur = x0_dec[:, :, :, s0:s1].contiguous()
             total = None
             for name, target in model_kwargs["rule"].items():
@@ -465,15 +473,32 @@ class GaussianDiffusion:
                     target = th.cat((target[:, :half][:, sl], target[:, half:][:, sl]), dim=-1)
                 elif "chord" in name:
                     target = target[:, i * rule_base: min((i + 1) * rule_base, target.shape[-1])]
-                lp = -LOSS_DICT[name](gen, target.repeat(n, 1)) * scg_kwargs.get(name, 1.)
+                lp = -LOSS_DICT[name](gen, target.repeat(nl, 1)) * scg_kwargs.get(name, 1.)
                 total = lp if total is None else total + lp
-            piece_src = cand_v[:, :, :, s0 // 8: s1 // 8].contiguous()
-            E = piece_src.numel() // (n * B)
-            out = th.empty((B,) + tuple(piece_src.shape[2:]), dtype=th.float32, device=cand.device)
-            with th.cuda.device(cand.device):
-                _rgm.check(_rgm.lib.rgm_scg_select(_rgm.ptr(piece_src), _rgm.ptr(total.float().view(n, B).contiguous()),
-                                                   _rgm.ptr(out), None, n, B, E, _rgm.current_stream()))
-            pieces.append(out)
+            totals.append(total.float().view(nl, B))
+        S = len(bounds)
+        local = th.stack(totals, dim=1).reshape(nl, S * B).contiguous()          # [k][segment][b]
+        total_all = (scg_shard.gather_totals(local) if sharded else local).view(n, S, B)
+        max_ind = th.empty((S, B), dtype=th.int64, device=dev)
+        pieces = []
+        cand_v = None if sharded else cand.view((n, B) + tuple(mean_pred.shape[1:]))
+        with th.cuda.device(dev):
+            for i, (s0, s1) in enumerate(bounds):
+                tab = total_all[:, i, :].contiguous()
+                if sharded:
+                    _rgm.check(_rgm.lib.rgm_scg_select(None, _rgm.ptr(tab), None, _rgm.ptr(max_ind[i]), n, B, 1, _rgm.current_stream()))
+                    continue
+                piece_src = cand_v[:, :, :, s0 // 8: s1 // 8].contiguous()
+                E = piece_src.numel() // (n * B)
+                out = th.empty((B,) + tuple(piece_src.shape[2:]), dtype=th.float32, device=dev)
+                _rgm.check(_rgm.lib.rgm_scg_select(_rgm.ptr(piece_src), _rgm.ptr(tab), _rgm.ptr(out), _rgm.ptr(max_ind[i]), n, B, E,
+                                                   _rgm.current_stream()))
+                pieces.append(out)
+        if sharded:
+            wins = max_ind.tolist()                                              # S x B ints: one sync per guided step
+            for i, (s0, s1) in enumerate(bounds):
+                pieces.append(rebuild(wins[i])[:, :, s0 // 8: s1 // 8])
+        self.last_scg = {"total_log_prob": total_all, "max_ind": max_ind}
         return th.cat(pieces, dim=-2)
 
     def _record_scg(self, t, total, max_ind, each, x0, nl, B, record_freq, sharded):

@@ -236,3 +236,42 @@ def test_sharded_scg_rank_sees_same_winner_and_rebuilds_it(monkeypatch):
         assert torch.equal(idx, ref_idx) and torch.equal(total, ref_total)
         assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt winner differs"
     assert len(set(ref_idx.tolist())) >= 1
+
+
+def test_sharded_segmentwise_scg_matches_unsharded(monkeypatch):
+    """dc.base > 0 (per-segment winners, reference :562-592) under candidate sharding: rank r scores its half of the
+    candidates on every segment, the stand-in all-gather completes the (n, S, B) table, every rank picks the same
+    per-segment winners and rebuilds them -- local or not -- from the Philox counters: bit-identical to one GPU."""
+    from types import SimpleNamespace
+    from gpu_util import dev
+    from rgm import scg_shard
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    g = load_golden("steps")
+    m, vae = _dit(SM, 11), _vae(2)
+    tgt = {"pitch_hist": dev(g["scg.target.pitch_hist"]), "note_density": dev(g["scg.target.note_density"])}
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance", dc=SimpleNamespace(base=64))
+    scg = {"num_samples": 8, "pitch_hist": 40., "note_density": 1.}
+
+    def run(d):
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=321)
+        out = d.p_sample(_model_fn(m), dev(g["x"]), dev(g["scg.t"]), clip_denoised=False,
+                         model_kwargs={"y": dev(g["y"]), "rule": tgt}, embed_model=vae, scale_factor=1.2465,
+                         guidance_kwargs=guid, scg_kwargs=scg)
+        return out["sample"], d.last_scg["total_log_prob"].clone(), d.last_scg["max_ind"].clone()
+
+    ref_sample, ref_total, ref_idx = run(_diffusion(""))
+    assert ref_total.shape == (8, 2, 2) and ref_idx.shape == (2, 2)               # (n, segments, B), (segments, B)
+    for rank in (0, 1):
+        monkeypatch.setattr(scg_shard, "partition", lambda n, r=rank: (r * n // 2, n // 2, True))
+
+        def fake_gather(local, r=rank):
+            mine = ref_total[r * 4:(r + 1) * 4].reshape(4, -1)
+            assert torch.equal(local, mine)
+            parts = [ref_total[:4].reshape(4, -1), ref_total[4:].reshape(4, -1)]
+            parts[r] = local
+            return torch.cat(parts, dim=0)
+        monkeypatch.setattr(scg_shard, "gather_totals", fake_gather)
+        s, total, idx = run(_diffusion(""))
+        assert torch.equal(idx, ref_idx) and torch.equal(total, ref_total)
+        assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
