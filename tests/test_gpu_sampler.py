@@ -275,3 +275,25 @@ def test_sharded_segmentwise_scg_matches_unsharded(monkeypatch):
         s, total, idx = run(_diffusion(""))
         assert torch.equal(idx, ref_idx) and torch.equal(total, ref_total)
         assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
+
+
+def test_full_size_batch_is_row_independent_of_the_small_pinned_batches(precision):
+    """BASELINE config 2 runs B = 16 (and SCG decodes hundreds of squares at once); the goldens pin B = 2.  Size-independent
+    property that carries the parity over: every sample of the big batch equals the same sample computed in a batch of 2
+    (tile shapes, grids and kernels differ with the batch size; the per-row arithmetic must not)."""
+    from gpu_util import dev, rel
+    arch = dict(depth=28, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4, num_classes=3)
+    m = _dit(arch, 1, final_std=0.3 / 1152 ** 0.5, device_gen=True)
+    rng = np.random.RandomState(77)
+    x = dev(rng.randn(16, 4, 128, 16).astype(F32))
+    t = dev(rng.randint(0, 1000, size=16).astype(np.int64))
+    y = dev(rng.randint(0, 3, size=16).astype(np.int64))
+    big = m(x, t, y)
+    for i in (0, 6, 14):
+        small = m(x[i:i + 2].contiguous(), t[i:i + 2].contiguous(), y[i:i + 2].contiguous())
+        assert rel(big[i:i + 2].cpu().numpy(), small.cpu().numpy()) < 2e-6, i
+    vae = _vae(2)
+    z = dev(rng.randn(64, 4, 16, 16).astype(F32))
+    dec = vae.decode(z)
+    for i in (0, 31, 62):
+        assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < 2e-6, i
