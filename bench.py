@@ -260,6 +260,10 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--simulate-ranks", type=int, default=0,
+                    help="--workload scg on ONE GPU: time the per-rank work of an R-GPU run (this process scores candidates "
+                         "[0, n/R) like rank 0 would, the all-gather is a local stand-in): an estimate of the sharded step "
+                         "time without the fabric; marked 'simulated' in the JSON, never the headline metric")
     ap.add_argument("--precision", default=os.environ.get("RGM_BENCH_PRECISION", "bf16x3_presplit"), choices=["fp32", "bf16x3", "bf16x3_presplit"],
                     help="GEMM arithmetic: bf16x3 split (default; fp32-grade: 2.5e-6 latent error on the 50-step golden, "
                          "parity suite runs in both modes) or exact fp32 MFMA")
@@ -282,6 +286,12 @@ def main():
     torch.manual_seed(0)
     batch = args.batch or {"c2": 16, "c3": 32, "scg": 4}[args.workload]
     work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload}[args.workload](device, batch)
+    if args.simulate_ranks > 1:
+        assert args.workload == "scg" and world == 1, "--simulate-ranks is a single-GPU SCG experiment"
+        from rgm import scg_shard
+        Rn = args.simulate_ranks
+        scg_shard.partition = lambda n, world_size=None, rank=None: (0, n // Rn, True) if n % Rn == 0 else (0, n, False)
+        scg_shard.gather_totals = lambda local: local.repeat(Rn, 1)     # same table shape and selection work as the real all-gather
     for _ in range(args.warmup):
         work.step()
 
@@ -319,7 +329,8 @@ def main():
             "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else f"f32 via {args.precision} split (3 bf16 MFMA per product, fp32 accumulate)",
             "data": "synthetic",
-            "config": {"workload": work.name, "batch_per_gpu": batch, "sample_steps_per_s": round(units * batch / dt, 2),
+            "config": {"workload": work.name + (f" [SIMULATED rank 0 of {args.simulate_ranks}: per-rank work only, no fabric]"
+                                                if args.simulate_ranks > 1 else ""), "batch_per_gpu": batch, "sample_steps_per_s": round(units * batch / dt, 2),
                        "weights": "synthetic random-init (rgm.synth seed 1; adaLN/final layers re-randomised)",
                        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
                        "algorithmic_tflops": round(work.flop_per_step * units / dt / 1e12, 2)},
