@@ -752,6 +752,76 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   return RGM_OK;
 }
 
+// ---- deterministic split-K for small grids (M <= ~1k rows: B = 2..8 latents, the per-rank SCG batches).  A K-split IS a
+// batched GEMM: slice s reads A / B at column offset s*K/S (a stride of K/S floats, rows keep their ld) and writes its raw
+// partial to P[s][M][N]; this kernel then sums the S partials in a fixed order and applies the epilogue (bias, act, gate,
+// residual, split-row output) -- no atomics, bit-reproducible.  One float4 per thread.
+__global__ void splitk_reduce_kernel(const float* __restrict__ P, GemmParams p, int S) {
+  const long long i4 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const int nq = p.N >> 2;
+  if (i4 >= (long long)p.M * nq) return;
+  const int row = (int)(i4 / nq), col = (int)(i4 - (long long)row * nq) * 4;
+  const long long MN = (long long)p.M * p.N;
+  float4 a = *reinterpret_cast<const float4*>(P + (long long)row * p.N + col);
+  for (int sidx = 1; sidx < S; ++sidx) {
+    const float4 b = *reinterpret_cast<const float4*>(P + sidx * MN + (long long)row * p.N + col);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+  float v[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+  if (p.bias) {
+    const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+    v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+  }
+  if (p.act == 1) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = silu_f(v[q]);
+  } else if (p.act == 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = gelu_tanh_fast_f(v[q]);
+  }
+  if (p.gate) {
+    const float4 g = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+    v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+  }
+  if (p.res) {
+    const float4 r = *reinterpret_cast<const float4*>(p.res + (long long)row * p.ldres + col);
+    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+  }
+  if (p.out_split) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      hi[q] = (__bf16)v[q];
+      lo[q] = (__bf16)(v[q] - (float)hi[q]);
+    }
+    __bf16* rowp = reinterpret_cast<__bf16*>(p.C + (long long)row * p.ldc);
+    *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+    *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+  } else {
+    *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
+static float* g_splitk_buf = nullptr;      // partial sums, grown on demand (rare: hipMalloc synchronises)
+static size_t g_splitk_cap = 0;
+
+// number of K slices for a dense, unbatched GEMM whose 128x64 grid leaves most of the chip idle; 1 = do not split
+static int splitk_factor(const GemmParams& p) {
+  if (p.aload || p.batch != 1 || p.tile != 0 || (p.N & 3) || (p.ldc & 3) || (p.ldres & 3) || (p.gate_ld & 3)) return 1;
+  if ((((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) != 0) return 1;
+  const long long t64 = (long long)cdiv(p.M, 128) * cdiv(p.N, 64);
+  const int KT = p.K >> 5;
+  if (t64 >= 384 || KT < 72) return 1;          // measured (tools/gemm_sweep.py, SWEEP_SHAPES=small): pays for K = 4608 only
+  int best = 1;
+  for (int S = 2; S <= 8; ++S) {
+    if (KT % S != 0 || KT / S < 9) continue;
+    best = S;
+    if (t64 * S >= 512) break;
+  }
+  return best;
+}
+
 // A and B in split-row format (see top).  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 5 = 256x128 (8 waves)
 int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && (p.K & 31) == 0, "gemm2: bad shape M=%d N=%d K=%d (K%%32)", p.M, p.N, p.K);
@@ -759,6 +829,29 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm2: operands must be 16-byte aligned with ld%%4==0");
   RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
+  const int S = splitk_factor(p);
+  if (S > 1) {
+    const size_t need = (size_t)S * p.M * p.N * sizeof(float);
+    if (need > g_splitk_cap) {
+      if (g_splitk_buf) RGM_CHECK_HIP(hipFree(g_splitk_buf));
+      g_splitk_buf = nullptr;
+      g_splitk_cap = 0;
+      RGM_CHECK_HIP(hipMalloc(&g_splitk_buf, need));
+      g_splitk_cap = need;
+    }
+    GemmParams q = p;                     // the K slices as a batch: raw partial sums, no epilogue
+    q.K = p.K / S;
+    q.batch = S;
+    q.sA = q.K; q.sB = q.K;
+    q.C = g_splitk_buf; q.ldc = p.N; q.sC = (long long)p.M * p.N;
+    q.bias = nullptr; q.act = 0; q.alpha = 1.0f; q.gate = nullptr; q.res = nullptr; q.out_split = 0;
+    q.tile = 44;
+    RGM_TRY(gemm2_launch(q, s));
+    const long long total4 = (long long)p.M * (p.N >> 2);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)g_splitk_buf, p, S);
+    RGM_LAUNCH_CHECK();
+    return RGM_OK;
+  }
   int tile = p.tile;
   if (tile == 0) {
     // tools/gemm_sweep.py on MI355X: cross-iteration pipeline (PIPE 3) at 128x128 (2 workgroups per CU) once the grid
@@ -770,7 +863,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     // 1152 / 2304 tiles = 2.25 (75 %) / 3.0 (100 %) rounds, qkv 864 / 1728 = 1.69 (84 %) / 2.25 (75 %)
     auto fill = [](long long tiles, long long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     if (t128 >= 512 && fill(t128, 512) * 1.03 >= fill(t64, 768)) tile = 43;
-    else tile = (t64 >= 512 || p.aload) ? 44 : 52;
+    else tile = (t64 >= 384 || p.aload) ? 44 : (t64 >= 256 ? 46 : 52);   // small grids: SWEEP_SHAPES=small sweep
     // implicit-conv loader: the per-piece pixel bookkeeping pushes the cross-iteration pipeline at 128x128 over 256
     // registers (one wave per SIMD) -> the single-set pipeline (PIPE 1) there
     if (p.aload && tile == 43) tile = 21;

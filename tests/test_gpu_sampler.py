@@ -291,7 +291,8 @@ def test_full_size_batch_is_row_independent_of_the_small_pinned_batches(precisio
     big = m(x, t, y)
     for i in (0, 6, 14):
         small = m(x[i:i + 2].contiguous(), t[i:i + 2].contiguous(), y[i:i + 2].contiguous())
-        assert rel(big[i:i + 2].cpu().numpy(), small.cpu().numpy()) < 2e-6, i
+        # presplit mode: the batch-of-2 GEMMs with K = 4608 run split-K (a different, still deterministic, summation order)
+        assert rel(big[i:i + 2].cpu().numpy(), small.cpu().numpy()) < (3e-5 if precision == "bf16x3_presplit" else 2e-6), i
     vae = _vae(2)
     z = dev(rng.randn(64, 4, 16, 16).astype(F32))
     dec = vae.decode(z)

@@ -13,6 +13,9 @@ from rgm import native as R  # noqa: E402
 
 if os.environ.get("SWEEP_SHAPES") == "big":
     SHAPES_OVERRIDE = [("fc1", 4096, 4608, 1152), ("fc1_scg", 16384, 4608, 1152), ("fc2_scg", 16384, 1152, 4608)]
+elif os.environ.get("SWEEP_SHAPES") == "small":      # B = 2 / 4 / 8 latents
+    SHAPES_OVERRIDE = [(f"{n}_b{b}", 256 * b, N, K) for b in (2, 4, 8)
+                       for n, N, K in (("qkv", 3456, 1152), ("proj", 1152, 1152), ("fc1", 4608, 1152), ("fc2", 1152, 4608))]
 else:
     SHAPES_OVERRIDE = None
 SHAPES = [("qkv", 4096, 3456, 1152), ("proj", 4096, 1152, 1152), ("fc1", 4096, 4608, 1152), ("fc2", 4096, 1152, 4608),
