@@ -19,16 +19,6 @@ namespace rgm {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float exp_neg_x3(float x) {   // exp(x), x <= 0, no range-check compares (see attention.hip)
-  const float L2E_HI = 1.44269502162933349609375f, L2E_LO = 1.925963033500011e-8f;
-  x = fmaxf(x, -104.0f);
-  const float t = x * L2E_HI;
-  float r = fmaf(x, L2E_HI, -t);
-  r = fmaf(x, L2E_LO, r);
-  const float e = __builtin_amdgcn_exp2f(t);
-  return fmaf(e, r * 0.693147182464599609375f, e);
-}
-
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -106,7 +96,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   __syncthreads();
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const float scale = rsqrtf((float)HD);
+  // scores are kept in the log2 domain (log2(e) folded into the query scale): p = 2^(s - max) is ONE v_exp_f32 per element
+  // instead of the 8-op double-float exp of the fp32 kernel (its ~2e-7 argument error is 100x below the bf16x3 product error)
+  const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;
   const int nqt = (T + 31) >> 5;
 
   for (int qt = wave; qt < nqt; qt += 8) {
@@ -178,7 +170,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const float pv = exp_neg_x3(sacc[kt][e] - mx);
+        const float pv = __builtin_amdgcn_exp2f(sacc[kt][e] - mx);   // masked scores: 2^(-inf) = 0
         sacc[kt][e] = pv;
         sum += pv;
       }
