@@ -128,6 +128,33 @@ class SCGWorkload:
         self.x = out["sample"]
 
 
+class LongWorkload(SCGWorkload):
+    """BASELINE config[4]: a 40.96 s sequence -- linear DiffCollage over 7 windows of 128 latent rows with overlap 64
+    (latent 4 x 512 x 16) -- with SCG (n = 16) scoring rule(decode(x0)) on the 4096-frame roll."""
+    name = ("C5 DiffCollage (linear, 7 windows, overlap 64) + SCG guided DDPM step, DiTRotary_XL_8 + KL-VAE decode of 32 squares "
+            "per candidate + pitch_hist/note_density, n=16 (sharded over GPUs)")
+
+    def __init__(self, device, batch):
+        from functools import partial
+        import diff_collage as dc
+        from guided_diffusion.condition_functions import dc_model_fn
+        super().__init__(device, batch)
+        model = self.model
+
+        def eps_fn(x, t, y=None):            # the backbone takes (4, time, pitch)
+            return model(x.permute(0, 1, 3, 2).contiguous(), t, y=y).permute(0, 1, 3, 2)
+        worker = dc.CondIndSimple((4, 16, 128), eps_fn, 7, overlap_size=64)
+        self.fn = partial(dc_model_fn, model=worker.eps_scalar_t_fn, num_classes=3, class_cond=True, cfg=False, w=0.)
+        H = worker.shape[2]
+        self.x = self.d._draw((batch, 4, H, 16), device)
+        nw = H * 8 // 128
+        ph = torch.tensor([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], device=device).repeat(batch, 1)
+        nd = torch.tensor([3.] * nw + [3.] * nw, device=device).repeat(batch, 1)
+        self.kw = {"y": torch.ones(batch, dtype=torch.int64, device=device), "rule": {"pitch_hist": ph, "note_density": nd}}
+        windows = 7 + 6                       # 7 full windows + 6 overlap halves evaluated by the collage
+        self.flop_per_step = batch * ((1 + 16) * windows * DIT_GFLOP_PER_SAMPLE + 16 * (H // 16) * VAE_GFLOP_PER_TILE) * 1e9
+
+
 class C3Workload:
     """Classifier guidance only (config[2]): p_sample on the '250' chain, batch 32, one DiTRotary-S/8-cls (note density)."""
     name = "C3 classifier-guided DDPM step ('250' chain), DiTRotary_XL_8 + DiTRotary-S/8-cls value-and-grad, batch 32"
@@ -258,7 +285,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg", "long"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="--workload scg on ONE GPU: time the per-rank work of an R-GPU run (this process scores candidates "
@@ -284,10 +311,10 @@ def main():
     from rgm import native as R
     R.set_gemm_precision(args.precision)
     torch.manual_seed(0)
-    batch = args.batch or {"c2": 16, "c3": 32, "scg": 4}[args.workload]
-    work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload}[args.workload](device, batch)
+    batch = args.batch or {"c2": 16, "c3": 32, "scg": 4, "long": 1}[args.workload]
+    work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload, "long": LongWorkload}[args.workload](device, batch)
     if args.simulate_ranks > 1:
-        assert args.workload == "scg" and world == 1, "--simulate-ranks is a single-GPU SCG experiment"
+        assert args.workload in ("scg", "long") and world == 1, "--simulate-ranks is a single-GPU SCG experiment"
         from rgm import scg_shard
         Rn = args.simulate_ranks
         scg_shard.partition = lambda n, world_size=None, rank=None: (0, n // Rn, True) if n % Rn == 0 else (0, n, False)
@@ -320,7 +347,7 @@ def main():
         log("roofline pass failed:", repr(e))
         roof = None
     if rank == 0:
-        sharded = args.workload == "scg"
+        sharded = args.workload in ("scg", "long")
         units = args.steps * (1 if sharded else world)           # SCG shards ONE chain; C2 runs one chain per GPU
         res = {
             "metric": "denoising steps/sec (whole node), DiTRotary_XL_8 4x128x16",
