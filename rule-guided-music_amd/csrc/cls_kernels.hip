@@ -94,29 +94,59 @@ int ln_mod_bwd_launch(const float* dy, const float* x, const float* res, float* 
   return RGM_OK;
 }
 
-__global__ void gate_rows_kernel(const float* __restrict__ dx, const float* __restrict__ gate, float* __restrict__ out,
-                                 long long total, int D, int gate_ld, int rows_per_batch) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const long long row = i / D;
-  const int c = (int)(i - row * D);
-  out[i] = dx[i] * gate[(row / rows_per_batch) * gate_ld + c];
+// write 4 consecutive values of a row either as fp32 or in the split-row format of the pre-split GEMMs (common.h split_idx)
+__device__ __forceinline__ void store4(float* __restrict__ out, long long row, int D, int c, float4 v, int out_split) {
+  if (out_split) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    __bf16* rp = reinterpret_cast<__bf16*>(out + row * D);
+    *reinterpret_cast<bf16x4*>(rp + split_idx(c)) = hi;
+    *reinterpret_cast<bf16x4*>(rp + split_idx(c) + 32) = lo;
+  } else {
+    *reinterpret_cast<float4*>(out + row * D + c) = v;
+  }
 }
-int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int D, int gate_ld, int rows_per_batch, hipStream_t s) {
-  const long long total = (long long)M * D;
-  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dx, gate, out, total, D, gate_ld, rows_per_batch);
+
+__global__ void gate_rows_kernel(const float* __restrict__ dx, const float* __restrict__ gate, float* __restrict__ out,
+                                 long long total4, int D, int gate_ld, int rows_per_batch, int out_split) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int q = D >> 2;
+  const long long row = i / q;
+  const int c = (int)(i - row * q) * 4;
+  const float4 a = *reinterpret_cast<const float4*>(dx + row * D + c);
+  const float4 g = *reinterpret_cast<const float4*>(gate + (row / rows_per_batch) * gate_ld + c);
+  store4(out, row, D, c, make_float4(a.x * g.x, a.y * g.y, a.z * g.z, a.w * g.w), out_split);
+}
+int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int D, int gate_ld, int rows_per_batch, hipStream_t s,
+                     int out_split) {
+  RGM_REQUIRE((D & 3) == 0 && (gate_ld & 3) == 0 && (!out_split || (D & 31) == 0), "gate_rows: D=%d gate_ld=%d", D, gate_ld);
+  const long long total4 = (long long)M * (D >> 2);
+  hipLaunchKernelGGL(gate_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, dx, gate, out, total4, D, gate_ld,
+                     rows_per_batch, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
-__global__ void act_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long long total, int act) {
+// out = act(in) over rows of D values (act 1 silu, 2 gelu-tanh); optionally written as split rows
+__global__ void act_rows_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4, int D, int act, int out_split) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const float v = in[i];
-  out[i] = act == 1 ? silu_f(v) : gelu_tanh_f(v);
+  if (i >= total4) return;
+  const int q = D >> 2;
+  const long long row = i / q;
+  const int c = (int)(i - row * q) * 4;
+  const float4 v = *reinterpret_cast<const float4*>(in + row * D + c);
+  const float4 r = act == 1 ? make_float4(silu_f(v.x), silu_f(v.y), silu_f(v.z), silu_f(v.w))
+                            : make_float4(gelu_tanh_f(v.x), gelu_tanh_f(v.y), gelu_tanh_f(v.z), gelu_tanh_f(v.w));
+  store4(out, row, D, c, r, out_split);
 }
-int act_rows_launch(const float* in, float* out, long long total, int act, hipStream_t s) {
-  hipLaunchKernelGGL(act_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, in, out, total, act);
+int act_rows_launch(const float* in, float* out, long long rows, int D, int act, hipStream_t s, int out_split) {
+  RGM_REQUIRE((D & 3) == 0 && (!out_split || (D & 31) == 0), "act_rows: D=%d", D);
+  const long long total4 = rows * (D >> 2);
+  hipLaunchKernelGGL(act_rows_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, in, out, total4, D, act, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -28,8 +28,9 @@ int fill_cls_launch(const float* cls, float* x, int N, int T, int D, hipStream_t
 int pool_rows_launch(const float* x, float* out, int N, int T, int D, int first, int groups, int per, hipStream_t s);
 int ln_mod_bwd_launch(const float* dy, const float* x, const float* res, float* out, int M, int D, float eps,
                       const float* weight, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s);
-int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int D, int gate_ld, int rows_per_batch, hipStream_t s);
-int act_rows_launch(const float* in, float* out, long long total, int act, hipStream_t s);
+int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int D, int gate_ld, int rows_per_batch, hipStream_t s,
+                     int out_split = 0);
+int act_rows_launch(const float* in, float* out, long long rows, int D, int act, hipStream_t s, int out_split = 0);
 int loss_grad_launch(const float* logits, const void* target, float* dl, int rows, int K, int Kp, float scale, int kind, hipStream_t s);
 int scatter_rows_launch(const float* src, float* dx, int N, int T, int D, int first, int groups, int per, hipStream_t s);
 }  // namespace rgm
@@ -83,6 +84,20 @@ static void add_t_slot(rgm_dit* h, const std::string& key, int out_f, int in_f) 
   s.t_ld = ld;
   h->slots[key + ".T"] = s;
   h->arena_floats += s.numel;
+}
+
+// split-row copy of a ".T" slot (W^T [in][ld]): B operand of the pre-split dgrad GEMM dX = dY . W
+static void add_ts_slot(rgm_dit* h, const std::string& key, bool in_t = false, size_t* cursor = nullptr) {
+  const Slot& t = h->slots.at(key + ".T");
+  Slot s;
+  s.off = cursor ? *cursor : h->arena_floats;
+  s.numel = t.numel;
+  s.set = true;
+  s.t_rows = t.t_rows; s.t_cols = t.t_cols; s.t_ld = t.t_ld;
+  s.in_t = in_t;
+  h->slots[key + ".TS"] = s;
+  if (cursor) *cursor += s.numel;
+  else h->arena_floats += s.numel;
 }
 
 // split-row copy (gemm2.hip format) of a Linear weight [out][in]: B operand of the pre-split bf16x3 GEMM path
@@ -179,6 +194,7 @@ extern "C" int rgm_dit_create(const rgm_dit_cfg* c, rgm_dit** out) {
       add_t_slot(h, b + "attn.proj.weight", Di, Di);
       add_t_slot(h, b + "mlp.fc1.weight", 4 * Di, Di);
       add_t_slot(h, b + "mlp.fc2.weight", Di, 4 * Di);
+      for (const char* w : {"attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"}) add_ts_slot(h, b + w);
     }
     add_t_slot(h, "classifier_head.0.weight", Di / 4, Di);
     add_t_slot(h, "classifier_head.2.weight", c->n_out, Di / 4);
@@ -225,6 +241,8 @@ extern "C" int rgm_dit_set_param(rgm_dit* h, const char* key, const void* dptr, 
   if (tt != h->slots.end()) {
     const Slot& ts = tt->second;
     RGM_TRY(transpose_launch(h->arena + it->second.off, h->sp(ts), ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
+    auto t2 = h->slots.find(k + ".TS");
+    if (t2 != h->slots.end()) RGM_TRY(split_rows_launch(h->sp(ts), h->sp(t2->second), ts.t_rows, ts.t_ld, ts.t_ld, ts.t_ld, 0));
     RGM_CHECK_HIP(hipStreamSynchronize(0));
   }
   auto ss = h->slots.find(k + ".S");
@@ -288,6 +306,10 @@ extern "C" int rgm_dit_enable_grad(rgm_dit* h) {
     add(b + "mlp.fc2.weight", D, 4 * D);
   }
   add("final_layer.linear.weight", c.patch * c.out_ch, D);
+  for (int i = 0; i < c.depth; ++i) {
+    const std::string b = "blocks." + std::to_string(i) + ".";
+    for (const char* w : {"attn.qkv.weight", "attn.proj.weight", "mlp.fc1.weight", "mlp.fc2.weight"}) add_ts_slot(h, b + w, true, &h->arena_t_floats);
+  }
   RGM_CHECK_HIP(hipMalloc(&h->arena_t, h->arena_t_floats * sizeof(float)));
   RGM_CHECK_HIP(hipMemset(h->arena_t, 0, h->arena_t_floats * sizeof(float)));
   for (auto& k : keys) {
@@ -295,6 +317,8 @@ extern "C" int rgm_dit_enable_grad(rgm_dit* h) {
     if (!base.set) continue;                       // set_param fills the copy when the weight arrives
     const Slot& ts = h->slots.at(k + ".T");
     RGM_TRY(transpose_launch(h->arena + base.off, h->sp(ts), ts.t_cols, ts.t_rows, ts.t_ld, 1, 0));
+    auto t2 = h->slots.find(k + ".TS");
+    if (t2 != h->slots.end()) RGM_TRY(split_rows_launch(h->sp(ts), h->sp(t2->second), ts.t_rows, ts.t_ld, ts.t_ld, ts.t_ld, 0));
   }
   RGM_CHECK_HIP(hipStreamSynchronize(0));
   return RGM_OK;
@@ -586,6 +610,27 @@ int dgrad(rgm_dit* h, const std::string& wkey, const float* dY, int lda, float* 
   g.aux = aux; g.ldaux = ldaux; g.act = act;
   return gemm_launch(g, s);
 }
+
+// the same on the pre-split LDS-DMA kernel: dY is in split-row format, W^T comes from the ".TS" copy; dX fp32 or split
+int dgrad2(rgm_dit* h, const std::string& wkey, const float* dY_split, int lda, float* dX, int ldc, int M, const float* aux, int ldaux,
+           int act, int out_split, hipStream_t s) {
+  const Slot& ts = h->slots.at(wkey + ".TS");
+  GemmParams g;
+  g.A = dY_split; g.lda = lda; g.B = h->sp(ts); g.ldb = ts.t_ld; g.C = dX; g.ldc = ldc;
+  g.M = M; g.N = ts.t_rows; g.K = ts.t_ld;
+  g.aux = aux; g.ldaux = ldaux; g.act = act; g.out_split = out_split;
+  return gemm2_launch(g, s);
+}
+
+// Linear on the pre-split kernel: A split rows, weight from the ".S" copy; optional adaLN gate + residual
+int lin_split(rgm_dit* h, const float* A_split, const std::string& wkey, const float* bias, float* C, int M, int N, int K, int act,
+              int out_split, const float* gate, int gate_ld, int rows_per_gate, const float* res, hipStream_t s) {
+  GemmParams g;
+  g.A = A_split; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
+  if (gate) { g.gate = gate; g.gate_ld = gate_ld; g.rows_per_gate = rows_per_gate; g.res = res; g.ldres = N; }
+  return gemm2_launch(g, s);
+}
 }  // namespace
 
 extern "C" size_t rgm_dit_grad_workspace_bytes(const rgm_dit* h, int N, int H) {
@@ -601,7 +646,7 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
   // ---------------- forward, keeping what the backward needs
   RGM_TRY(patchify_launch(x, p.tok_in, N, c.in_ch, H, c.width, c.patch, s));
   RGM_TRY(lin(p.tok_in, pc, h->p("x_embedder.MLP.0.weight"), h->p("x_embedder.MLP.0.bias"), p.zpre, 256, p.M0, 256, pc, 0, s));
-  RGM_TRY(act_rows_launch(p.zpre, p.h1, (long long)p.M0 * 256, 1, s));
+  RGM_TRY(act_rows_launch(p.zpre, p.h1, p.M0, 256, 1, s));
   {
     GemmParams g;
     g.A = p.h1; g.lda = 256; g.sA = (long long)p.T0 * 256;
@@ -621,6 +666,7 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
   }
   RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, N, L, D, 0, s));
   const size_t lse_sz = (size_t)N * c.heads * T;
+  const bool v2 = rgm_get_gemm_precision() == 2;
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string(i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
@@ -630,6 +676,18 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
     float* qkv = p.qkvs + i * MD * 3;
     float* ao = p.aos + i * MD;
     float* pre = p.pres + i * MD * 4;
+    if (v2) {   // bf16x3_presplit: producers write split rows, every GEMM of the block runs on the LDS-DMA kernel
+      RGM_TRY(layernorm_modulate_launch(xi, p.xm, M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
+      RGM_TRY(lin_split(h, p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), qkv, M, 3 * D, D, 0, 0, nullptr, 0, 1, nullptr, s));
+      RGM_TRY(rotary_attention_launch(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, p.lses + i * lse_sz));
+      RGM_TRY(split_rows_launch(ao, p.t1, M, D, D, D, s));          // the backward needs O in fp32, proj its split image
+      RGM_TRY(lin_split(h, p.t1, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x1, M, D, D, 0, 0, m + 2 * D, L, T, xi, s));
+      RGM_TRY(layernorm_modulate_launch(x1, p.xm, M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
+      RGM_TRY(lin_split(h, p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), pre, M, 4 * D, D, 0, 0, nullptr, 0, 1, nullptr, s));
+      RGM_TRY(act_rows_launch(pre, p.hid, M, 4 * D, 2, s, 1));
+      RGM_TRY(lin_split(h, p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), xn, M, D, 4 * D, 0, 0, m + 5 * D, L, T, x1, s));
+      continue;
+    }
     RGM_TRY(layernorm_modulate_launch(xi, p.xm, M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), qkv, 3 * D, M, 3 * D, D, 0, s));
     RGM_TRY(rotary_attention_launch(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, p.lses + i * lse_sz));
@@ -642,7 +700,7 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
     }
     RGM_TRY(layernorm_modulate_launch(x1, p.xm, M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "mlp.fc1.weight"), h->p(b + "mlp.fc1.bias"), pre, 4 * D, M, 4 * D, D, 0, s));
-    RGM_TRY(act_rows_launch(pre, p.hid, (long long)M * 4 * D, 2, s));
+    RGM_TRY(act_rows_launch(pre, p.hid, M, 4 * D, 2, s));
     {
       GemmParams g;
       g.A = p.hid; g.lda = 4 * D; g.B = h->p(b + "mlp.fc2.weight"); g.ldb = 4 * D; g.C = xn; g.ldc = D;
@@ -666,6 +724,20 @@ static int grad_blocks_backward(rgm_dit* h, const GPlan& p, hipStream_t s) {
     const float* m = p.mod + (size_t)i * 6 * D;
     const float* xi = p.xs + i * MD;
     const float* x1 = p.x1s + i * MD;
+    if (rgm_get_gemm_precision() == 2) {   // same chain on the pre-split kernel: every GEMM operand is produced as split rows
+      RGM_TRY(gate_rows_launch(p.dx, m + 5 * D, p.t1, M, D, L, T, s, 1));
+      RGM_TRY(dgrad2(h, b + "mlp.fc2.weight", p.t1, D, p.dbig, 4 * D, M, p.pres + i * MD * 4, 4 * D, 3, 1, s));
+      RGM_TRY(dgrad2(h, b + "mlp.fc1.weight", p.dbig, 4 * D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
+      RGM_TRY(ln_mod_bwd_launch(p.dsmall, x1, p.dx, p.dx1, M, D, 1e-6f, nullptr, m + 4 * D, L, T, s));
+      RGM_TRY(gate_rows_launch(p.dx1, m + 2 * D, p.t1, M, D, L, T, s, 1));
+      RGM_TRY(dgrad2(h, b + "attn.proj.weight", p.t1, D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
+      RGM_TRY(rotary_attention_bwd_launch(p.qkvs + i * MD * 3, p.aos + i * MD, p.dsmall, p.lses + i * lse_sz, p.dqkv, h->cos_tab,
+                                          h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s));
+      RGM_TRY(split_rows_launch(p.dqkv, p.dbig, M, 3 * D, 3 * D, 3 * D, s));
+      RGM_TRY(dgrad2(h, b + "attn.qkv.weight", p.dbig, 3 * D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
+      RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s));
+      continue;
+    }
     RGM_TRY(gate_rows_launch(p.dx, m + 5 * D, p.t1, M, D, L, T, s));                                   // d f2 = g2 * dx
     RGM_TRY(dgrad(h, b + "mlp.fc2.weight", p.t1, D, p.dbig, 4 * D, M, p.pres + i * MD * 4, 4 * D, 3, s)); // d pre = (. W2) * gelu'
     RGM_TRY(dgrad(h, b + "mlp.fc1.weight", p.dbig, 4 * D, p.dsmall, D, M, nullptr, 0, 0, s));            // d m2
@@ -727,7 +799,7 @@ extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int6
   RGM_TRY(pool_rows_launch(xf, p.pool, N, T, D, first, p.groups, per, s));
   RGM_TRY(layernorm_modulate_launch(p.pool, p.pooln, rows, D, 1e-5f, h->p("norm.weight"), h->p("norm.bias"), nullptr, nullptr, 0, 1, s));
   RGM_TRY(lin(p.pooln, D, h->p("classifier_head.0.weight"), h->p("classifier_head.0.bias"), p.z1pre, D / 4, rows, D / 4, D, 0, s));
-  RGM_TRY(act_rows_launch(p.z1pre, p.z1, (long long)rows * (D / 4), 1, s));
+  RGM_TRY(act_rows_launch(p.z1pre, p.z1, rows, D / 4, 1, s));
   float* logits = logits_out ? logits_out : p.logits;
   RGM_TRY(lin(p.z1, D / 4, h->p("classifier_head.2.weight"), h->p("classifier_head.2.bias"), logits, c.n_out, rows, c.n_out, D / 4, 0, s));
   RGM_TRY(loss_grad_launch(logits, target, p.dl, rows, c.n_out, p.Kp, scale, loss_kind, s));

@@ -77,9 +77,10 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
   float* __restrict__ Cb = p.C + (long long)z * p.sC;
   const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
   const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  const float* auxb = p.aux ? p.aux + (long long)z * p.sAux : nullptr;   // act 3 / 4: pre-activation whose derivative multiplies the result
   // vector epilogue (below) needs 16-B aligned rows; uniform over the workgroup
-  const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate) & 15) == 0 &&
-                   exp != 5;
+  const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
+                   (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate | (uintptr_t)auxb) & 15) == 0 && exp != 5;
   const int KT = p.K >> 5;
 
   if constexpr (PIPE == 4) {
@@ -615,6 +616,11 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
           } else if (p.act == 2) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) v[q4] = gelu_tanh_fast_f(v[q4]);
+          } else if (p.act == 3 || p.act == 4) {   // backward through an activation: times gelu'(aux) / silu'(aux)
+            const float4 x4 = *reinterpret_cast<const float4*>(auxb + (long long)row * p.ldaux + col);
+            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) v[q4] *= (p.act == 3 ? gelu_tanh_grad_f(xs[q4]) : silu_grad_f(xs[q4]));
           }
           if (p.gate) {
             const float4 g4 = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
@@ -655,6 +661,8 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
             float v = acc[im][in][e] * p.alpha + bv;
             if (p.act == 1) v = silu_f(v);
             else if (p.act == 2) v = gelu_tanh_f(v);
+            else if (p.act == 3) v *= gelu_tanh_grad_f(auxb[(long long)row * p.ldaux + col]);
+            else if (p.act == 4) v *= silu_grad_f(auxb[(long long)row * p.ldaux + col]);
             if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
             if (resb) v += resb[(long long)row * p.ldres + col];
             if (p.out_split) {   // split-row output (common.h split_idx)
@@ -808,7 +816,7 @@ static size_t g_splitk_cap = 0;
 
 // number of K slices for a dense, unbatched GEMM whose 128x64 grid leaves most of the chip idle; 1 = do not split
 static int splitk_factor(const GemmParams& p) {
-  if (p.aload || p.batch != 1 || p.tile != 0 || (p.N & 3) || (p.ldc & 3) || (p.ldres & 3) || (p.gate_ld & 3)) return 1;
+  if (p.aload || p.batch != 1 || p.tile != 0 || p.act >= 3 || (p.N & 3) || (p.ldc & 3) || (p.ldres & 3) || (p.gate_ld & 3)) return 1;
   if ((((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) != 0) return 1;
   const long long t64 = (long long)cdiv(p.M, 128) * cdiv(p.N, 64);
   const int KT = p.K >> 5;
