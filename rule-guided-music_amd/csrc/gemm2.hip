@@ -870,7 +870,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     // fraction of the CU-rounds a grid fills (512 resident 128x128 workgroups, 768 of 128x64): at B = 16 fc1 has
     // 1152 / 2304 tiles = 2.25 (75 %) / 3.0 (100 %) rounds, qkv 864 / 1728 = 1.69 (84 %) / 2.25 (75 %)
     auto fill = [](long long tiles, long long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
-    if (t128 >= 512 && fill(t128, 512) * 1.03 >= fill(t64, 768)) tile = 43;
+    if (t128 >= 512 && fill(t128, 512) * 1.15 >= fill(t64, 768)) tile = 43;   // 128x128 is ~15 % ahead per tile (B = 32 sweep)
     else tile = (t64 >= 384 || p.aload) ? 44 : (t64 >= 256 ? 46 : 52);   // small grids: SWEEP_SHAPES=small sweep
     // implicit-conv loader: the per-piece pixel bookkeeping pushes the cross-iteration pipeline at 128x128 over 256
     // registers (one wave per SIMD) -> the single-set pipeline (PIPE 1) there

@@ -19,6 +19,8 @@ elif os.environ.get("SWEEP_SHAPES") == "small":      # B = 2 / 4 / 8 latents
 elif os.environ.get("SWEEP_SHAPES") == "cls":        # DiTRotary-S/8 classifier (D = 384) at B = 32: forward and dgrad shapes
     SHAPES_OVERRIDE = [("qkv", 8224, 1152, 384), ("proj", 8224, 384, 384), ("fc1", 8224, 1536, 384), ("fc2", 8224, 384, 1536),
                        ("d_qkv", 8224, 384, 1152), ("d_fc2", 8224, 1536, 384), ("d_fc1", 8224, 384, 1536)]
+elif os.environ.get("SWEEP_SHAPES") == "b32":        # XL backbone at B = 32 (C3)
+    SHAPES_OVERRIDE = [("qkv", 8192, 3456, 1152), ("proj", 8192, 1152, 1152), ("fc1", 8192, 4608, 1152), ("fc2", 8192, 1152, 4608)]
 else:
     SHAPES_OVERRIDE = None
 SHAPES = [("qkv", 4096, 3456, 1152), ("proj", 4096, 1152, 1152), ("fc1", 4096, 4608, 1152), ("fc2", 4096, 1152, 4608),
