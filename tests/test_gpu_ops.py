@@ -164,3 +164,24 @@ def test_gemm_split_dma_kernel(tile, M, N, K):
         R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(cs), M, N, K, R.ptr(bd), 2, tile, 1, R.current_stream()))
         torch.cuda.synchronize()
         assert rel(_unsplit(cs), _ref_gemm(A, B, bias, 2, 1.0, None, 1, None)) < 3e-5
+
+
+def test_split_rows_and_gemm_with_padded_row_strides():
+    """rgm_split_rows_ld / rgm_gemm_split_ld: operands and output with padded rows (ld > K, ldc > N), ragged M and N."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    rng = np.random.RandomState(9)
+    M, N, K, lda, ldb, ldc = 333, 160, 192, 192 + 32, 192 + 64, 160 + 32
+    A, B, bias = rng.randn(M, K).astype(F32), rng.randn(N, K).astype(F32), rng.randn(N).astype(F32)
+    As, Bs = torch.zeros(M, lda, device="cuda"), torch.zeros(N, ldb, device="cuda")
+    st = R.current_stream()
+    R.check(R.lib.rgm_split_rows_ld(R.ptr(dev(A)), K, R.ptr(As), lda, M, K, st))
+    R.check(R.lib.rgm_split_rows_ld(R.ptr(dev(B)), K, R.ptr(Bs), ldb, N, K, st))
+    assert rel(_unsplit(As[:, :K].contiguous()), A) < 2 ** -16
+    C = torch.full((M, ldc), 7.0, device="cuda")
+    for tile in (0, 43, 44, 52, 61):
+        C.fill_(7.0)
+        R.check(R.lib.rgm_gemm_split_ld(R.ptr(As), lda, R.ptr(Bs), ldb, R.ptr(C), ldc, M, N, K, R.ptr(dev(bias)), 0, tile, 0, st))
+        torch.cuda.synchronize()
+        assert rel(C[:, :N].cpu().numpy(), _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)) < 3e-5, tile
+        assert bool((C[:, N:] == 7.0).all()), f"tile {tile} wrote into the row padding"
