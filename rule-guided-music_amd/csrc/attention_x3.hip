@@ -31,7 +31,7 @@ template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                   const float* __restrict__ cos_tab,
                                                                   const float* __restrict__ sin_tab, int T, int heads, int rot_half,
-                                                                  int out_split) {
+                                                                  float* __restrict__ lse, int out_split) {
   constexpr int KP = (HD + 15) / 16 * 16;   // padded contraction length of QK^T
   constexpr int KS = KP / 16;               // k16 steps of QK^T
   constexpr int DT = (HD + 31) / 32;        // 32-wide output-channel tiles
@@ -176,6 +176,8 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       }
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
+    // natural-log sum-exp of the scaled scores, saved for the backward (scores here are in the log2 domain)
+    if (lse && hh == 0 && q < T) lse[((long long)n * heads + head) * T + q] = (mx + log2f(sum)) * 0.693147180559945309417f;
     // ---- O^T[d][query] = V^T . P^T ; A operand = V^T rows (d = lane&31), B operand = the probability registers, split
     f32x16 oacc[DT];
 #pragma unroll
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
 
 template <int HD, int NKT>
 static int launch_attn_x3(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,
-                          int out_split, hipStream_t s) {
+                          float* lse, int out_split, hipStream_t s) {
   constexpr int KP = (HD + 15) / 16 * 16, TP = NKT * 32;
   const size_t lds = (size_t)TP * (KP * 4 + 16) + (size_t)HD * (TP * 4 + 16);
   static bool attr_set = false;
@@ -245,37 +247,37 @@ static int launch_attn_x3(const float* qkv, float* o, const float* ct, const flo
     RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, out_split);
+  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
-// same contract as rotary_attention_launch (attention.hip) without the log-sum-exp output
+// same contract as rotary_attention_launch (attention.hip)
 int rotary_attention_x3_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads,
-                               int hd, int rot_half, hipStream_t s, int out_split) {
+                               int hd, int rot_half, hipStream_t s, float* lse, int out_split) {
   RGM_REQUIRE(N > 0 && T > 0 && T <= 288, "attention: T=%d out of range (1..288)", T);
   RGM_REQUIRE((2 * rot_half) % 4 == 0 && 2 * rot_half <= hd, "attention: rotary dim %d", 2 * rot_half);
   const int nkt = (T + 31) / 32;
   if (hd == 72) {
-    if (nkt <= 4) return launch_attn_x3<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
-    if (nkt <= 8) return launch_attn_x3<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    if (nkt <= 4) return launch_attn_x3<72, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    if (nkt <= 8) return launch_attn_x3<72, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
     set_error("attention: head_dim 72 supports T <= 256 (K+V of one head must fit the 160 KiB LDS), got %d", T);
     return RGM_ERR_INVALID;
   }
   if (hd == 64) {
-    if (nkt <= 4) return launch_attn_x3<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
-    if (nkt <= 5) return launch_attn_x3<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
-    if (nkt <= 8) return launch_attn_x3<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
-    return launch_attn_x3<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, out_split, s);
+    if (nkt <= 4) return launch_attn_x3<64, 4>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    if (nkt <= 5) return launch_attn_x3<64, 5>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    if (nkt <= 8) return launch_attn_x3<64, 8>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
+    return launch_attn_x3<64, 9>(qkv, o, cos_tab, sin_tab, N, T, heads, rot_half, lse, out_split, s);
   }
   set_error("attention: head_dim %d not supported (64, 72)", hd);
   return RGM_ERR_INVALID;
 }
 
 int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
-                         int rot_half, hipStream_t s, int out_split) {
-  if (rgm_get_gemm_precision() != 0) return rotary_attention_x3_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, out_split);
-  return rotary_attention_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, nullptr, out_split);
+                         int rot_half, hipStream_t s, int out_split, float* lse) {
+  if (rgm_get_gemm_precision() != 0) return rotary_attention_x3_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, lse, out_split);
+  return rotary_attention_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, lse, out_split);
 }
 
 }  // namespace rgm

@@ -159,12 +159,12 @@ int layernorm_modulate_launch(const float* x, float* out, int M, int D, float ep
                               int rows_per_batch, hipStream_t s, int out_split = 0);
 int rotary_attention_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N,
                             int T, int heads, int hd, int rot_half, hipStream_t s, float* lse = nullptr, int out_split = 0);
-// the same forward in bf16x3 arithmetic (attention_x3.hip); no log-sum-exp output
+// the same forward in bf16x3 arithmetic (attention_x3.hip)
 int rotary_attention_x3_launch(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads,
-                               int hd, int rot_half, hipStream_t s, int out_split = 0);
-// forward attention of the inference paths: fp32 MFMA in fp32 mode, bf16x3 otherwise (rgm_set_gemm_precision)
+                               int hd, int rot_half, hipStream_t s, float* lse = nullptr, int out_split = 0);
+// forward attention by mode: fp32 MFMA in fp32 mode, bf16x3 otherwise (rgm_set_gemm_precision); lse (optional) for the backward
 int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
-                         int rot_half, hipStream_t s, int out_split = 0);
+                         int rot_half, hipStream_t s, int out_split = 0, float* lse = nullptr);
 // attention backward (attention_bwd.hip): dqkv (N*T, 3*heads*hd) from dO, the saved qkv / O / lse
 int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                 const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,

@@ -679,7 +679,7 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
     if (v2) {   // bf16x3_presplit: producers write split rows, every GEMM of the block runs on the LDS-DMA kernel
       RGM_TRY(layernorm_modulate_launch(xi, p.xm, M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
       RGM_TRY(lin_split(h, p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), qkv, M, 3 * D, D, 0, 0, nullptr, 0, 1, nullptr, s));
-      RGM_TRY(rotary_attention_launch(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, p.lses + i * lse_sz));
+      RGM_TRY(rotary_attention_fwd(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, 0, p.lses + i * lse_sz));
       RGM_TRY(split_rows_launch(ao, p.t1, M, D, D, D, s));          // the backward needs O in fp32, proj its split image
       RGM_TRY(lin_split(h, p.t1, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x1, M, D, D, 0, 0, m + 2 * D, L, T, xi, s));
       RGM_TRY(layernorm_modulate_launch(x1, p.xm, M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
@@ -690,7 +690,7 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
     }
     RGM_TRY(layernorm_modulate_launch(xi, p.xm, M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), qkv, 3 * D, M, 3 * D, D, 0, s));
-    RGM_TRY(rotary_attention_launch(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, p.lses + i * lse_sz));
+    RGM_TRY(rotary_attention_fwd(qkv, ao, h->cos_tab, h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, 0, p.lses + i * lse_sz));
     {
       GemmParams g;
       g.A = ao; g.lda = D; g.B = h->p(b + "attn.proj.weight"); g.ldb = D; g.C = x1; g.ldc = D;

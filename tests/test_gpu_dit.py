@@ -127,10 +127,9 @@ def test_classifier_guidance_gradient_matches_autograd_golden(tag, depth, precis
     assert rel(grad.cpu().numpy(), g[f"{tag}.grad"]) < 5e-4
     assert torch.equal(grad_nn_zt_mse(x, t, rule=rule, classifier_scale=10., classifier=m), grad)
     # plain forward still agrees with the saved-activation forward
-    # the plain forward and the saved-activation forward are the same arithmetic in fp32 mode; in the bf16x3 modes the
-    # plain forward runs the bf16x3 attention (the saved-activation forward keeps the fp32 one, whose log-sum-exp the
-    # backward consumes) and, in presplit mode, the LDS-DMA GEMMs with the exp2/rcp GELU
-    assert rel(m(x, t).cpu().numpy(), logits.cpu().numpy()) < (1e-6 if precision == "fp32" else 3e-5)
+    # the plain forward and the saved-activation forward run the same kernels except, in presplit mode, the GELU (fused
+    # exp2/rcp form in the GEMM epilogue vs libm tanh in the stand-alone activation pass that keeps the pre-activation)
+    assert rel(m(x, t).cpu().numpy(), logits.cpu().numpy()) < (1e-5 if precision == "bf16x3_presplit" else 1e-6)
 
 
 def test_chord_classifier_guidance_gradient(precision):
