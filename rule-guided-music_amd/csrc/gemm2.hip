@@ -20,6 +20,7 @@
 // Out-of-range rows (M / N tails, conv zero padding) read a zero page, so the kernel has no divergent loads.
 #include <stdlib.h>
 #include <stdint.h>
+#include <map>
 #include <vector>
 #include "common.h"
 
@@ -811,8 +812,12 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, GemmParams p, 
   }
 }
 
-static float* g_splitk_buf = nullptr;      // partial sums, grown on demand (rare: hipMalloc synchronises)
-static size_t g_splitk_cap = 0;
+// partial sums: one buffer per stream (launches on different streams may overlap), grown on demand (rare: hipMalloc synchronises)
+struct SplitKBuf {
+  float* p = nullptr;
+  size_t cap = 0;
+};
+static std::map<hipStream_t, SplitKBuf> g_splitk;
 
 // number of K slices for a dense, unbatched GEMM whose 128x64 grid leaves most of the chip idle; 1 = do not split
 static int splitk_factor(const GemmParams& p) {
@@ -840,23 +845,27 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   const int S = splitk_factor(p);
   if (S > 1) {
     const size_t need = (size_t)S * p.M * p.N * sizeof(float);
-    if (need > g_splitk_cap) {
-      if (g_splitk_buf) RGM_CHECK_HIP(hipFree(g_splitk_buf));
-      g_splitk_buf = nullptr;
-      g_splitk_cap = 0;
-      RGM_CHECK_HIP(hipMalloc(&g_splitk_buf, need));
-      g_splitk_cap = need;
+    SplitKBuf& sk = g_splitk[s];
+    if (need > sk.cap) {
+      if (sk.p) {
+        RGM_CHECK_HIP(hipStreamSynchronize(s));      // an earlier launch on this stream may still read the old buffer
+        RGM_CHECK_HIP(hipFree(sk.p));
+      }
+      sk.p = nullptr;
+      sk.cap = 0;
+      RGM_CHECK_HIP(hipMalloc(&sk.p, need));
+      sk.cap = need;
     }
     GemmParams q = p;                     // the K slices as a batch: raw partial sums, no epilogue
     q.K = p.K / S;
     q.batch = S;
     q.sA = q.K; q.sB = q.K;
-    q.C = g_splitk_buf; q.ldc = p.N; q.sC = (long long)p.M * p.N;
+    q.C = sk.p; q.ldc = p.N; q.sC = (long long)p.M * p.N;
     q.bias = nullptr; q.act = 0; q.alpha = 1.0f; q.gate = nullptr; q.res = nullptr; q.out_split = 0;
     q.tile = 44;
     RGM_TRY(gemm2_launch(q, s));
     const long long total4 = (long long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)g_splitk_buf, p, S);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)sk.p, p, S);
     RGM_LAUNCH_CHECK();
     return RGM_OK;
   }
