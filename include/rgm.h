@@ -185,6 +185,21 @@ int rgm_vae_decode_latent(rgm_vae* h, const float* latent, float inv_scale, floa
  * stride-2 Downsample convs :56-75, then quant_conv): x (M,3,128,128) piano-roll tiles in [-1,1] -> moments
  * (M,8,16,16) = mean (channels 0..3) | logvar (4..7).  Workspace as for decode with the same M. */
 int rgm_vae_encode(rgm_vae* h, const float* x, float* moments, int M, void* ws, size_t ws_bytes, void* stream);
+/* Decoder input gradient -- what torch.autograd computes when the reference's dps_rule branch differentiates
+ * rule(_decode(x0_hat)) w.r.t. the latent (gaussian_diffusion.py:415-433 with guidance.nn False; _decode :1347-1358;
+ * Decoder.forward model.py:506-537).  Two stream-ordered calls sharing one workspace of
+ * rgm_vae_grad_workspace_bytes(h, N*H/16) bytes that the caller leaves untouched in between:
+ *   rgm_vae_decode_latent_save: the same roll as rgm_vae_decode_latent, keeping every ResnetBlock's input and conv1
+ *     output, the attention tensors and all GroupNorm statistics (~105 MB per 16x16 square) in `ws`;
+ *   rgm_vae_decode_latent_vjp:  d_latent (N,4,H,16) = (d roll / d latent)^T d_roll, d_roll (N,3,128,8H).
+ * rgm_vae_enable_grad builds the mirrored/transposed weight copies the backward GEMMs read (once, after set_param;
+ * ~0.2 GB); the grad calls return RGM_ERR_STATE without it.  Input gradients only -- no parameter gradients. */
+int rgm_vae_enable_grad(rgm_vae* h);
+size_t rgm_vae_grad_workspace_bytes(const rgm_vae* h, int M /* number of 16x16 latent squares */);
+int rgm_vae_decode_latent_save(rgm_vae* h, const float* latent, float inv_scale, float* roll, int N, int H, void* ws,
+                               size_t ws_bytes, void* stream);
+int rgm_vae_decode_latent_vjp(rgm_vae* h, const float* d_roll, float inv_scale, float* d_latent, int N, int H, void* ws,
+                              size_t ws_bytes, void* stream);
 /* midi_util.py:59-63 on an existing roll: (B,3,128,T) float32 -> (B,128,T,3) uint8. */
 int rgm_quantise_roll(const float* roll, uint8_t* out_u8, int B, int T, float threshold, void* stream);
 
@@ -195,6 +210,11 @@ int rgm_quantise_roll(const float* roll, uint8_t* out_u8, int B, int T, float th
  * ---------------------------------------------------------------------------------------------- */
 /* total_pitch_class_histogram (:29-43): out (N,12); scratch N*128 floats. */
 int rgm_rule_pitch_hist(float* roll, float* out, float* scratch, int N, int C, int T, void* stream);
+/* rule_x0_mse_dummy for pitch_hist (condition_functions.py:122-126): logp (N) = -scale * ||pitch_hist(roll) - target||^2
+ * and d_roll (N,C,128,T) = d logp / d roll (0.5 * d/dh on channel 0's piano rows, 0 elsewhere); hist (N,12) optional;
+ * scratch N*140 floats.  Writes the piano_like mask into roll like rgm_rule_pitch_hist. */
+int rgm_rule_pitch_hist_vag(float* roll, const float* target, float scale, float* hist, float* logp, float* d_roll,
+                            float* scratch, int N, int C, int T, void* stream);
 /* note_density (:46-83): out (N, 2*T/interval) = [vertical..., horizontal...]; interval divides 256 and T. */
 int rgm_rule_note_density(float* roll, float* out, int N, int C, int T, int interval, float hscale, void* stream);
 /* torch.bucketize(v, bounds) as used by note_density_class (:86-94): out int64. */

@@ -118,6 +118,56 @@ __global__ void row_loss_kernel(const float* __restrict__ a, const float* __rest
   }
   out[r] = s / (float)K;
 }
+// DPS through the differentiable pitch histogram (condition_functions.py:122-126 rule_x0_mse_dummy on music_rules.py:29-43):
+// one thread per sample: hist as pitch_fold_kernel, logp = -scale * sum (hist - target)^2 and
+// dh[c] = d logp / d (unnormalised class sum c) = (u_c - sum_k u_k hist_k) / (tot + 1e-12), u = -2 scale (hist - target)
+__global__ void pitch_fold_vag_kernel(const float* __restrict__ rowsum, const float* __restrict__ target, float scale,
+                                      float* __restrict__ hist_out, float* __restrict__ logp, float* __restrict__ dh, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float h[12];
+  float tot = 0.f;
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    float s = 0.f;
+    for (int o = 0; o < 11; ++o) {
+      const int p = o * 12 + c;
+      if (p < 128) s += rowsum[n * 128 + p];
+    }
+    h[c] = s;
+    tot += s;
+  }
+  const float d = tot + 1e-12f;
+  float lp = 0.f, dot = 0.f, u[12];
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    const float hc = h[c] / d;
+    const float e = hc - target[n * 12 + c];
+    lp += e * e;
+    u[c] = -2.0f * scale * e;
+    dot += u[c] * hc;
+    h[c] = hc;
+  }
+  logp[n] = -scale * lp;
+#pragma unroll
+  for (int c = 0; c < 12; ++c) {
+    if (hist_out) hist_out[n * 12 + c] = h[c];
+    dh[n * 12 + c] = (u[c] - dot) / d;
+  }
+}
+
+// d_roll (N,C,128,T): channel 0, piano rows get 0.5 * dh[pitch % 12] (the (x+1)/2 rescale), everything else 0
+__global__ void pitch_grad_fill_kernel(const float* __restrict__ dh, float* __restrict__ droll, long long total, int C, int T) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long r = i / T;
+  const int p = (int)(r % 128);
+  const long long nc = r / 128;
+  const int ch = (int)(nc % C);
+  const long long n = nc / C;
+  droll[i] = (ch == 0 && p >= MIN_PIANO && p <= MAX_PIANO) ? 0.5f * dh[n * 12 + p % 12] : 0.0f;
+}
+
 }  // namespace rgm
 
 using namespace rgm;
@@ -128,6 +178,23 @@ extern "C" int rgm_rule_pitch_hist(float* roll, float* out, float* scratch, int 
   hipLaunchKernelGGL(pitch_rowsum_kernel, dim3(128, N), dim3(256), 0, s, roll, scratch, C, T);
   RGM_LAUNCH_CHECK();
   hipLaunchKernelGGL(pitch_fold_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, scratch, out, N);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// log p = -scale * ||pitch_hist(roll) - target||^2 per sample and its gradient w.r.t. the roll (N,C,128,T).  Like
+// rgm_rule_pitch_hist the non-piano rows of channel 0 of `roll` are overwritten with -1.  scratch: N*(128+12) floats.
+extern "C" int rgm_rule_pitch_hist_vag(float* roll, const float* target, float scale, float* hist, float* logp, float* d_roll,
+                                       float* scratch, int N, int C, int T, void* stream) {
+  RGM_REQUIRE(roll && target && logp && d_roll && scratch && N > 0 && C > 0 && T > 0, "pitch_hist_vag: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  float* dh = scratch + (size_t)N * 128;
+  hipLaunchKernelGGL(pitch_rowsum_kernel, dim3(128, N), dim3(256), 0, s, roll, scratch, C, T);
+  RGM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(pitch_fold_vag_kernel, dim3(cdiv(N, 64)), dim3(64), 0, s, scratch, target, scale, hist, logp, dh, N);
+  RGM_LAUNCH_CHECK();
+  const long long total = (long long)N * C * 128 * T;
+  hipLaunchKernelGGL(pitch_grad_fill_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dh, d_roll, total, C, T);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -268,6 +268,191 @@ __global__ void quantise_roll_kernel(const float* __restrict__ roll, uint8_t* __
   u8[i] = (uint8_t)v;
 }
 
+
+// ------------------------------------------------------------------- decoder backward (input gradients only)
+// GroupNorm(+swish) backward, pass 1: per (tile, group) sums of dxhat and dxhat*xhat in fp64, where
+// xhat = (x-mean)*rstd, y = xhat*gamma+beta, dxhat = dz * swish'(y) * gamma.  Same grid / chunking as gn_partial_kernel.
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ x, const float* __restrict__ dz,
+                                                             const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, double* __restrict__ part, int P,
+                                                             int C, int chunks, int swish) {
+  __shared__ double sh[32][2];
+  const int m = blockIdx.y, ch = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) sh[tid >> 1][tid & 1] = 0.0;
+  __syncthreads();
+  const int q = C >> 2;
+  const int ppi = 256 / q;
+  const int cq = tid % q, p_off = tid / q;
+  const int p0 = (int)((long long)P * ch / chunks), p1 = (int)((long long)P * (ch + 1) / chunks);
+  const float4* xb = reinterpret_cast<const float4*>(x + (long long)m * P * C);
+  const float4* db = reinterpret_cast<const float4*>(dz + (long long)m * P * C);
+  const int g = (cq * 4) / (C >> 5);
+  const float mean = stats[(m * 32 + g) * 2], rstd = stats[(m * 32 + g) * 2 + 1];
+  const float4 ga4 = reinterpret_cast<const float4*>(gamma)[cq], be4 = reinterpret_cast<const float4*>(beta)[cq];
+  const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
+  double s = 0.0, ss = 0.0;
+  for (int p = p0 + p_off; p < p1; p += ppi) {
+    const float4 v4 = xb[(long long)p * q + cq], d4 = db[(long long)p * q + cq];
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xh = (v[k] - mean) * rstd;
+      const float dy = swish ? d[k] * silu_grad_f(xh * ga[k] + be[k]) : d[k];
+      const float dxh = dy * ga[k];
+      s += (double)dxh;
+      ss += (double)dxh * (double)xh;
+    }
+  }
+  atomicAdd(&sh[g][0], s);
+  atomicAdd(&sh[g][1], ss);
+  __syncthreads();
+  if (tid < 64) part[(((long long)m * chunks + ch) * 32 + (tid >> 1)) * 2 + (tid & 1)] = sh[tid >> 1][tid & 1];
+}
+
+__global__ void gn_bwd_finalize_kernel(const double* __restrict__ part, float* __restrict__ sums, int M, int chunks, double count) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over M*32
+  if (idx >= M * 32) return;
+  const int m = idx >> 5, g = idx & 31;
+  double s = 0.0, ss = 0.0;
+  for (int c = 0; c < chunks; ++c) {
+    s += part[(((long long)m * chunks + c) * 32 + g) * 2];
+    ss += part[(((long long)m * chunks + c) * 32 + g) * 2 + 1];
+  }
+  sums[idx * 2] = (float)(s / count);
+  sums[idx * 2 + 1] = (float)(ss / count);
+}
+
+// pass 2: dx = rstd * (dxhat - mean_g(dxhat) - xhat * mean_g(dxhat*xhat)) (+ add); may run in place on dz
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* dz, const float* __restrict__ stats,
+                                    const float* __restrict__ sums, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* add, float* out, long long total4, int P, int C,
+                                    int swish) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= total4) return;
+  const int q = C >> 2;
+  const int c4 = (int)(i % q);
+  const int m = (int)(i / ((long long)q * P));
+  const int g = (c4 * 4) / (C >> 5);
+  const float mean = stats[(m * 32 + g) * 2], rstd = stats[(m * 32 + g) * 2 + 1];
+  const float m1 = sums[(m * 32 + g) * 2], m2 = sums[(m * 32 + g) * 2 + 1];
+  const float4 v4 = reinterpret_cast<const float4*>(x)[i], d4 = reinterpret_cast<const float4*>(dz)[i];
+  const float4 ga4 = reinterpret_cast<const float4*>(gamma)[c4], be4 = reinterpret_cast<const float4*>(beta)[c4];
+  const float v[4] = {v4.x, v4.y, v4.z, v4.w}, d[4] = {d4.x, d4.y, d4.z, d4.w};
+  const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
+  float o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float xh = (v[k] - mean) * rstd;
+    const float dy = swish ? d[k] * silu_grad_f(xh * ga[k] + be[k]) : d[k];
+    o[k] = rstd * (dy * ga[k] - m1 - xh * m2);
+  }
+  if (add) {
+    const float4 a = reinterpret_cast<const float4*>(add)[i];
+    o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// conv_out backward: d_in[m][y][x][c] = sum_{co,ky,kx} d_roll[n][co][y-ky+1][s*128 + x-kx+1] * w[co][ky*3+kx][c]
+// (the roll gradient is read in the (N,3,128,T) layout the forward scatters to); one thread per (pixel, 4 channels)
+__global__ __launch_bounds__(256) void vae_conv_out_bwd_kernel(const float* __restrict__ droll, const float* __restrict__ w,
+                                                               float* __restrict__ dx, int M, int Nb, int Tt) {
+  constexpr int C = 128;
+  __shared__ __attribute__((aligned(16))) float ws[3 * 9 * C];
+  for (int i = threadIdx.x; i < 3 * 9 * C; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const long long idx = blockIdx.x * 256LL + threadIdx.x;     // over M*16384*32 (grid exact)
+  const int c4 = (int)(idx & 31);
+  const int pix = (int)(idx >> 5);
+  const int m = pix >> 14, y = (pix >> 7) & 127, x0 = pix & 127;
+  const int s = m / Nb, n = m - s * Nb;
+  const long long plane = 128LL * Tt;
+  const float* base = droll + (long long)n * 3 * plane + s * 128;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int yo = y - tap / 3 + 1, xo = x0 - tap % 3 + 1;
+    if ((unsigned)yo >= 128u || (unsigned)xo >= 128u) continue;
+#pragma unroll
+    for (int co = 0; co < 3; ++co) {
+      const float d = base[co * plane + (long long)yo * Tt + xo];
+      const float4 ww = *reinterpret_cast<const float4*>(ws + (co * 9 + tap) * C + c4 * 4);
+      acc.x = fmaf(d, ww.x, acc.x); acc.y = fmaf(d, ww.y, acc.y); acc.z = fmaf(d, ww.z, acc.z); acc.w = fmaf(d, ww.w, acc.w);
+    }
+  }
+  reinterpret_cast<float4*>(dx)[idx] = acc;
+}
+
+// backward of the nearest x2 upsampling folded into the upsample conv: out[m][y][x][c] = sum of the 2x2 block of in
+__global__ void sumpool2_kernel(const float* __restrict__ in, float* __restrict__ out, long long total4, int H, int q) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // over M*H*H*q (H = output size)
+  if (i >= total4) return;
+  const int c4 = (int)(i % q);
+  const long long pix = i / q;
+  const int x = (int)(pix % H), y = (int)((pix / H) % H);
+  const long long m = pix / ((long long)H * H);
+  const float4* b = reinterpret_cast<const float4*>(in) + ((m * 2 * H + 2 * y) * 2 * H + 2 * x) * q + c4;
+  const float4 a0 = b[0], a1 = b[q], a2 = b[2LL * H * q], a3 = b[2LL * H * q + q];
+  reinterpret_cast<float4*>(out)[i] = make_float4((a0.x + a1.x) + (a2.x + a3.x), (a0.y + a1.y) + (a2.y + a3.y),
+                                                  (a0.z + a1.z) + (a2.z + a3.z), (a0.w + a1.w) + (a2.w + a3.w));
+}
+
+// conv_in (4 -> Cout, 3x3) and post_quant_conv (1x1, 4 -> 4) backward plus the scatter back into the latent layout the
+// forward gathered from (incl. in_scale): one wave per 16x16-square pixel, lanes stride the Cout channels of dy
+__global__ __launch_bounds__(256) void vae_conv_in_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              const float* __restrict__ wpq, float* __restrict__ dlat, int M,
+                                                              int Cout, int Nb, long long n_stride, long long s_stride,
+                                                              long long sc, long long si, long long sj, float in_scale) {
+  const int pix = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= M * 256) return;
+  const int lane = threadIdx.x & 63;
+  const int m = pix >> 8, y = (pix >> 4) & 15, x = pix & 15;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int yo = y - tap / 3 + 1, xo = x - tap % 3 + 1;
+    if ((unsigned)yo >= 16u || (unsigned)xo >= 16u) continue;
+    const float* d = dy + ((long long)(m << 8) + (yo << 4) + xo) * Cout;
+    for (int co = lane; co < Cout; co += 64) {
+      const float g = d[co];
+      const float4 ww = *reinterpret_cast<const float4*>(w + ((long long)co * 9 + tap) * 4);
+      a0 = fmaf(g, ww.x, a0); a1 = fmaf(g, ww.y, a1); a2 = fmaf(g, ww.z, a2); a3 = fmaf(g, ww.w, a3);
+    }
+  }
+  a0 = wave_sum(a0); a1 = wave_sum(a1); a2 = wave_sum(a2); a3 = wave_sum(a3);
+  if (lane == 0) {
+    const int s = m / Nb, n = m - s * Nb;
+    float* p = dlat + n * n_stride + s * s_stride + y * si + x * sj;
+    const float dpq[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      p[c * sc] = in_scale * (wpq[0 * 4 + c] * dpq[0] + wpq[1 * 4 + c] * dpq[1] + wpq[2 * 4 + c] * dpq[2] + wpq[3 * 4 + c] * dpq[3]);
+  }
+}
+
+// softmax backward on rows, in place on dP: dS = alpha * P * (dP - sum_j dP_j P_j); one wave per row
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ P, float* __restrict__ dP, int rows,
+                                                               int cols, float alpha) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* p = P + (long long)row * cols;
+  float* d = dP + (long long)row * cols;
+  float dot = 0.f;
+  for (int c = lane; c < cols; c += 64) dot = fmaf(d[c], p[c], dot);
+  dot = wave_sum(dot);
+  for (int c = lane; c < cols; c += 64) d[c] = alpha * p[c] * (d[c] - dot);
+}
+
+// weights of the input-gradient conv: rep [Cout][9][Cin] (arena layout) -> out [Cin][9][Cout] with the taps mirrored
+__global__ void repack_conv3_dgrad_kernel(const float* __restrict__ rep, float* __restrict__ out, int Cout, int Cin) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)Cout * Cin * 9) return;
+  const int co = (int)(i % Cout);
+  const int tap = (int)((i / Cout) % 9);
+  const int ci = (int)(i / ((long long)Cout * 9));
+  out[i] = rep[((long long)co * 9 + (8 - tap)) * Cin + ci];
+}
+
 }  // namespace rgm
 
 using namespace rgm;
@@ -290,6 +475,11 @@ struct rgm_vae {
   int ch = 128;
   int cur_group = 0;       // group given to the slots being registered
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
+  // input-gradient copies of the decoder weights (rgm_vae_enable_grad): 3x3 convs as [Cin][9 mirrored][Cout], 1x1 as [Cin][Cout]
+  float* garena = nullptr;
+  std::map<std::string, size_t> goff;
+  bool grad_ready = false;
+  const float* gp(const std::string& k) const { return garena + goff.at(k); }
 };
 
 static void vslot(rgm_vae* h, const std::string& key, size_t numel, int conv3 = 0, int cout = 0, int cin = 0) {
@@ -407,6 +597,7 @@ extern "C" void rgm_vae_destroy(rgm_vae* h) {
   if (!h) return;
   if (h->arena) (void)hipFree(h->arena);
   if (h->stage) (void)hipFree(h->stage);
+  if (h->garena) (void)hipFree(h->garena);
   delete h;
 }
 
@@ -436,6 +627,7 @@ extern "C" int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, 
     RGM_CHECK_HIP(hipMemcpy(h->arena + s.off, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
   }
   s.set = true;
+  h->grad_ready = false;   // the input-gradient copies are stale: rgm_vae_enable_grad again
   return RGM_OK;
 }
 
@@ -451,6 +643,48 @@ extern "C" int rgm_vae_encoder_missing_params(rgm_vae* h) {
   int n = 0;
   for (auto& kv : h->slots) n += (kv.second.set || kv.second.group != 1) ? 0 : 1;   // what encode needs
   return n;
+}
+
+// Builds the weight copies the decoder's input-gradient pass multiplies with (decoder 3x3 convs with >= 32 channels on
+// both sides, nin_shortcut and the attention 1x1 convs).  Call after the decoder parameters are set; set_param invalidates.
+extern "C" int rgm_vae_enable_grad(rgm_vae* h) {
+  RGM_REQUIRE(h, "vae_enable_grad: null handle");
+  RGM_REQUIRE(rgm_vae_missing_params(h) == 0, "vae_enable_grad: %d decoder parameters not set", rgm_vae_missing_params(h));
+  if (h->grad_ready) return RGM_OK;
+  if (!h->garena) {
+    size_t off = 0;
+    for (auto& kv : h->slots) {
+      const VSlot& s = kv.second;
+      const std::string& k = kv.first;
+      if (s.derived || s.group != 0 || k.compare(0, 8, "decoder.") != 0) continue;
+      const bool c3 = s.conv3 && s.cin % 32 == 0 && s.cout % 32 == 0;
+      const bool c1 = !s.conv3 && k.size() > 7 && k.compare(k.size() - 7, 7, ".weight") == 0 &&
+                      (k.find("nin_shortcut") != std::string::npos || k.find("attn_1.q.") != std::string::npos ||
+                       k.find("attn_1.k.") != std::string::npos || k.find("attn_1.v.") != std::string::npos ||
+                       k.find("attn_1.proj_out.") != std::string::npos);
+      if (!c3 && !c1) continue;
+      h->goff[k + ".T"] = off;
+      off += (s.numel + 3) / 4 * 4;
+    }
+    RGM_CHECK_HIP(hipMalloc(&h->garena, off * sizeof(float)));
+  }
+  for (auto& kv : h->goff) {
+    const std::string key = kv.first.substr(0, kv.first.size() - 2);
+    const VSlot& s = h->slots.at(key);
+    float* dst = h->garena + kv.second;
+    if (s.conv3) {
+      hipLaunchKernelGGL(repack_conv3_dgrad_kernel, dim3((unsigned)((s.numel + 255) / 256)), dim3(256), 0, 0, h->arena + s.off, dst,
+                         s.cout, s.cin);
+      RGM_LAUNCH_CHECK();
+    } else {   // [Cout][Cin] -> [Cin][Cout]; 1x1 slots do not record their shape: bias length = Cout
+      const int cout = (int)h->slots.at(key.substr(0, key.size() - 6) + "bias").numel;
+      const int cin = (int)(s.numel / cout);
+      RGM_TRY(transpose_launch(h->arena + s.off, dst, cout, cin, cout, 1, 0));
+    }
+  }
+  RGM_CHECK_HIP(hipStreamSynchronize(0));
+  h->grad_ready = true;
+  return RGM_OK;
 }
 
 namespace {
@@ -494,14 +728,17 @@ struct Ctx {
   int split = 0;   // bf16x3_presplit: GroupNorm writes split rows, the 3x3 convs run on gemm2.hip
 };
 
-int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish, int out_split = 0) {
+// stats: where (mean, rstd) of the M x 32 groups go (kept for the backward when given; default the shared scratch)
+int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish, int out_split = 0,
+               float* stats = nullptr) {
+  if (!stats) stats = c.p.stats;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_CHUNKS, c.M), dim3(256), 0, c.s, x, c.p.part, P, C, GN_CHUNKS);
   RGM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, c.p.stats, c.M, GN_CHUNKS,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, stats, c.M, GN_CHUNKS,
                      (double)P * (C / 32), 1e-6f);
   RGM_LAUNCH_CHECK();
   const long long total4 = (long long)c.M * P * C / 4;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, y, c.p.stats,
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, y, stats,
                      c.h->p(key + ".weight"), c.h->p(key + ".bias"), total4, P, C, swish, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
@@ -535,27 +772,33 @@ int conv1(Ctx& c, const float* in, float* out, int rows, int Cin, int Cout, cons
   return gemm_launch(g, c.s);
 }
 
-// x (cur) -> result buffer; uses the two other rotating buffers as scratch. Returns which buffer holds the result.
-int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout, const std::string& key) {
+// ResnetBlock (taming model.py:78-137): out = shortcut(x) + conv2(swish(norm2(b))), b = conv1(swish(norm1(x))).
+// t1 is scratch for the normalised maps; hbuf (Cin != Cout only) holds conv2's output and may alias b; out may alias x when
+// Cin == Cout.  st1/st2 keep the GroupNorm statistics (the backward pass reads them together with x and b).
+int resnet(Ctx& c, const float* x, float* b, float* hbuf, float* out, float* t1, int H, int Cin, int Cout, const std::string& key,
+           float* st1 = nullptr, float* st2 = nullptr) {
   const int P = H * H;
-  RGM_TRY(group_norm(c, cur, t1, P, Cin, key + "norm1", 1, c.split));
-  RGM_TRY(conv3(c, t1, t2, H, Cin, Cout, key + "conv1", 0, nullptr, c.split));
-  RGM_TRY(group_norm(c, t2, t1, P, Cout, key + "norm2", 1, c.split));
-  if (Cin == Cout) {
-    RGM_TRY(conv3(c, t1, cur, H, Cout, Cout, key + "conv2", 0, cur, c.split));  // in place: out = conv2(.) + x
-  } else {
-    RGM_TRY(conv3(c, t1, t2, H, Cout, Cout, key + "conv2", 0, nullptr, c.split));
-    RGM_TRY(conv1(c, cur, t1, c.M * P, Cin, Cout, key + "nin_shortcut", t2));  // t1 = nin(x) + h
-    std::swap(cur, t1);
-  }
+  RGM_TRY(group_norm(c, x, t1, P, Cin, key + "norm1", 1, c.split, st1));
+  RGM_TRY(conv3(c, t1, b, H, Cin, Cout, key + "conv1", 0, nullptr, c.split));
+  RGM_TRY(group_norm(c, b, t1, P, Cout, key + "norm2", 1, c.split, st2));
+  if (Cin == Cout) return conv3(c, t1, out, H, Cout, Cout, key + "conv2", 0, x, c.split);  // out = conv2(.) + x
+  RGM_TRY(conv3(c, t1, hbuf, H, Cout, Cout, key + "conv2", 0, nullptr, c.split));
+  return conv1(c, x, out, c.M * P, Cin, Cout, key + "nin_shortcut", hbuf);                  // out = nin(x) + h
+}
+// the three-buffer in-place form the plain decode / encode schedules use: cur <- block(cur)
+int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout, const std::string& key) {
+  if (Cin == Cout) return resnet(c, cur, t2, nullptr, cur, t1, H, Cin, Cout, key);
+  RGM_TRY(resnet(c, cur, t2, t2, t1, t1, H, Cin, Cout, key));   // conv2 has consumed t1 before nin writes it
+  std::swap(cur, t1);
   return RGM_OK;
 }
 
 // AttnBlock (taming model.py:140-192) on the 256 tokens of a 16x16 map, single head of width C: cur <- cur + proj(attn(norm(cur)))
-int attn_block(Ctx& c, float* cur, float* t1, const std::string& a, int C) {
+// (out may alias x; q, k, v and the softmax stay in the plan's buffers, where the backward pass finds them)
+int attn_block(Ctx& c, const float* cur, float* out, float* t1, const std::string& a, int C, float* st = nullptr) {
   const int M = c.M, rows = M * 256;
   hipStream_t s = c.s;
-  RGM_TRY(group_norm(c, cur, t1, 256, C, a + "norm", 0));
+  RGM_TRY(group_norm(c, cur, t1, 256, C, a + "norm", 0, 0, st));
   RGM_TRY(conv1(c, t1, c.p.q, rows, C, C, a + "q", nullptr));
   RGM_TRY(conv1(c, t1, c.p.k, rows, C, C, a + "k", nullptr));
   RGM_TRY(conv1(c, t1, c.p.v, rows, C, C, a + "v", nullptr));
@@ -571,7 +814,7 @@ int attn_block(Ctx& c, float* cur, float* t1, const std::string& a, int C) {
   o.A = c.p.sc; o.lda = 256; o.sA = 256LL * 256; o.B = c.p.vt; o.ldb = 256; o.sB = 256LL * C;
   o.C = t1; o.ldc = C; o.sC = 256LL * C; o.M = 256; o.N = C; o.K = 256; o.batch = M;
   RGM_TRY(gemm_launch(o, s));
-  return conv1(c, t1, cur, rows, C, C, a + "proj_out", cur);  // x + proj_out(o), in place
+  return conv1(c, t1, out, rows, C, C, a + "proj_out", cur);  // x + proj_out(o)
 }
 }  // namespace
 
@@ -611,7 +854,7 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
     RGM_LAUNCH_CHECK();
   }
   RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, d + "mid.block_1."));
-  RGM_TRY(attn_block(c, cur, t1, d + "mid.attn_1.", C));
+  RGM_TRY(attn_block(c, cur, cur, t1, d + "mid.attn_1.", C));
   RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, d + "mid.block_2."));
   int H = 16;
   for (int lvl = 3; lvl >= 0; --lvl) {
@@ -649,6 +892,260 @@ extern "C" int rgm_vae_decode_latent(rgm_vae* h, const float* latent, float inv_
   RGM_REQUIRE(H > 0 && H % 16 == 0, "vae_decode_latent: H=%d must be a multiple of 16", H);
   return decode_impl(h, latent, N, H / 16, 4LL * H * 16, 256, (long long)H * 16, 1, 16, inv_scale, roll, roll_u8, threshold, ws,
                      ws_bytes, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------- decode with saves + input-gradient pass
+// The workspace of the grad entry points = the plain plan (scratch, attention tensors) followed by a tape: the input x and
+// the conv1 output b of every ResnetBlock, the attention / upsample inputs and every GroupNorm's (mean, rstd).  Its
+// layout is a pure function of M, so the backward call re-derives every pointer from the workspace it is handed.
+namespace {
+struct GNode {
+  int kind = 0;            // 0 ResnetBlock, 1 AttnBlock, 2 Upsample conv
+  const float* x = nullptr;
+  float *b = nullptr, *out = nullptr, *st1 = nullptr, *st2 = nullptr;
+  int H = 0, Cin = 0, Cout = 0;   // H: spatial size of the node's output
+  std::string key;
+};
+struct GradPlan {
+  VPlan p;
+  std::vector<GNode> nodes;
+  float *x0 = nullptr, *st_out = nullptr, *sums = nullptr;
+  const float* x_last = nullptr;
+  float *at[7] = {}, *as[3] = {};   // attention-backward scratch: token-sized / score-sized
+  size_t bytes = 0;
+};
+GradPlan gradplan(const rgm_vae* h, int M, void* ws) {
+  GradPlan g;
+  g.p = vplan(M, ws);
+  char* base = (char*)ws;
+  size_t off = g.p.bytes;
+  auto take = [&](size_t floats) {
+    char* r = base + off;
+    off += align_up(floats * sizeof(float), 256);
+    return (float*)r;
+  };
+  const std::string d = "decoder.";
+  int C = 512, H = 16;
+  g.x0 = take((size_t)M * 256 * C);
+  const float* cur = g.x0;
+  auto res = [&](const std::string& key, int Cin, int Cout) {
+    GNode n;
+    n.kind = 0; n.x = cur; n.H = H; n.Cin = Cin; n.Cout = Cout; n.key = key;
+    n.b = take((size_t)M * H * H * Cout);
+    n.out = take((size_t)M * H * H * Cout);
+    n.st1 = take((size_t)M * 64);
+    n.st2 = take((size_t)M * 64);
+    cur = n.out;
+    g.nodes.push_back(n);
+  };
+  res(d + "mid.block_1.", C, C);
+  {
+    GNode n;
+    n.kind = 1; n.x = cur; n.H = 16; n.Cin = n.Cout = C; n.key = d + "mid.attn_1.";
+    n.out = take((size_t)M * 256 * C);
+    n.st1 = take((size_t)M * 64);
+    cur = n.out;
+    g.nodes.push_back(n);
+  }
+  res(d + "mid.block_2.", C, C);
+  for (int lvl = 3; lvl >= 0; --lvl) {
+    const int bo = h->ch * CH_MULT[lvl];
+    for (int ib = 0; ib < 3; ++ib) {
+      res(d + "up." + std::to_string(lvl) + ".block." + std::to_string(ib) + ".", C, bo);
+      C = bo;
+    }
+    if (lvl != 0) {
+      H *= 2;
+      GNode n;
+      n.kind = 2; n.x = cur; n.H = H; n.Cin = n.Cout = C; n.key = d + "up." + std::to_string(lvl) + ".upsample.conv";
+      n.out = take((size_t)M * H * H * C);
+      cur = n.out;
+      g.nodes.push_back(n);
+    }
+  }
+  g.x_last = cur;
+  g.st_out = take((size_t)M * 64);
+  g.sums = take((size_t)M * 64);
+  for (auto& a : g.at) a = take((size_t)M * 256 * 512);
+  for (auto& a : g.as) a = take((size_t)M * 256 * 256);
+  g.bytes = off;
+  return g;
+}
+
+int check_grad_call(rgm_vae* h, const GradPlan& g, void* ws, size_t ws_bytes, const char* who) {
+  if (!h->grad_ready) {
+    set_error("%s: call rgm_vae_enable_grad after loading the decoder parameters", who);
+    return RGM_ERR_STATE;
+  }
+  if (!ws || g.bytes > ws_bytes) {
+    set_error("%s: workspace %zu bytes < required %zu (rgm_vae_grad_workspace_bytes)", who, ws_bytes, g.bytes);
+    return RGM_ERR_WORKSPACE;
+  }
+  return RGM_OK;
+}
+
+// dx = GroupNorm(+swish) backward of dz at input x (+ add); out may alias dz
+int group_norm_bwd(Ctx& c, const GradPlan& g, const float* x, const float* dz, const float* stats, float* out, int P, int C,
+                   const std::string& key, int swish, const float* add) {
+  const float *ga = c.h->p(key + ".weight"), *be = c.h->p(key + ".bias");
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(GN_CHUNKS, c.M), dim3(256), 0, c.s, x, dz, stats, ga, be, c.p.part, P, C, GN_CHUNKS, swish);
+  RGM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, g.sums, c.M, GN_CHUNKS,
+                     (double)P * (C / 32));
+  RGM_LAUNCH_CHECK();
+  const long long total4 = (long long)c.M * P * C / 4;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, dz, stats, g.sums, ga, be, add,
+                     out, total4, P, C, swish);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// input gradient of a 3x3 conv (forward Cin -> Cout at H x H): dx[M*H*H, Cin] = conv3x3(dy, mirrored W^T)
+int conv3_dgrad(Ctx& c, const float* dy, float* dx, int H, int Cin, int Cout, const std::string& key) {
+  GemmParams g;
+  g.A = dy; g.B = c.h->gp(key + ".weight.T"); g.ldb = 9 * Cout; g.C = dx; g.ldc = Cin;
+  g.M = c.M * H * H; g.N = Cin; g.K = 9 * Cout; g.lda = Cout;
+  g.aload = 1; g.H = H; g.W = H; g.Cin = Cout; g.logH = ilog2(H); g.logW = ilog2(H); g.ups = 0;
+  return gemm_launch(g, c.s);
+}
+// input gradient of a 1x1 conv: dx[rows, Cin] = dy[rows, Cout] . W (+ res)
+int conv1_dgrad(Ctx& c, const float* dy, float* dx, int rows, int Cin, int Cout, const std::string& key, const float* res) {
+  GemmParams g;
+  g.A = dy; g.lda = Cout; g.B = c.h->gp(key + ".weight.T"); g.ldb = Cout; g.C = dx; g.ldc = Cin;
+  g.M = rows; g.N = Cin; g.K = Cout; g.res = res; g.ldres = Cin;
+  return gemm_launch(g, c.s);
+}
+int bgemm(Ctx& c, const float* A, int lda, long long sA, const float* B, int ldb, long long sB, float* C, int ldc, long long sC,
+          int M, int N, int K) {
+  GemmParams g;
+  g.A = A; g.lda = lda; g.sA = sA; g.B = B; g.ldb = ldb; g.sB = sB; g.C = C; g.ldc = ldc; g.sC = sC;
+  g.M = M; g.N = N; g.K = K; g.batch = c.M;
+  return gemm_launch(g, c.s);
+}
+}  // namespace
+
+extern "C" size_t rgm_vae_grad_workspace_bytes(const rgm_vae* h, int M) {
+  if (!h || M <= 0) return 0;
+  return gradplan(h, M, nullptr).bytes;
+}
+
+// Same decode as decode_impl (same kernels in the same order, hence the same roll) with every tensor the backward needs kept.
+static int decode_save_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_stride, long long s_stride, long long sc,
+                            long long si, long long sj, float in_scale, float* roll, void* ws, size_t ws_bytes, hipStream_t s) {
+  RGM_REQUIRE(h && in && roll && Nb > 0 && S > 0, "vae_decode_save: bad arguments");
+  const int M = Nb * S;
+  GradPlan g = gradplan(h, M, ws);
+  RGM_TRY(check_grad_call(h, g, ws, ws_bytes, "vae_decode_save"));
+  Ctx c{h, g.p, M, s, rgm_get_gemm_precision() == 2 ? 1 : 0};
+  hipLaunchKernelGGL(vae_gather_pq_kernel, dim3(cdiv(M * 256, 256)), dim3(256), 0, s, in, h->p("post_quant_conv.weight"),
+                     h->p("post_quant_conv.bias"), c.p.pq, M, Nb, n_stride, s_stride, sc, si, sj, in_scale);
+  RGM_LAUNCH_CHECK();
+  {
+    const long long tot = (long long)M * 256 * 512;
+    hipLaunchKernelGGL(vae_conv_in_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, c.p.pq, h->p("decoder.conv_in.weight"),
+                       h->p("decoder.conv_in.bias"), g.x0, M, 512);
+    RGM_LAUNCH_CHECK();
+  }
+  float *t1 = c.p.b1, *t2 = c.p.b2;
+  for (const GNode& n : g.nodes) {
+    if (n.kind == 0) {
+      RGM_TRY(resnet(c, n.x, n.b, t2, n.out, t1, n.H, n.Cin, n.Cout, n.key, n.st1, n.st2));
+    } else if (n.kind == 1) {
+      RGM_TRY(attn_block(c, n.x, n.out, t1, n.key, n.Cin, n.st1));
+    } else if (c.split) {
+      RGM_TRY(split_rows_launch(n.x, t2, (long long)M * (n.H / 2) * (n.H / 2), n.Cin, n.Cin, n.Cin, s));
+      RGM_TRY(conv3(c, t2, n.out, n.H, n.Cin, n.Cin, n.key, 1, nullptr, 1));
+    } else {
+      RGM_TRY(conv3(c, n.x, n.out, n.H, n.Cin, n.Cin, n.key, 1, nullptr));
+    }
+  }
+  RGM_TRY(group_norm(c, g.x_last, t1, 128 * 128, 128, "decoder.norm_out", 1, 0, g.st_out));
+  hipLaunchKernelGGL(vae_conv_out_kernel, dim3(M * 64), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
+                     h->p("decoder.conv_out.bias"), roll, (uint8_t*)nullptr, M, Nb, S * 128, -0.95f);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// d_in = (d roll / d in)^T d_roll for the decode decode_save_impl ran on this workspace
+static int decode_vjp_impl(rgm_vae* h, const float* d_roll, int Nb, int S, long long n_stride, long long s_stride, long long sc,
+                           long long si, long long sj, float in_scale, float* d_in, void* ws, size_t ws_bytes, hipStream_t s) {
+  RGM_REQUIRE(h && d_roll && d_in && Nb > 0 && S > 0, "vae_decode_vjp: bad arguments");
+  const int M = Nb * S;
+  GradPlan g = gradplan(h, M, ws);
+  RGM_TRY(check_grad_call(h, g, ws, ws_bytes, "vae_decode_vjp"));
+  Ctx c{h, g.p, M, s, 0};
+  float *gr = c.p.b0, *s1 = c.p.b1, *s2 = c.p.b2;
+  hipLaunchKernelGGL(vae_conv_out_bwd_kernel, dim3((unsigned)(M * 16384LL * 32 / 256)), dim3(256), 0, s, d_roll,
+                     h->p("decoder.conv_out.weight"), gr, M, Nb, S * 128);
+  RGM_LAUNCH_CHECK();
+  RGM_TRY(group_norm_bwd(c, g, g.x_last, gr, g.st_out, gr, 128 * 128, 128, "decoder.norm_out", 1, nullptr));
+  for (auto it = g.nodes.rbegin(); it != g.nodes.rend(); ++it) {
+    const GNode& n = *it;
+    const int P = n.H * n.H;
+    if (n.kind == 2) {            // conv on the nearest-upsampled map: full-resolution input gradient, then fold the 2x2 blocks
+      RGM_TRY(conv3_dgrad(c, gr, s1, n.H, n.Cin, n.Cin, n.key));
+      const int Hh = n.H / 2, q = n.Cin / 4;
+      const long long total4 = (long long)M * Hh * Hh * q;
+      hipLaunchKernelGGL(sumpool2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, s1, s2, total4, Hh, q);
+      RGM_LAUNCH_CHECK();
+      std::swap(gr, s2);
+    } else if (n.kind == 0) {
+      RGM_TRY(conv3_dgrad(c, gr, s1, n.H, n.Cout, n.Cout, n.key + "conv2"));                                  // d swish(norm2(b))
+      RGM_TRY(group_norm_bwd(c, g, n.b, s1, n.st2, s1, P, n.Cout, n.key + "norm2", 1, nullptr));               // d b
+      RGM_TRY(conv3_dgrad(c, s1, s2, n.H, n.Cin, n.Cout, n.key + "conv1"));                                   // d swish(norm1(x))
+      if (n.Cin == n.Cout) {
+        RGM_TRY(group_norm_bwd(c, g, n.x, s2, n.st1, s2, P, n.Cin, n.key + "norm1", 1, gr));                   // + identity shortcut
+      } else {
+        RGM_TRY(group_norm_bwd(c, g, n.x, s2, n.st1, s2, P, n.Cin, n.key + "norm1", 1, nullptr));
+        RGM_TRY(conv1_dgrad(c, gr, s2, M * P, n.Cin, n.Cout, n.key + "nin_shortcut", s2));                     // + nin_shortcut^T
+      }
+      std::swap(gr, s2);
+    } else {                      // AttnBlock: out = x + proj(softmax(alpha q k^T) v), q/k/v = 1x1 convs of norm(x)
+      const int C = n.Cin, rows = M * 256;
+      const long long tk = 256LL * C, sq = 256LL * 256;
+      const float *q = c.p.q, *k = c.p.k, *v = c.p.v, *Pm = c.p.sc;
+      float *d_o = g.at[0], *d_oT = g.at[1], *dv = g.at[2], *kT = g.at[3], *dq = g.at[4], *qT = g.at[5], *dk = g.at[6];
+      float *dS = g.as[0], *Pt = g.as[1], *dSt = g.as[2];
+      RGM_TRY(conv1_dgrad(c, gr, d_o, rows, C, C, n.key + "proj_out", nullptr));
+      RGM_TRY(bgemm(c, d_o, C, tk, v, C, tk, dS, 256, sq, 256, 256, C));                  // dP[i][j] = d_o[i] . v[j]
+      hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, Pm, dS, rows, 256, 1.0f / sqrtf((float)C));
+      RGM_LAUNCH_CHECK();
+      RGM_TRY(transpose_launch(Pm, Pt, 256, 256, 256, M, s));
+      RGM_TRY(transpose_launch(d_o, d_oT, 256, C, 256, M, s));
+      RGM_TRY(bgemm(c, Pt, 256, sq, d_oT, 256, tk, dv, C, tk, 256, C, 256));              // dv[j] = sum_i P[i][j] d_o[i]
+      RGM_TRY(transpose_launch(k, kT, 256, C, 256, M, s));
+      RGM_TRY(bgemm(c, dS, 256, sq, kT, 256, tk, dq, C, tk, 256, C, 256));                // dq[i] = sum_j dS[i][j] k[j]
+      RGM_TRY(transpose_launch(dS, dSt, 256, 256, 256, M, s));
+      RGM_TRY(transpose_launch(q, qT, 256, C, 256, M, s));
+      RGM_TRY(bgemm(c, dSt, 256, sq, qT, 256, tk, dk, C, tk, 256, C, 256));               // dk[j] = sum_i dS[i][j] q[i]
+      RGM_TRY(conv1_dgrad(c, dq, s1, rows, C, C, n.key + "q", nullptr));
+      RGM_TRY(conv1_dgrad(c, dk, s1, rows, C, C, n.key + "k", s1));
+      RGM_TRY(conv1_dgrad(c, dv, s1, rows, C, C, n.key + "v", s1));
+      RGM_TRY(group_norm_bwd(c, g, n.x, s1, n.st1, s1, 256, C, n.key + "norm", 0, gr));
+      std::swap(gr, s1);
+    }
+  }
+  hipLaunchKernelGGL(vae_conv_in_bwd_kernel, dim3(cdiv(M * 256, 4)), dim3(256), 0, s, gr, h->p("decoder.conv_in.weight"),
+                     h->p("post_quant_conv.weight"), d_in, M, 512, Nb, n_stride, s_stride, sc, si, sj, in_scale);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// decode_latent keeping what rgm_vae_decode_latent_vjp needs in `ws` (rgm_vae_grad_workspace_bytes(h, N*H/16) bytes, left
+// untouched by the caller between the two calls).  roll (N,3,128,8H) is the same as rgm_vae_decode_latent's.
+extern "C" int rgm_vae_decode_latent_save(rgm_vae* h, const float* latent, float inv_scale, float* roll, int N, int H, void* ws,
+                                          size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(H > 0 && H % 16 == 0, "vae_decode_latent_save: H=%d must be a multiple of 16", H);
+  return decode_save_impl(h, latent, N, H / 16, 4LL * H * 16, 256, (long long)H * 16, 1, 16, inv_scale, roll, ws, ws_bytes,
+                          (hipStream_t)stream);
+}
+// d_latent (N,4,H,16) = (d roll / d latent)^T d_roll, d_roll (N,3,128,8H): reference autograd through _decode
+// (gaussian_diffusion.py:1347-1358) -> AutoencoderKL.decode, as the dps_rule branch of condition_mean differentiates it (:425-433)
+extern "C" int rgm_vae_decode_latent_vjp(rgm_vae* h, const float* d_roll, float inv_scale, float* d_latent, int N, int H, void* ws,
+                                         size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(H > 0 && H % 16 == 0, "vae_decode_latent_vjp: H=%d must be a multiple of 16", H);
+  return decode_vjp_impl(h, d_roll, N, H / 16, 4LL * H * 16, 256, (long long)H * 16, 1, 16, inv_scale, d_latent, ws, ws_bytes,
+                         (hipStream_t)stream);
 }
 
 extern "C" int rgm_quantise_roll(const float* roll, uint8_t* out_u8, int B, int T, float threshold, void* stream) {
@@ -698,7 +1195,7 @@ extern "C" int rgm_vae_encode(rgm_vae* h, const float* x, float* moments, int M,
     }
   }
   RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, e + "mid.block_1."));
-  RGM_TRY(attn_block(c, cur, t1, e + "mid.attn_1.", C));
+  RGM_TRY(attn_block(c, cur, cur, t1, e + "mid.attn_1.", C));
   RGM_TRY(resnet(c, cur, t1, t2, 16, C, C, e + "mid.block_2."));
   RGM_TRY(group_norm(c, cur, t1, 256, C, e + "norm_out", 1));
   RGM_TRY(conv3(c, t1, t2, 16, C, 8, e + "conv_out", 0, nullptr));          // [M*256][8]

@@ -4,11 +4,13 @@
 model_fn / dc_model_fn are thin: class-conditional call, null label (= num_classes) when unconditional,
 classifier-free guidance as one 2B-row forward.  The grad_nn_zt_* guidance functions call the classifier's
 fused value-and-input-gradient kernel chain (no autograd graph; weights are frozen at sampling time).
-DPS variants nn_z0_* are provided (value + input gradient from the same fused chain); rule_x0_* (through the VAE decoder)
-are a 'next' row.
+DPS variants: nn_z0_* (value + input gradient from the same fused chain) and rule_x0_* on the decoded roll (value + roll
+gradient; the sampler pulls it back through the VAE decoder and the eps-network).
 """
 import torch as th
 import torch.nn as nn
+
+from rgm import native as _rgm
 
 
 def _null_labels(x, num_classes):
@@ -105,15 +107,68 @@ def _nn_z0_chord_dummy_vag(x, rule, classifier_scale, classifier):
     return _chord_logp(logits, rule, x.shape[0]) * classifier_scale, grad
 
 
-def _dps_rule(*a, **k):
-    raise NotImplementedError("DPS through rule(decode(x0)) (rule_x0_*) needs the VAE decoder's backward: 'next' row SURVEY 8f.1")
+# ---- DPS through a rule on the DECODED roll (reference :122-138; guidance.nn False, guidance.vae True).  x is the decoded
+# piano roll (N,3,128,T); the `_vag` twin also returns d log p / d roll, which the sampler pulls back through the VAE
+# decoder (rgm_vae_decode_latent_vjp) and the eps-network (rgm_dit_vjp) -- the reference leaves that to autograd.
+def rule_x0_mse_dummy(x, t, y=None, rule=None, rule_name='pitch_hist'):
+    from music_rule_guidance.rule_maps import FUNC_DICT
+    return _mse_logp(FUNC_DICT[rule_name](x), rule.to(x.device))
+
+
+def rule_x0_mse(x, rule=None, rule_name='pitch_hist', soft=False):
+    if soft:
+        raise NotImplementedError("soft rules: the reference's rule programs take no `soft` argument either")
+    from music_rule_guidance.rule_maps import FUNC_DICT
+    return _mse_logp(FUNC_DICT[rule_name](x), rule.to(x.device))
+
+
+def _rule_x0_vag(roll, rule, name, scale):
+    """(scale * log p (N,), d (scale * sum log p) / d roll or None when it is identically zero) for one rule program."""
+    import functools
+    from music_rule_guidance import music_rules, rule_maps
+    fn = rule_maps.FUNC_DICT[name]
+    base = fn.func if isinstance(fn, functools.partial) else fn
+    N, Cc, _, T = roll.shape
+    if fn is music_rules.total_pitch_class_histogram:
+        _rgm.require_cuda(roll)
+        assert roll.is_contiguous() and roll.dtype == th.float32
+        tgt = rule.to(roll.device, th.float32).reshape(N, 12).contiguous()
+        logp = th.empty((N,), dtype=th.float32, device=roll.device)
+        d_roll = th.empty_like(roll)
+        scratch = th.empty((N, 140), dtype=th.float32, device=roll.device)
+        with th.cuda.device(roll.device):
+            _rgm.check(_rgm.lib.rgm_rule_pitch_hist_vag(_rgm.ptr(roll), _rgm.ptr(tgt), float(scale), None, _rgm.ptr(logp),
+                                                        _rgm.ptr(d_roll), _rgm.ptr(scratch), N, Cc, T, _rgm.current_stream()))
+        return logp, d_roll
+    if base in (music_rules.note_density, music_rules.note_density_class, music_rules.get_chords):
+        # counting behind hard thresholds: the reference's autograd returns an all-zero gradient for these too
+        # (every element of the roll is overwritten by a constant before it is summed, music_rules.py:66-70)
+        return _mse_logp(fn(roll).reshape(N, -1).float(), rule.to(roll.device).reshape(N, -1)) * scale, None
+    with th.enable_grad():                                   # a user-registered torch rule: autograd on the roll only
+        r = roll.detach().requires_grad_(True)
+        lp = _mse_logp(fn(r).reshape(N, -1), rule.to(roll.device).reshape(N, -1)) * scale
+        g = th.autograd.grad(lp.sum(), r)[0]
+    return lp.detach(), g
+
+
+def composite_rule_value_and_grad(roll, t, y=None, rule=None, fns=None, classifier_scales=None, rule_names=None):
+    """(log_probs (N,), d sum(log_probs) / d roll) of composite_rule on a decoded roll."""
+    lp, grad = 0, None
+    for fn, scale, name in zip(fns, classifier_scales, rule_names):
+        if fn not in ("rule_x0_mse_dummy", "rule_x0_mse"):
+            raise NotImplementedError(f"DPS rule guidance with cond_fn '{fn}'")
+        a, b = _rule_x0_vag(roll, rule[name], name, scale)
+        lp = lp + a
+        if b is not None:
+            grad = b if grad is None else grad + b
+    return lp, grad
 
 
 function_map = {
     "grad_nn_zt_mse": grad_nn_zt_mse,
     "grad_nn_zt_chord": grad_nn_zt_chord,
     "nn_z0_chord_dummy": nn_z0_chord_dummy, "nn_z0_mse_dummy": nn_z0_mse_dummy, "nn_z0_mse": nn_z0_mse,
-    "rule_x0_mse_dummy": _dps_rule, "rule_x0_mse": _dps_rule,
+    "rule_x0_mse_dummy": rule_x0_mse_dummy, "rule_x0_mse": rule_x0_mse,
 }
 _vag_map = {"nn_z0_mse_dummy": _nn_z0_mse_dummy_vag, "nn_z0_chord_dummy": _nn_z0_chord_dummy_vag}
 

@@ -315,14 +315,14 @@ class GaussianDiffusion:
         """Classifier guidance on the mean: mean + variance * grad log p(y|x_t)   (non-DPS branch)."""
         self._reject_unsupported(None, edit_kwargs, guidance_kwargs)
         if getattr(guidance_kwargs, "method", None) == "dps":
-            return self._dps_mean(cond_fn, p_mean_var, x, t, model_kwargs or {}, guidance_kwargs, model, embed_model)
+            return self._dps_mean(cond_fn, p_mean_var, x, t, model_kwargs or {}, guidance_kwargs, model, embed_model, scale_factor)
         if edit_kwargs is None:
             grad = cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
         else:
             grad = self._edit_grad(cond_fn, x, self._scale_timesteps(t), model_kwargs or {}, edit_kwargs)
         return p_mean_var["mean"].float() + p_mean_var["variance"] * grad.float()
 
-    def _dps_mean(self, cond_fn, p_mean_var, x, t, model_kwargs, guidance_kwargs, model, embed_model):
+    def _dps_mean(self, cond_fn, p_mean_var, x, t, model_kwargs, guidance_kwargs, model, embed_model, scale_factor=1.):
         """DPS (reference :415-465): mean + step_size * d log p(rule | x0_hat(x_t)) / d x_t / sqrt(-log p), where
         x0_hat = c1 x_t - c2 eps(x_t).  The reference differentiates through the eps-network and the classifier with
         autograd; here d/dx_t = c1 g + (d eps/d x_t)^T (-c2 g) with g = d log p / d x0 from the classifier's fused
@@ -330,11 +330,11 @@ class GaussianDiffusion:
         import functools
         from . import condition_functions as cf
         assert model is not None
-        if embed_model is not None and not getattr(guidance_kwargs, "nn", True):
-            raise NotImplementedError("DPS through rule(decode(x0)) needs the VAE decoder's backward: 'next' row SURVEY 8f.1")
+        through_vae = embed_model is not None and not getattr(guidance_kwargs, "nn", True)
         inner_c = cond_fn.model if hasattr(cond_fn, "map_ts") else cond_fn
-        if not (isinstance(inner_c, functools.partial) and inner_c.func is cf.composite_nn_zt):
-            raise NotImplementedError("DPS guidance expects cond_fn = partial(composite_nn_zt, ...)")
+        want = cf.composite_rule if through_vae else cf.composite_nn_zt
+        if not (isinstance(inner_c, functools.partial) and inner_c.func is want):
+            raise NotImplementedError(f"DPS guidance expects cond_fn = partial({want.__name__}, ...)")
         ts = self._scale_timesteps(t)
         inner_m = model.model if hasattr(model, "map_ts") else model
         ts_m = model.map_ts(ts) if hasattr(model, "map_ts") else ts
@@ -348,7 +348,18 @@ class GaussianDiffusion:
         eps = net.vjp_forward(x, ts_m, y)
         x0 = self._predict_xstart_from_eps(x, t, eps)
         rule_kwargs = {k: v for k, v in model_kwargs.items() if k in ("y", "rule")}
-        log_probs, g0 = cf.composite_nn_zt_value_and_grad(x0, ts, **rule_kwargs, **inner_c.keywords)
+        if through_vae:
+            # rule(_decode(x0_hat)) (reference :425-433): decode keeping the activations, d log p / d roll from the rule
+            # program, pulled back through the decoder (rgm_vae_decode_latent_vjp) -- autograd's job in the reference
+            if not hasattr(embed_model, "decode_latent_save"):
+                raise NotImplementedError("DPS rule guidance needs the native AutoencoderKL (decode_latent_save / _vjp)")
+            roll = embed_model.decode_latent_save(x0, scale_factor=scale_factor)
+            log_probs, d_roll = cf.composite_rule_value_and_grad(roll, ts, **rule_kwargs, **inner_c.keywords)
+            if d_roll is None:        # only hard-threshold rules: the gradient is identically zero (in the reference as well)
+                return p_mean_var["mean"].float()
+            g0 = embed_model.decode_latent_vjp(d_roll)
+        else:
+            log_probs, g0 = cf.composite_nn_zt_value_and_grad(x0, ts, **rule_kwargs, **inner_c.keywords)
         c1 = self._per_sample(self.sqrt_recip_alphas_cumprod, t, x)
         c2 = self._per_sample(self.sqrt_recipm1_alphas_cumprod, t, x)
         grad = c1 * g0 + net.vjp_backward(-c2 * g0)

@@ -52,8 +52,13 @@ def _load():
         "rgm_vae_workspace_bytes": (sz, [vp, i32]),
         "rgm_vae_decode": (C.c_int, [vp, vp, vp, i32, vp, sz, vp]),
         "rgm_vae_decode_latent": (C.c_int, [vp, vp, f32, vp, vp, f32, i32, i32, vp, sz, vp]),
+        "rgm_vae_enable_grad": (C.c_int, [vp]),
+        "rgm_vae_grad_workspace_bytes": (sz, [vp, i32]),
+        "rgm_vae_decode_latent_save": (C.c_int, [vp, vp, f32, vp, i32, i32, vp, sz, vp]),
+        "rgm_vae_decode_latent_vjp": (C.c_int, [vp, vp, f32, vp, i32, i32, vp, sz, vp]),
         "rgm_quantise_roll": (C.c_int, [vp, vp, i32, i32, f32, vp]),
         "rgm_rule_pitch_hist": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
+        "rgm_rule_pitch_hist_vag": (C.c_int, [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_rule_note_density": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, vp]),
         "rgm_bucketize": (C.c_int, [vp, vp, i32, vp, i32, vp]),
         "rgm_row_loss": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),

@@ -146,6 +146,44 @@ class AutoencoderKL(nn.Module):
         return u8 if want_u8 else roll
 
     @torch.no_grad()
+    def decode_latent_save(self, latent, scale_factor=1.):
+        """decode_latent keeping the activations decode_latent_vjp needs (rgm_vae_decode_latent_save): what the reference gets
+        from autograd when dps_rule differentiates rule(_decode(x0_hat)) (gaussian_diffusion.py:425-433)."""
+        _rgm.require_cuda(latent)
+        dev = self._ensure_native()
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_vae_enable_grad(self._handle))            # no-op once built; set_param invalidates
+        latent = latent.detach().to(torch.float32).contiguous()
+        N, Cc, H, W = latent.shape
+        assert Cc == 4 and W == 16 and H % 16 == 0, f"latent must be (N,4,16k,16), got {tuple(latent.shape)}"
+        need = _rgm.lib.rgm_vae_grad_workspace_bytes(self._handle, N * (H // 16))
+        if getattr(self, "_gws", None) is None or self._gws.numel() < need or self._gws.device != dev:
+            self._gws = None
+            self._gws = torch.empty(need, dtype=torch.uint8, device=dev)
+        roll = torch.empty((N, 3, 128, 8 * H), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_vae_decode_latent_save(self._handle, _rgm.ptr(latent), 1.0 / float(scale_factor), _rgm.ptr(roll),
+                                                           N, H, _rgm.ptr(self._gws), need, _rgm.current_stream()))
+        self._saved = (N, H, 1.0 / float(scale_factor), need)
+        return roll
+
+    @torch.no_grad()
+    def decode_latent_vjp(self, d_roll):
+        """d_latent (N,4,H,16) = (d roll / d latent)^T d_roll for the last decode_latent_save."""
+        if getattr(self, "_saved", None) is None:
+            raise _rgm.RgmError("decode_latent_vjp: no decode_latent_save to differentiate")
+        N, H, inv_scale, need = self._saved
+        _rgm.require_cuda(d_roll)
+        dev = d_roll.device
+        d_roll = d_roll.detach().to(torch.float32).contiguous()
+        assert tuple(d_roll.shape) == (N, 3, 128, 8 * H), f"d_roll must be {(N, 3, 128, 8 * H)}, got {tuple(d_roll.shape)}"
+        out = torch.empty((N, 4, H, 16), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _rgm.check(_rgm.lib.rgm_vae_decode_latent_vjp(self._handle, _rgm.ptr(d_roll), inv_scale, _rgm.ptr(out), N, H,
+                                                          _rgm.ptr(self._gws), need, _rgm.current_stream()))
+        return out
+
+    @torch.no_grad()
     def encode_save(self, x, range_fix=False):
         """x (M,3,128,128) piano-roll tiles in [-1,1] -> moments (M,8,16,16): mean | logvar (klvae_pedal.py:61-68)."""
         _rgm.require_cuda(x)

@@ -567,6 +567,69 @@ def g_dps():
     save("dps", **out)
 
 
+def g_dpsrule():
+    """DPS through rule(decode(x0)) (dps_rule): the VAE decoder's input gradient via the reference's autograd
+    through _decode, the differentiable pitch histogram, and full dps_rule steps.  The roll cotangent of the decoder VJP is
+    np.random.RandomState(seed).randn -- the test regenerates it instead of storing 1.5 MB."""
+    print("[dps_rule: decoder VJP (autograd through _decode), pitch_hist gradient, rule_x0 guided steps]")
+    from functools import partial
+    from types import SimpleNamespace
+    rng = np.random.RandomState(1200)
+    out = {}
+    vae = RefVAE(2)
+    torch.set_grad_enabled(True)
+    lat = rng.randn(2, 4, 32, 16).astype(F32)
+    gseed = 1201
+    g = np.random.RandomState(gseed).randn(2, 3, 128, 256).astype(F32)
+    lt = torch.from_numpy(lat).requires_grad_(True)
+    roll = rgd._decode(lt, vae, scale_factor=1.2465)
+    dl = torch.autograd.grad((roll * torch.from_numpy(g)).sum(), lt)[0]
+    out.update({"vjp.lat": lat, "vjp.gseed": np.array(gseed), "vjp.dlat": dl.numpy(), "vjp.roll_sum": roll.detach().numpy().sum(axis=(2, 3))})
+    print(f"    decoder vjp: |d_lat| {np.abs(dl.numpy()).max():.4f}")
+    # pitch_hist value and gradient on a decoded-like roll (smooth values: the rule is differentiated, not thresholded)
+    rseed = 1202
+    r = (np.random.RandomState(rseed).rand(2, 3, 128, 256).astype(F32) * 2 - 1) * 0.8
+    tgt = rng.rand(2, 12).astype(F32)
+    tgt /= tgt.sum(-1, keepdims=True)
+    rt = torch.from_numpy(r.copy()).requires_grad_(True)
+    lp = rcf.rule_x0_mse_dummy(rt * 1.0, None, rule=torch.from_numpy(tgt), rule_name="pitch_hist")
+    gr = torch.autograd.grad(lp.sum(), rt)[0]
+    out.update({"ph.rseed": np.array(rseed), "ph.target": tgt, "ph.logp": lp.detach().numpy(), "ph.grad_rows": gr.numpy()[:, :, :, 0]})
+    assert np.abs(gr.numpy() - gr.numpy()[:, :, :, :1]).max() == 0      # constant along time: only column 0 is stored
+    print(f"    pitch_hist logp {lp.detach().numpy()}  |grad| {np.abs(gr.numpy()).max():.3e}")
+    # ---- dps_rule steps (condition_mean dps branch, guidance.nn False) with the SM backbone and the reference Decoder
+    m, sd = ref_dit(SM, 11)
+    mf = ref_model_fn(m, 3, True)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    rule = {"pitch_hist": tgt}
+    cond = partial(rcf.composite_rule, fns=["rule_x0_mse_dummy"], classifier_scales=[1.], rule_names=["pitch_hist"])
+    out.update({"x": x, "y": y, "rule": tgt})
+    for tag, rs, ti in (("dpsr250", "250", 90), ("dpsr", "", 520)):
+        d = make_diffusion(rs)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        gk = SimpleNamespace(schedule=False, method="dps", step_size=100.0, nn=False, vae=True)
+        t0 = time.time()
+        r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, cond_fn=cond,
+                       model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in rule.items()}},
+                       guidance_kwargs=gk, embed_model=vae, scale_factor=1.2465)
+        r0 = make_diffusion(rs)
+        r0.t_end = 0
+        NQ.push(nz)
+        u = r0.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False,
+                        model_kwargs={"y": torch.from_numpy(y)})
+        shift = (r["sample"] - u["sample"]).detach().numpy()
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].detach().numpy(),
+                    f"{tag}.pred_xstart": r["pred_xstart"].detach().numpy(), f"{tag}.shift": shift})
+        print(f"    {tag}: guidance shift |max| {np.abs(shift).max():.4e}  ({time.time() - t0:.0f} s)")
+    torch.set_grad_enabled(False)
+    save("dps_rule", **out)
+
+
 def g_collage():
     print("[diff_collage]")
     m, sd = ref_dit(SM, 11)
@@ -664,7 +727,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -687,6 +750,8 @@ if __name__ == "__main__":
         g_edit()
     if "dps" in which:
         g_dps()
+    if "dpsrule" in which:
+        g_dpsrule()
     if "cli" in which:
         g_cli()
     if "e2e" in which:
