@@ -194,6 +194,35 @@ class C3Workload:
         self.x = out["sample"]
 
 
+class DPSRuleWorkload(SCGWorkload):
+    """One DPS step through the rule itself (cond_table/single/dps_rule/pitch.yml): eps-network forward with saves,
+    x0 -> VAE decode with saves -> pitch_hist log p and roll gradient -> decoder input-gradient pass -> eps-network VJP."""
+    name = ("dps_rule guided DDPM step ('250' chain), DiTRotary_XL_8 forward+VJP + KL-VAE decode+input-gradient + pitch_hist "
+            "value-and-grad, batch 16")
+
+    def __init__(self, device, batch):
+        from functools import partial
+        from types import SimpleNamespace
+        from guided_diffusion.condition_functions import composite_rule
+        super().__init__(device, batch)
+        self.d = make_diffusion("250")
+        self.d.t_end = 0
+        self.cond = partial(composite_rule, fns=["rule_x0_mse_dummy"], classifier_scales=[1.], rule_names=["pitch_hist"])
+        self.kw = {"y": self.kw["y"], "rule": {"pitch_hist": self.kw["rule"]["pitch_hist"]}}
+        self.guid = SimpleNamespace(schedule=False, method="dps", step_size=1.0, nn=False, vae=True)
+        self.flop_per_step = batch * (3 * DIT_GFLOP_PER_SAMPLE + 3 * 8 * VAE_GFLOP_PER_TILE) * 1e9
+
+    def step(self):
+        i = 249 - (self.k % 250)
+        self.k += 1
+        t = torch.full((self.B,), i, dtype=torch.int64, device=self.device)
+        self.d._t_host = i
+        out = self.d.p_sample(self.fn, self.x, t, clip_denoised=False, cond_fn=self.cond, model_kwargs=self.kw,
+                              embed_model=self.vae, scale_factor=1.2465, guidance_kwargs=self.guid)
+        self.d._t_host = None
+        self.x = out["sample"]
+
+
 def roofline_pass(work, steps=2):
     """Dominant-kernel roofline from HIP events around every GEMM launch (its own short pass)."""
     from rgm import native as R
@@ -285,7 +314,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=None)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg", "long"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg", "long", "dps_rule"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="--workload scg on ONE GPU: time the per-rank work of an R-GPU run (this process scores candidates "
@@ -311,8 +340,9 @@ def main():
     from rgm import native as R
     R.set_gemm_precision(args.precision)
     torch.manual_seed(0)
-    batch = args.batch or {"c2": 16, "c3": 32, "scg": 4, "long": 1}[args.workload]
-    work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload, "long": LongWorkload}[args.workload](device, batch)
+    batch = args.batch or {"c2": 16, "c3": 32, "scg": 4, "long": 1, "dps_rule": 16}[args.workload]
+    work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload, "long": LongWorkload,
+            "dps_rule": DPSRuleWorkload}[args.workload](device, batch)
     if args.simulate_ranks > 1:
         assert args.workload in ("scg", "long") and world == 1, "--simulate-ranks is a single-GPU SCG experiment"
         from rgm import scg_shard

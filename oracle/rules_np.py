@@ -36,6 +36,26 @@ def pitch_hist(roll):
     return hist[0] if hist.shape[0] == 1 else hist
 
 
+def pitch_hist_logp_grad(roll, target, scale=1.0):
+    """rule_x0_mse_dummy on pitch_hist (condition_functions.py:122-126 over music_rules.py:29-43) with its gradient written out:
+    log p = -scale * sum_c (hist_c - target_c)^2 (N,), and d log p / d roll (N,C,128,T).  hist = h / (sum h + 1e-12) with h_c the
+    sum of (x+1)/2 over the piano rows of class c, so d/d x = 0.5 * (u_c - sum_k u_k hist_k) / (sum h + 1e-12), u = -2 scale (hist -
+    target), on channel 0's piano rows [21,108] and 0 elsewhere (piano_like overwrites the other rows with a constant)."""
+    pr = piano_like(roll[:, :1])
+    h128 = ((pr + 1) / F32(2.0))[:, 0].sum(-1, dtype=np.float64)                    # (N,128)
+    h = np.concatenate((h128, np.zeros((h128.shape[0], 4))), axis=-1).reshape(-1, 11, 12).sum(1)
+    d = h.sum(-1, keepdims=True) + 1e-12
+    hist = h / d
+    e = hist - np.asarray(target, dtype=np.float64).reshape(hist.shape)
+    logp = -scale * (e * e).sum(-1)
+    u = -2.0 * scale * e
+    dh = (u - (u * hist).sum(-1, keepdims=True)) / d                                 # (N,12)
+    grad = np.zeros(roll.shape, dtype=np.float64)
+    p = np.arange(MIN_PIANO, MAX_PIANO + 1)
+    grad[:, 0, p, :] = 0.5 * dh[:, p % 12][:, :, None]
+    return logp.astype(F32), grad.astype(F32)
+
+
 def note_density(roll, interval=128, horizontal_scale=5):
     """(N,C,128,T) -> (N, 2*T/interval): [vertical windows..., horizontal windows...]."""
     pr = piano_like(roll[:, :1])

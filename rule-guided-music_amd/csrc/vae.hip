@@ -326,7 +326,7 @@ __global__ void gn_bwd_finalize_kernel(const double* __restrict__ part, float* _
 __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* dz, const float* __restrict__ stats,
                                     const float* __restrict__ sums, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* add, float* out, long long total4, int P, int C,
-                                    int swish) {
+                                    int swish, int out_split) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int q = C >> 2;
@@ -350,7 +350,20 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* dz
     const float4 a = reinterpret_cast<const float4*>(add)[i];
     o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
   }
-  reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  if (out_split) {   // split-row pixels for the pre-split input-gradient conv (out must not alias dz then)
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      hi[k] = (__bf16)o[k];
+      lo[k] = (__bf16)(o[k] - (float)hi[k]);
+    }
+    __bf16* px = reinterpret_cast<__bf16*>(out + (i / q) * C);
+    *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4)) = hi;
+    *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4) + 32) = lo;
+  } else {
+    reinterpret_cast<float4*>(out)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
 }
 
 // conv_out backward: d_in[m][y][x][c] = sum_{co,ky,kx} d_roll[n][co][y-ky+1][s*128 + x-kx+1] * w[co][ky*3+kx][c]
@@ -665,10 +678,15 @@ extern "C" int rgm_vae_enable_grad(rgm_vae* h) {
       if (!c3 && !c1) continue;
       h->goff[k + ".T"] = off;
       off += (s.numel + 3) / 4 * 4;
+      if (c3) {   // split-row copy for the pre-split kernel (rows = Cin, K = 9*Cout: a 32-block never straddles a tap)
+        h->goff[k + ".TS"] = off;
+        off += (s.numel + 3) / 4 * 4;
+      }
     }
     RGM_CHECK_HIP(hipMalloc(&h->garena, off * sizeof(float)));
   }
   for (auto& kv : h->goff) {
+    if (kv.first.compare(kv.first.size() - 3, 3, ".TS") == 0) continue;   // written with its ".T" twin
     const std::string key = kv.first.substr(0, kv.first.size() - 2);
     const VSlot& s = h->slots.at(key);
     float* dst = h->garena + kv.second;
@@ -676,6 +694,7 @@ extern "C" int rgm_vae_enable_grad(rgm_vae* h) {
       hipLaunchKernelGGL(repack_conv3_dgrad_kernel, dim3((unsigned)((s.numel + 255) / 256)), dim3(256), 0, 0, h->arena + s.off, dst,
                          s.cout, s.cin);
       RGM_LAUNCH_CHECK();
+      RGM_TRY(split_rows_launch(dst, h->garena + h->goff.at(key + ".TS"), s.cin, 9 * s.cout, 9 * s.cout, 9 * s.cout, 0));
     } else {   // [Cout][Cin] -> [Cin][Cout]; 1x1 slots do not record their shape: bias length = Cout
       const int cout = (int)h->slots.at(key.substr(0, key.size() - 6) + "bias").numel;
       const int cin = (int)(s.numel / cout);
@@ -986,7 +1005,7 @@ int check_grad_call(rgm_vae* h, const GradPlan& g, void* ws, size_t ws_bytes, co
 
 // dx = GroupNorm(+swish) backward of dz at input x (+ add); out may alias dz
 int group_norm_bwd(Ctx& c, const GradPlan& g, const float* x, const float* dz, const float* stats, float* out, int P, int C,
-                   const std::string& key, int swish, const float* add) {
+                   const std::string& key, int swish, const float* add, int out_split = 0) {
   const float *ga = c.h->p(key + ".weight"), *be = c.h->p(key + ".bias");
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(GN_CHUNKS, c.M), dim3(256), 0, c.s, x, dz, stats, ga, be, c.p.part, P, C, GN_CHUNKS, swish);
   RGM_LAUNCH_CHECK();
@@ -995,18 +1014,19 @@ int group_norm_bwd(Ctx& c, const GradPlan& g, const float* x, const float* dz, c
   RGM_LAUNCH_CHECK();
   const long long total4 = (long long)c.M * P * C / 4;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, dz, stats, g.sums, ga, be, add,
-                     out, total4, P, C, swish);
+                     out, total4, P, C, swish, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
 // input gradient of a 3x3 conv (forward Cin -> Cout at H x H): dx[M*H*H, Cin] = conv3x3(dy, mirrored W^T)
-int conv3_dgrad(Ctx& c, const float* dy, float* dx, int H, int Cin, int Cout, const std::string& key) {
+// (in_split: dy holds split-row pixels -> pre-split LDS-DMA kernel on the ".TS" weights)
+int conv3_dgrad(Ctx& c, const float* dy, float* dx, int H, int Cin, int Cout, const std::string& key, int in_split = 0) {
   GemmParams g;
-  g.A = dy; g.B = c.h->gp(key + ".weight.T"); g.ldb = 9 * Cout; g.C = dx; g.ldc = Cin;
+  g.A = dy; g.B = c.h->gp(key + (in_split ? ".weight.TS" : ".weight.T")); g.ldb = 9 * Cout; g.C = dx; g.ldc = Cin;
   g.M = c.M * H * H; g.N = Cin; g.K = 9 * Cout; g.lda = Cout;
   g.aload = 1; g.H = H; g.W = H; g.Cin = Cout; g.logH = ilog2(H); g.logW = ilog2(H); g.ups = 0;
-  return gemm_launch(g, c.s);
+  return in_split ? gemm2_launch(g, c.s) : gemm_launch(g, c.s);
 }
 // input gradient of a 1x1 conv: dx[rows, Cin] = dy[rows, Cout] . W (+ res)
 int conv1_dgrad(Ctx& c, const float* dy, float* dx, int rows, int Cin, int Cout, const std::string& key, const float* res) {
@@ -1073,8 +1093,9 @@ static int decode_vjp_impl(rgm_vae* h, const float* d_roll, int Nb, int S, long 
   const int M = Nb * S;
   GradPlan g = gradplan(h, M, ws);
   RGM_TRY(check_grad_call(h, g, ws, ws_bytes, "vae_decode_vjp"));
-  Ctx c{h, g.p, M, s, 0};
+  Ctx c{h, g.p, M, s, rgm_get_gemm_precision() == 2 ? 1 : 0};
   float *gr = c.p.b0, *s1 = c.p.b1, *s2 = c.p.b2;
+  const int sp = c.split;   // pre-split mode: the conv input gradients read split rows (one extra HBM pass where no producer writes them)
   hipLaunchKernelGGL(vae_conv_out_bwd_kernel, dim3((unsigned)(M * 16384LL * 32 / 256)), dim3(256), 0, s, d_roll,
                      h->p("decoder.conv_out.weight"), gr, M, Nb, S * 128);
   RGM_LAUNCH_CHECK();
@@ -1083,23 +1104,26 @@ static int decode_vjp_impl(rgm_vae* h, const float* d_roll, int Nb, int S, long 
     const GNode& n = *it;
     const int P = n.H * n.H;
     if (n.kind == 2) {            // conv on the nearest-upsampled map: full-resolution input gradient, then fold the 2x2 blocks
-      RGM_TRY(conv3_dgrad(c, gr, s1, n.H, n.Cin, n.Cin, n.key));
+      if (sp) RGM_TRY(split_rows_launch(gr, s2, (long long)M * P, n.Cin, n.Cin, n.Cin, s));
+      RGM_TRY(conv3_dgrad(c, sp ? s2 : gr, s1, n.H, n.Cin, n.Cin, n.key, sp));
       const int Hh = n.H / 2, q = n.Cin / 4;
       const long long total4 = (long long)M * Hh * Hh * q;
       hipLaunchKernelGGL(sumpool2_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, s1, s2, total4, Hh, q);
       RGM_LAUNCH_CHECK();
       std::swap(gr, s2);
     } else if (n.kind == 0) {
-      RGM_TRY(conv3_dgrad(c, gr, s1, n.H, n.Cout, n.Cout, n.key + "conv2"));                                  // d swish(norm2(b))
-      RGM_TRY(group_norm_bwd(c, g, n.b, s1, n.st2, s1, P, n.Cout, n.key + "norm2", 1, nullptr));               // d b
-      RGM_TRY(conv3_dgrad(c, s1, s2, n.H, n.Cin, n.Cout, n.key + "conv1"));                                   // d swish(norm1(x))
+      if (sp) RGM_TRY(split_rows_launch(gr, s2, (long long)M * P, n.Cout, n.Cout, n.Cout, s));
+      RGM_TRY(conv3_dgrad(c, sp ? s2 : gr, s1, n.H, n.Cout, n.Cout, n.key + "conv2", sp));                    // d swish(norm2(b))
+      RGM_TRY(group_norm_bwd(c, g, n.b, s1, n.st2, sp ? s2 : s1, P, n.Cout, n.key + "norm2", 1, nullptr, sp)); // d b
+      RGM_TRY(conv3_dgrad(c, sp ? s2 : s1, sp ? s1 : s2, n.H, n.Cin, n.Cout, n.key + "conv1", sp));          // d swish(norm1(x))
+      float* da = sp ? s1 : s2;
       if (n.Cin == n.Cout) {
-        RGM_TRY(group_norm_bwd(c, g, n.x, s2, n.st1, s2, P, n.Cin, n.key + "norm1", 1, gr));                   // + identity shortcut
+        RGM_TRY(group_norm_bwd(c, g, n.x, da, n.st1, da, P, n.Cin, n.key + "norm1", 1, gr));                   // + identity shortcut
       } else {
-        RGM_TRY(group_norm_bwd(c, g, n.x, s2, n.st1, s2, P, n.Cin, n.key + "norm1", 1, nullptr));
-        RGM_TRY(conv1_dgrad(c, gr, s2, M * P, n.Cin, n.Cout, n.key + "nin_shortcut", s2));                     // + nin_shortcut^T
+        RGM_TRY(group_norm_bwd(c, g, n.x, da, n.st1, da, P, n.Cin, n.key + "norm1", 1, nullptr));
+        RGM_TRY(conv1_dgrad(c, gr, da, M * P, n.Cin, n.Cout, n.key + "nin_shortcut", da));                     // + nin_shortcut^T
       }
-      std::swap(gr, s2);
+      if (sp) std::swap(gr, s1); else std::swap(gr, s2);
     } else {                      // AttnBlock: out = x + proj(softmax(alpha q k^T) v), q/k/v = 1x1 convs of norm(x)
       const int C = n.Cin, rows = M * 256;
       const long long tk = 256LL * C, sq = 256LL * 256;

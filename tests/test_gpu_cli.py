@@ -31,6 +31,8 @@ COMMON = ["--model", "DiTRotary_B_8", "--image_size", "128", "16", "--in_channel
     ("cond_table/all/scg_classifier_all.yml", ["--diffusion_steps", "25"], ["pitch_hist", "note_density"]),
     ("cond_demo/demo_long.yml", ["--diffusion_steps", "20"], ["pitch_hist", "note_density"]),
     ("cond_table/single/dps_nn/nd.yml", ["--diffusion_steps", "25"], ["note_density"]),
+    ("cond_table/single/dps_rule/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
+    ("cond_table/single/dps_rule/nd.yml", ["--diffusion_steps", "20"], ["note_density"]),
 ])
 def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
     monkeypatch.chdir(tmp_path)

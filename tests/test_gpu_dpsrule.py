@@ -107,6 +107,20 @@ def test_pitch_hist_value_and_grad_matches_reference_autograd():
     assert rel(lp3.cpu().numpy(), 3 * g["ph.logp"]) < 1e-5 and rel(d3.cpu().numpy(), 3 * d) < 1e-5
 
 
+def test_pitch_hist_value_and_grad_matches_oracle_at_sampling_size():
+    from gpu_util import dev, rel
+    from guided_diffusion.condition_functions import _rule_x0_vag
+    from oracle import rules_np as orl
+    rng = np.random.RandomState(77)
+    r = np.tanh(rng.randn(5, 3, 128, 1024)).astype(F32)
+    tgt = rng.rand(5, 12).astype(F32)
+    ologp, ograd = orl.pitch_hist_logp_grad(r.copy(), tgt, scale=40.0)
+    roll = dev(r)
+    lp, d = _rule_x0_vag(roll, dev(tgt), "pitch_hist", 40.0)
+    assert rel(lp.cpu().numpy(), ologp) < 1e-5 and rel(d.cpu().numpy(), ograd) < 2e-5
+    assert (roll[:, 0, :21] == -1).all() and (roll[:, 0, 109:] == -1).all()      # piano_like wrote through, like the reference
+
+
 def _dps_rule_step(d, m, vae, g, tag, rule_names=("pitch_hist",), rule=None, step_size=100.0):
     from functools import partial
     from types import SimpleNamespace

@@ -103,6 +103,18 @@ def test_rules_bit_exact_counts_and_histogram():
     assert orl.note_density(roll[:1].copy()).shape == g["note_density_b1"].shape == (16,)
 
 
+def test_pitch_hist_gradient_matches_reference_autograd():
+    """The written-out gradient of rule_x0_mse_dummy(pitch_hist) against what the reference's autograd returned (dps_rule golden)."""
+    g = load_golden("dps_rule")
+    r = (np.random.RandomState(int(g["ph.rseed"])).rand(2, 3, 128, 256).astype(np.float32) * 2 - 1) * 0.8
+    logp, grad = orl.pitch_hist_logp_grad(r, g["ph.target"])
+    assert rel_err(logp, g["ph.logp"]) < 1e-5
+    assert np.abs(grad - grad[:, :, :, :1]).max() == 0
+    assert rel_err(grad[:, :, :, 0], g["ph.grad_rows"]) < 1e-5
+    lp2, g2 = orl.pitch_hist_logp_grad(r, g["ph.target"], scale=2.5)
+    assert rel_err(lp2, 2.5 * logp) < 1e-6 and rel_err(g2, 2.5 * grad) < 1e-6
+
+
 def _np_model(sd, arch):
     def f(x, t, y=None, rule=None):
         return odit.dit_forward(sd, x, t, y, depth=arch["depth"], heads=arch["heads"])
