@@ -77,10 +77,13 @@ def register_midi_reader(fn):
 
 
 def read_midi_piano_roll(path, fs=100):
-    if _MIDI_READER is None:
-        raise RuntimeError("no MIDI reader registered (guided_diffusion.midi_util.register_midi_reader); "
-                           "pretty_midi is not vendored -- or pass a .npy piano roll")
-    return np.asarray(_MIDI_READER(path, fs), dtype=np.float32)
+    """MIDI file -> (3,128,T) [velocity | onset | pedal] roll.  Default: the built-in SMF reader + get_full_piano_roll's logic
+    (music_rule_guidance.piano_roll_to_chord; its onset channel is an assumption about the reference's pretty_midi fork);
+    register_midi_reader replaces it, e.g. with the fork itself."""
+    if _MIDI_READER is not None:
+        return np.asarray(_MIDI_READER(path, fs), dtype=np.float32)
+    from music_rule_guidance.piano_roll_to_chord import SimpleMIDI, midi_to_full_piano_roll
+    return midi_to_full_piano_roll(SimpleMIDI(path), fs=fs)
 
 
 def register_midi_writer(fn):
@@ -90,14 +93,21 @@ def register_midi_writer(fn):
 
 
 def save_piano_roll_midi(sample, save_dir, fs=100, y=None, save_piano_roll=False, save_ind=0):
-    """sample: (B, 3, 128, T) uint8 array.  Writes one file per sample (names as in the reference)."""
+    """sample: (B, 3, 128, T) uint8 array (or (B,128,T) / (B,2,128,T)).  Writes sample_<i>[_y_<label>].midi per sample (names
+    and event extraction as in the reference :67-93, incl. the forced onsets in the first column) plus the raw roll as
+    .npy; register_midi_writer replaces the built-in SMF writer.  save_piano_roll (PNG plots) is not provided."""
+    from music_rule_guidance.piano_roll_to_chord import piano_roll_to_pretty_midi
     os.makedirs(save_dir, exist_ok=True)
     for i in range(sample.shape[0]):
         stem = f"sample_{i + save_ind}" + (f"_y_{int(y[i])}" if y is not None else "")
+        np.save(os.path.join(save_dir, stem + ".npy"), sample[i])
         if _MIDI_WRITER is not None:
             _MIDI_WRITER(sample[i], os.path.join(save_dir, stem + ".midi"), fs)
-        else:
-            np.save(os.path.join(save_dir, stem + ".npy"), sample[i])
+            continue
+        cur = np.array(sample[i])
+        if cur.ndim == 3 and cur.shape[0] == 3:            # a note sounding in the first column starts there
+            cur[1, np.nonzero(cur[0, :, 0])[0], 0] = 127
+        piano_roll_to_pretty_midi(cur.astype(np.float32), fs=fs).write(os.path.join(save_dir, stem + ".midi"))
 
 
 def eval_rule_loss(generated_samples, target_rules):

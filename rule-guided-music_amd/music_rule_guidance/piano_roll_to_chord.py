@@ -1,0 +1,287 @@
+"""Piano roll -> note events -> Standard MIDI File, without pretty_midi / mido (neither is vendored).
+
+Reference: music_rule_guidance/piano_roll_to_chord.py:167-275 (piano_roll_to_pretty_midi: which notes and sustain-pedal
+events a generated (3,128,T) roll [velocity | onset | pedal] turns into) and guided_diffusion/midi_util.py:67-93
+(save_piano_roll_midi).  The event extraction is restated here and pinned to the reference's output
+(tests/golden/midi_events.npz).  The container classes mirror the pretty_midi attributes the reference touches
+(`.instruments[0].notes`, `.control_changes`, `.write(path)`), the byte layout of the file follows the SMF 1.0
+specification (format 1, 220 ticks per quarter note at 120 bpm -- pretty_midi's defaults); it is NOT claimed to be
+byte-identical to pretty_midi's writer (parity unpinned: the library is absent).  Chord analysis (music21) stays a host plug-in:
+music_rules.register_chord_backend.  Host-side I/O only -- nothing here is on the sampling hot path.
+"""
+import math
+import struct
+
+import numpy as np
+
+from .music_rules import MAX_PIANO, MIN_PIANO
+
+RESOLUTION = 220            # ticks per quarter note
+TEMPO_US = 500000           # 120 bpm
+TICKS_PER_SECOND = RESOLUTION * 1e6 / TEMPO_US
+
+
+class Note:
+    __slots__ = ("velocity", "pitch", "start", "end")
+
+    def __init__(self, velocity, pitch, start, end):
+        self.velocity, self.pitch, self.start, self.end = int(velocity), int(pitch), float(start), float(end)
+
+    def __repr__(self):
+        return f"Note(start={self.start:f}, end={self.end:f}, pitch={self.pitch}, velocity={self.velocity})"
+
+
+class ControlChange:
+    __slots__ = ("number", "value", "time")
+
+    def __init__(self, number, value, time):
+        self.number, self.value, self.time = int(number), int(value), float(time)
+
+
+class Instrument:
+    def __init__(self, program=0, is_drum=False, name=""):
+        self.program, self.is_drum, self.name = int(program), bool(is_drum), name
+        self.notes, self.control_changes = [], []
+
+
+def _vlq(n):
+    out = [n & 0x7F]
+    n >>= 7
+    while n:
+        out.append((n & 0x7F) | 0x80)
+        n >>= 7
+    return bytes(reversed(out))
+
+
+def _track(events):
+    """events: (tick, order, bytes) -> MTrk chunk with delta times and the end-of-track meta event."""
+    body, last = bytearray(), 0
+    for tick, _, data in sorted(events, key=lambda e: (e[0], e[1])):
+        body += _vlq(tick - last) + data
+        last = tick
+    body += _vlq(1 if events else 0) + b"\xff\x2f\x00"
+    return b"MTrk" + struct.pack(">I", len(body)) + bytes(body)
+
+
+class SimpleMIDI:
+    """The slice of pretty_midi.PrettyMIDI the sampling scripts use: a list of instruments, write(), and a reader."""
+
+    def __init__(self, midi_file=None):
+        self.instruments = []
+        self.resolution = RESOLUTION
+        if midi_file is not None:
+            self._read(midi_file)
+
+    def get_end_time(self):
+        ends = [n.end for i in self.instruments for n in i.notes] + [c.time for i in self.instruments for c in i.control_changes]
+        return max(ends) if ends else 0.0
+
+    # ------------------------------------------------------------------ writer
+    def write(self, filename):
+        tick = lambda t: int(round(t * TICKS_PER_SECOND))  # noqa: E731
+        chunks = [_track([(0, 0, b"\xff\x51\x03" + struct.pack(">I", TEMPO_US)[1:]),
+                          (0, 1, b"\xff\x58\x04\x04\x02\x18\x08")])]
+        for k, ins in enumerate(self.instruments):
+            ch = 9 if ins.is_drum else (k % 15 if k % 15 < 9 else k % 15 + 1)
+            ev = [(0, 0, bytes([0xC0 | ch, ins.program & 0x7F]))]
+            for c in ins.control_changes:
+                ev.append((tick(c.time), 1, bytes([0xB0 | ch, c.number & 0x7F, c.value & 0x7F])))
+            for n in ins.notes:
+                # at equal ticks: note-offs (order 2) before note-ons (order 3), so a repeated pitch re-triggers
+                ev.append((tick(n.start), 3, bytes([0x90 | ch, n.pitch & 0x7F, max(1, n.velocity) & 0x7F])))
+                ev.append((max(tick(n.end), tick(n.start) + 1), 2, bytes([0x90 | ch, n.pitch & 0x7F, 0])))
+            chunks.append(_track(ev))
+        with open(filename, "wb") as f:
+            f.write(b"MThd" + struct.pack(">IHHH", 6, 1, len(chunks), self.resolution))
+            for c in chunks:
+                f.write(c)
+
+    # ------------------------------------------------------------------ reader (format 0 / 1, tempo map, running status)
+    def _read(self, filename):
+        with open(filename, "rb") as f:
+            data = f.read()
+        if data[:4] != b"MThd":
+            raise ValueError(f"{filename}: not a Standard MIDI File")
+        hlen, _fmt, ntrk, div = struct.unpack(">IHHH", data[4:14])
+        if div & 0x8000:
+            raise NotImplementedError("SMPTE time division")
+        self.resolution = div
+        pos = 8 + hlen
+        tracks, tempos = [], [(0, TEMPO_US)]
+        for _ in range(ntrk):
+            if data[pos:pos + 4] != b"MTrk":
+                raise ValueError(f"{filename}: bad track chunk")
+            tlen = struct.unpack(">I", data[pos + 4:pos + 8])[0]
+            tr, p, end, tick, status = [], pos + 8, pos + 8 + tlen, 0, 0
+            while p < end:
+                d = 0
+                while True:
+                    b = data[p]
+                    p += 1
+                    d = (d << 7) | (b & 0x7F)
+                    if not b & 0x80:
+                        break
+                tick += d
+                b = data[p]
+                if b == 0xFF:
+                    kind = data[p + 1]
+                    p += 2
+                    ln = 0
+                    while True:
+                        c = data[p]
+                        p += 1
+                        ln = (ln << 7) | (c & 0x7F)
+                        if not c & 0x80:
+                            break
+                    if kind == 0x51 and ln == 3:
+                        tempos.append((tick, int.from_bytes(data[p:p + 3], "big")))
+                    p += ln
+                elif b in (0xF0, 0xF7):
+                    p += 1
+                    ln = 0
+                    while True:
+                        c = data[p]
+                        p += 1
+                        ln = (ln << 7) | (c & 0x7F)
+                        if not c & 0x80:
+                            break
+                    p += ln
+                else:
+                    if b & 0x80:
+                        status = b
+                        p += 1
+                    hi = status & 0xF0
+                    nargs = 1 if hi in (0xC0, 0xD0) else 2
+                    a = data[p:p + nargs]
+                    p += nargs
+                    tr.append((tick, status, a[0], a[1] if nargs == 2 else 0))
+            tracks.append(tr)
+            pos = end
+        tempos.sort()
+        t_ticks = np.array([t for t, _ in tempos], dtype=np.float64)
+        t_us = np.array([u for _, u in tempos], dtype=np.float64)
+        t_sec = np.concatenate(([0.0], np.cumsum(np.diff(t_ticks) * t_us[:-1] / (1e6 * div))))
+
+        def seconds(tick):
+            i = int(np.searchsorted(t_ticks, tick, side="right") - 1)
+            return float(t_sec[i] + (tick - t_ticks[i]) * t_us[i] / (1e6 * div))
+
+        for tr in tracks:
+            by_ch = {}
+            for tick, status, a, b in tr:
+                ch, hi = status & 0x0F, status & 0xF0
+                ins, on = by_ch.setdefault(ch, (Instrument(0, ch == 9), {}))
+                if hi == 0xC0:
+                    ins.program = a
+                elif hi == 0xB0:
+                    ins.control_changes.append(ControlChange(a, b, seconds(tick)))
+                elif hi == 0x90 and b > 0:
+                    on.setdefault(a, []).append((tick, b))
+                elif hi == 0x80 or (hi == 0x90 and b == 0):
+                    if on.get(a):
+                        t0, vel = on[a].pop(0)
+                        ins.notes.append(Note(vel, a, seconds(t0), seconds(tick)))
+            for ch in sorted(by_ch):
+                ins = by_ch[ch][0]
+                if ins.notes or ins.control_changes:
+                    ins.notes.sort(key=lambda n: (n.start, n.pitch))
+                    self.instruments.append(ins)
+
+
+def piano_roll_to_pretty_midi(full_roll, fs=100, program=0):
+    """(128,T), (2,128,T) [velocity | pedal] or (3,128,T) [velocity | onset | pedal] roll in [0,127] -> SimpleMIDI with
+    one instrument (reference :167-275).  Like the reference this WRITES into full_roll: onsets < 64 and pedal < 4
+    are zeroed, velocities <= the loudest value below the piano range become 0.
+
+    A note spans a maximal run of non-zero velocity in a pitch row and takes the run's first velocity; with an onset
+    channel the run is cut at every onset inside it (+1 column) and dropped when it has none.  Pedal: the piano rows'
+    mean per column (truncated), emitted as CC 64 where non-zero, < 16 -> 0 and > 112 -> 127."""
+    full_roll = np.asarray(full_roll)
+    onset_roll = None
+    if full_roll.ndim == 3:
+        piano_roll = full_roll[0]
+        if full_roll.shape[0] == 2:
+            pedal_roll = full_roll[1]
+        else:
+            onset_roll = full_roll[1]
+            onset_roll[onset_roll < 64] = 0
+            pedal_roll = full_roll[2]
+        pedal_roll[pedal_roll < 4] = 0
+        pedal = pedal_roll[MIN_PIANO:MAX_PIANO + 1].mean(axis=0).astype(np.intc)
+        has_pedal = not math.isclose(pedal.max(), 0)
+    else:
+        piano_roll, pedal, has_pedal = full_roll, None, False
+    piano_roll[piano_roll <= piano_roll[:MIN_PIANO, :].max()] = 0
+    ins = Instrument(program=program)
+    T = piano_roll.shape[1]
+    active = np.zeros((128, T + 2), dtype=np.int8)
+    active[:, 1:-1] = piano_roll != 0
+    edges = np.diff(active, axis=1)                        # +1 at the first column of a run, -1 one past its last column
+    off_t, off_p = np.nonzero(edges.T == -1)               # note-offs in (time, pitch) order: the order the reference appends in
+    starts = {}
+    on_t, on_p = np.nonzero(edges.T == 1)
+    for t, p in zip(on_t, on_p):
+        starts.setdefault(int(p), []).append(int(t))
+    taken = {p: 0 for p in starts}
+    for t, p in zip(off_t, off_p):
+        t, p = int(t), int(p)
+        s = starts[p][taken[p]]
+        taken[p] += 1
+        vel = int(piano_roll[p, s])
+        if onset_roll is None:
+            ins.notes.append(Note(vel, p, s / fs, t / fs))
+            continue
+        s_ind, e_ind = round((s / fs) * fs), round((t / fs) * fs)
+        ons = np.nonzero(onset_roll[p, s_ind:e_ind + 1])[0]
+        if len(ons) == 0:
+            continue
+        st = (ons + s_ind) / fs
+        en = np.concatenate((st[1:], np.array([t / fs])))
+        for a, b in zip(st, en):
+            ins.notes.append(Note(vel, p, a, b))
+    if has_pedal:
+        for t in np.nonzero(pedal)[0]:
+            v = int(pedal[t])
+            v = 0 if v < 16 else (127 if v > 112 else v)
+            ins.control_changes.append(ControlChange(64, v, t / fs))
+    pm = SimpleMIDI()
+    pm.instruments.append(ins)
+    return pm
+
+
+def quantize_pedal(value, num_bins=8):
+    """pedal CC value 0..127 -> centre of its bin (reference midi_util.py:252-264: 0..15 -> 8, ..., 112..127 -> 120)."""
+    if value < 0 or value > 127:
+        raise ValueError("Value should be between 0 and 127")
+    width = 128 // num_bins
+    return min(int(value) // width * width + width // 2, 127)
+
+
+def midi_to_full_piano_roll(pm, fs=100):
+    """SimpleMIDI -> (3,128,T) [velocity | onset | pedal] float32 roll (reference midi_util.py:267-291 get_full_piano_roll over
+    its pretty_midi fork's get_piano_roll(fs, pedal_threshold=None, onset=True)).  The fork is not part of the reference
+    repository; velocity follows pretty_midi's documented get_piano_roll (velocity held over [int(start*fs), int(end*fs)),
+    summed over instruments, clipped to 127), the onset channel is ASSUMED to be the note's velocity at its first column
+    -- parity unpinned for that channel.  The pedal channel is the reference's own code."""
+    T = int(math.ceil(pm.get_end_time() * fs))
+    roll = np.zeros((3, 128, max(T, 1)), dtype=np.float32)
+    for ins in pm.instruments:
+        if ins.is_drum:
+            continue
+        for n in ins.notes:
+            a, b = int(n.start * fs), int(n.end * fs)
+            if a < roll.shape[2]:
+                roll[0, n.pitch, a:max(b, a + 1)] += n.velocity
+                roll[1, n.pitch, a] = n.velocity
+    np.clip(roll[0], 0, 127, out=roll[0])
+    for ins in pm.instruments:
+        for cc in ins.control_changes:
+            if cc.number != 64:
+                continue
+            t = int(cc.time * fs)
+            if t < roll.shape[2]:
+                if roll[2, MIN_PIANO, t] != 0.0 and abs(roll[2, MIN_PIANO, t] - cc.value) > 64:
+                    roll[2, MIN_PIANO:MAX_PIANO + 1, min(t + 2, roll.shape[2] - 1)] = quantize_pedal(cc.value)
+                else:
+                    roll[2, MIN_PIANO:MAX_PIANO + 1, t] = quantize_pedal(cc.value)
+    return roll

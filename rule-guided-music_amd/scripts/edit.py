@@ -7,8 +7,8 @@ overwritten by the ground truth outside the editable rows (p_mean_variance :293-
 editable excerpt.  Rule targets are absolute values from the YAML, a shift of the rule extracted from the source
 (integers), or the source's own rule (Null).
 
-Sources: `edit.source` may be a `.npy` piano roll ((3,128,T) float in [-1,1] or (128,T,3) uint8), a MIDI file when a
-reader was registered (guided_diffusion.midi_util.register_midi_reader; pretty_midi is not vendored), or `synthetic`
+Sources: `edit.source` may be a `.npy` piano roll ((3,128,T) float in [-1,1] or (128,T,3) uint8), a MIDI file (built-in
+SMF reader; guided_diffusion.midi_util.register_midi_reader swaps in another, e.g. pretty_midi), or `synthetic`
 (a seeded sparse roll, for smoke runs).  `source: dataset` needs the reference's data loader and is not provided.
 """
 import argparse

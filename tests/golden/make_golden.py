@@ -630,6 +630,55 @@ def g_dpsrule():
     save("dps_rule", **out)
 
 
+def g_midi():
+    """Note / pedal events the reference's piano_roll_to_pretty_midi extracts from a (3,128,T) roll (piano_roll_to_chord.py:167-275).
+    pretty_midi is absent: its four classes are replaced by attribute containers for this call (they hold what the reference
+    passes them; no pretty_midi behaviour is involved in the extraction)."""
+    print("[midi events]")
+    from music_rule_guidance import piano_roll_to_chord as rp2c
+
+    class Box:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+    pmod = types.SimpleNamespace(
+        PrettyMIDI=lambda: Box(instruments=[]), Instrument=lambda program=0: Box(program=program, notes=[], control_changes=[]),
+        Note=lambda velocity, pitch, start, end: Box(velocity=velocity, pitch=pitch, start=start, end=end),
+        ControlChange=lambda number, value, time: Box(number=number, value=value, time=time))
+    old = rp2c.pretty_midi
+    rp2c.pretty_midi = pmod
+    out = {}
+    try:
+        for tag, seed, chans in (("r3", 500, 3), ("r2", 501, 2), ("r1", 502, 1)):
+            rng = np.random.RandomState(seed)
+            T = 384
+            vel = np.zeros((128, T), dtype=F32)
+            onset = np.zeros((128, T), dtype=F32)
+            for _ in range(60):                                   # notes of random length, some re-struck, some without onset
+                p, a = rng.randint(18, 112), rng.randint(0, T - 4)
+                b = min(T, a + rng.randint(1, 60))
+                vel[p, a:b] = rng.randint(1, 128)
+                if rng.rand() < 0.85:
+                    onset[p, a] = rng.choice([127, 90, 40])
+                if rng.rand() < 0.3 and b - a > 6:
+                    onset[p, a + (b - a) // 2] = 127
+            vel[:, 0][rng.rand(128) < 0.05] = 77                  # notes already sounding in the first column
+            vel[:, -3:][rng.rand(128) < 0.05] = 55                # and notes still sounding at the end
+            vel[:21][rng.rand(21, T) < 0.01] = 3                  # background below the piano range
+            pedal = np.zeros((128, T), dtype=F32)
+            for a in range(0, T, 48):
+                pedal[21:109, a:a + rng.randint(5, 40)] = rng.choice([2, 10, 40, 100, 120, 127])
+            roll = {3: np.stack([vel, onset, pedal]), 2: np.stack([vel, pedal]), 1: vel}[chans]
+            pm = rp2c.piano_roll_to_pretty_midi(roll.copy(), fs=100)
+            ins = pm.instruments[0]
+            notes = np.array([[n.velocity, n.pitch, n.start, n.end] for n in ins.notes], dtype=np.float64).reshape(-1, 4)
+            ccs = np.array([[c.number, c.value, c.time] for c in ins.control_changes], dtype=np.float64).reshape(-1, 3)
+            out.update({f"{tag}.roll": roll.astype(np.uint8), f"{tag}.notes": notes, f"{tag}.ccs": ccs})
+            print(f"    {tag}: {len(notes)} notes, {len(ccs)} pedal events")
+    finally:
+        rp2c.pretty_midi = old
+    save("midi_events", **out)
+
+
 def g_collage():
     print("[diff_collage]")
     m, sd = ref_dit(SM, 11)
@@ -727,7 +776,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -752,6 +801,8 @@ if __name__ == "__main__":
         g_dps()
     if "dpsrule" in which:
         g_dpsrule()
+    if "midi" in which:
+        g_midi()
     if "cli" in which:
         g_cli()
     if "e2e" in which:

@@ -203,3 +203,59 @@ def test_noise_seed_is_shared_across_ranks_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res[0] == res[1] == 1000
+
+
+@pytest.mark.parametrize("tag", ["r3", "r2", "r1"])
+def test_piano_roll_note_events_match_reference(tag):
+    """piano_roll_to_pretty_midi's note / pedal extraction (piano_roll_to_chord.py:167-275) on a roll with re-struck notes, notes
+    without onsets, notes cut by the excerpt's edges and a noisy background -- same events, same order as the reference."""
+    from music_rule_guidance.piano_roll_to_chord import piano_roll_to_pretty_midi
+    g = load_golden("midi_events")
+    pm = piano_roll_to_pretty_midi(g[f"{tag}.roll"].astype(np.float32), fs=100)
+    ins = pm.instruments[0]
+    notes = np.array([[n.velocity, n.pitch, n.start, n.end] for n in ins.notes], dtype=np.float64).reshape(-1, 4)
+    ccs = np.array([[c.number, c.value, c.time] for c in ins.control_changes], dtype=np.float64).reshape(-1, 3)
+    assert np.array_equal(notes, g[f"{tag}.notes"]) and np.array_equal(ccs, g[f"{tag}.ccs"])
+
+
+def test_midi_file_round_trip_and_default_io(tmp_path):
+    """The built-in SMF writer / reader (no pretty_midi): events survive write -> read to the tick (1/440 s), the default
+    save_piano_roll_midi writes .midi + .npy under the reference's names, read_midi_piano_roll returns a (3,128,T) roll whose
+    velocity and pedal channels match the source where notes sound."""
+    from guided_diffusion import midi_util
+    from music_rule_guidance.piano_roll_to_chord import SimpleMIDI, piano_roll_to_pretty_midi
+    g = load_golden("midi_events")
+    roll = g["r3.roll"]
+    pm = piano_roll_to_pretty_midi(roll.astype(np.float32), fs=100)
+    path = str(tmp_path / "a.midi")
+    pm.write(path)
+    with open(path, "rb") as f:
+        head = f.read(14)
+    assert head[:4] == b"MThd" and head[8:14] == bytes([0, 1, 0, 2, 0, 220])           # format 1, 2 tracks, 220 ticks / quarter
+    back = SimpleMIDI(path)
+    a = sorted((n.pitch, round(n.start * 440), round(n.end * 440), n.velocity) for n in pm.instruments[0].notes)
+    b = sorted((n.pitch, round(n.start * 440), round(n.end * 440), n.velocity) for n in back.instruments[0].notes)
+    assert a == b and len(a) > 10
+    ca = [(c.value, round(c.time * 440)) for c in pm.instruments[0].control_changes]
+    cb = [(c.value, round(c.time * 440)) for c in back.instruments[0].control_changes]
+    assert ca == cb and len(ca) > 10
+    # the module-level defaults
+    midi_util.save_piano_roll_midi(roll[None], str(tmp_path), fs=100, y=np.array([2]), save_ind=5)
+    assert sorted(os.listdir(tmp_path)) == ["a.midi", "sample_5_y_2.midi", "sample_5_y_2.npy"]
+    full = midi_util.read_midi_piano_roll(str(tmp_path / "sample_5_y_2.midi"), fs=100)
+    assert full.shape[:2] == (3, 128) and full.dtype == np.float32 and full.max() <= 127
+    n0 = back.instruments[0].notes[0]
+    s, e = int(n0.start * 100), int(n0.end * 100)
+    assert (full[0, n0.pitch, s:e] > 0).all() and full[1, n0.pitch, s] > 0
+    assert set(np.unique(full[2])) <= {0.0} | {float(v) for v in range(8, 128, 16)}      # quantised pedal bins
+    # a registered writer / reader replaces the defaults
+    seen = []
+    midi_util.register_midi_writer(lambda r, p, fs: seen.append((r.shape, os.path.basename(p), fs)))
+    midi_util.register_midi_reader(lambda p, fs: np.zeros((3, 128, 7)))
+    try:
+        midi_util.save_piano_roll_midi(roll[None], str(tmp_path / "w"), fs=50)
+        assert seen == [((3, 128, 384), "sample_0.midi", 50)]
+        assert midi_util.read_midi_piano_roll("x.midi").shape == (3, 128, 7)
+    finally:
+        midi_util.register_midi_writer(None)
+        midi_util.register_midi_reader(None)
