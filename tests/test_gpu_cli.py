@@ -71,3 +71,27 @@ def test_edit_cli_keeps_the_fixed_part_and_rewrites_the_excerpt(tmp_path, monkey
     out_dir = os.path.join("loggings", "edit_demo", "edit", "nd_short_cls_1")
     assert os.path.exists(os.path.join(out_dir, "results.csv")) and os.path.exists(os.path.join(out_dir, "gt", "sample_0_y_1.npy"))
     assert sample.shape == (2, 128, 1024, 3) and sample.dtype == torch.uint8
+
+
+def test_edit_cli_reads_a_midi_source(tmp_path, monkeypatch):
+    """edit.source = a MIDI file: the built-in SMF reader -> (3,128,T) roll -> padded with background -> encoded; the run's gt/
+    directory holds the re-written source as .midi again (default writer)."""
+    from conftest import load_golden
+    from music_rule_guidance.piano_roll_to_chord import piano_roll_to_pretty_midi
+    monkeypatch.chdir(tmp_path)
+    spec = importlib.util.spec_from_file_location("edit_cli", os.path.join(PKG, "scripts", "edit.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    src = os.path.join(str(tmp_path), "source.midi")
+    piano_roll_to_pretty_midi(load_golden("midi_events")["r3.roll"].astype(np.float32), fs=100).write(src)
+    cfg_src = os.path.join(CFG, "edit", "nd_scg_given_target.yml")
+    cfg = os.path.join(str(tmp_path), "configs", "edit", "nd_midi.yml")
+    os.makedirs(os.path.dirname(cfg))
+    text = open(cfg_src).read().replace("noise_level: 500", "noise_level: 12").replace("source: synthetic", f"source: {src}")
+    open(cfg, "w").write(text)
+    res, sample = cli.main(["--config_path", cfg, "--batch_size", "1", "--num_samples", "1", "--diffusion_steps", "20"] + COMMON)
+    assert len(res) == 1 and np.isfinite(res["note_density.loss"]).all()
+    gt_dir = os.path.join("loggings", "edit_demo", "edit", "nd_midi_cls_1", "gt")
+    assert os.path.exists(os.path.join(gt_dir, "sample_0_y_1.midi")) and os.path.exists(os.path.join(gt_dir, "sample_0_y_1.npy"))
+    gt = np.load(os.path.join(gt_dir, "sample_0_y_1.npy"))
+    assert gt.shape == (3, 128, 1024) and (gt[0, :, 384:] == 0).all() and gt[0, :, :384].max() > 0
