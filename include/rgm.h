@@ -217,6 +217,9 @@ int rgm_rule_pitch_hist_vag(float* roll, const float* target, float scale, float
                             float* scratch, int N, int C, int T, void* stream);
 /* note_density (:46-83): out (N, 2*T/interval) = [vertical..., horizontal...]; interval divides 256 and T. */
 int rgm_rule_note_density(float* roll, float* out, int N, int C, int T, int interval, float hscale, void* stream);
+/* get_chords' preamble (music_rules.py:97-110): piano_like mask and < -0.95 -> -1 written into channel 0 of roll, then
+ * clamp((x+1)/2*127, 0, 127) truncated -> out (N,128,T) uint8: the integer roll the host chord analyser (music21) reads. */
+int rgm_rule_chord_quantise(float* roll, uint8_t* out, int N, int C, int T, void* stream);
 /* torch.bucketize(v, bounds) as used by note_density_class (:86-94): out int64. */
 int rgm_bucketize(const float* v, const float* bounds, int nb, int64_t* out, int n, void* stream);
 /* mse_loss_mean / zero_one_loss_mean (rule_maps.py:17-22) over the last dim: a,b (rows,K) -> out (rows). */

@@ -56,6 +56,15 @@ def pitch_hist_logp_grad(roll, target, scale=1.0):
     return logp.astype(F32), grad.astype(F32)
 
 
+def chord_quantise(roll):
+    """get_chords' preamble (music_rules.py:97-110): piano_like + (< -0.95 -> -1) written into channel 0, then the integer roll
+    clamp((x+1)/2*127, 0, 127) truncated that the music21 analyser is given -> (N,128,T) int32."""
+    pr = piano_like(roll[:, :1])
+    pr[pr < F32(-0.95)] = -1.0
+    v = np.clip((pr + F32(1)) / F32(2) * F32(127), 0, 127)
+    return v[:, 0].astype(np.intc)
+
+
 def note_density(roll, interval=128, horizontal_scale=5):
     """(N,C,128,T) -> (N, 2*T/interval): [vertical windows..., horizontal windows...]."""
     pr = piano_like(roll[:, :1])

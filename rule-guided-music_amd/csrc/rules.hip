@@ -168,6 +168,25 @@ __global__ void pitch_grad_fill_kernel(const float* __restrict__ dh, float* __re
   droll[i] = (ch == 0 && p >= MIN_PIANO && p <= MAX_PIANO) ? 0.5f * dh[n * 12 + p % 12] : 0.0f;
 }
 
+// get_chords' device-side preamble (music_rules.py:97-110): piano_like mask and the < -0.95 background snap WRITTEN into channel 0
+// of the roll, then (x + 1) / 2 * 127, clamp to [0, 127], truncate -> the integer piano roll the host chord analyser reads
+__global__ void chord_quantise_kernel(float* __restrict__ roll, uint8_t* __restrict__ out, long long total, int C, int T) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // over N*128*T
+  if (i >= total) return;
+  const int t = (int)(i % T);
+  const int p = (int)((i / T) % 128);
+  const long long n = i / ((long long)T * 128);
+  float* px = roll + ((n * C) * 128 + p) * T + t;
+  float x = *px;
+  if (p < MIN_PIANO || p > MAX_PIANO || x < -0.95f) {
+    x = -1.0f;
+    *px = x;
+  }
+  float v = (x + 1.0f) / 2.0f * 127.0f;
+  v = fminf(fmaxf(v, 0.0f), 127.0f);
+  out[i] = (uint8_t)(int)v;
+}
+
 }  // namespace rgm
 
 using namespace rgm;
@@ -203,6 +222,14 @@ extern "C" int rgm_rule_note_density(float* roll, float* out, int N, int C, int 
   RGM_REQUIRE(roll && out && N > 0 && C > 0 && T > 0, "note_density: bad arguments");
   RGM_REQUIRE(interval > 0 && 256 % interval == 0 && T % interval == 0, "note_density: interval %d must divide 256 and T=%d", interval, T);
   hipLaunchKernelGGL(note_density_kernel, dim3(cdiv(T, 256), N), dim3(256), 0, (hipStream_t)stream, roll, out, C, T, interval, hscale);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_rule_chord_quantise(float* roll, uint8_t* out, int N, int C, int T, void* stream) {
+  RGM_REQUIRE(roll && out && N > 0 && C > 0 && T > 0, "chord_quantise: bad arguments");
+  const long long total = (long long)N * 128 * T;
+  hipLaunchKernelGGL(chord_quantise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, roll, out, total, C, T);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

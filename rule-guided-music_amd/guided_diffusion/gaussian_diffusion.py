@@ -729,10 +729,12 @@ def _decode(pred_zstart, embed_model, scale_factor=1., threshold=False):
 
 
 def _extract_rule(rule_name, pred_xstart):
-    """FUNC_DICT dispatch; chord rules are a host plugin (music21) evaluated on CPU copies."""
+    """FUNC_DICT dispatch.  Chord rules (reference :1363-1375) run on a COPY of the roll -- the reference hands .cpu() chunks to a
+    process pool, so their in-place mask / snap never reaches the caller's tensor; here the copy stays on the device (the
+    integer quantisation is a kernel) and only uint8 rolls travel to the host analyser's worker pool."""
     if "chord" in rule_name:
         fn = FUNC_DICT[rule_name]
-        out = fn(pred_xstart.cpu())
+        out = fn(pred_xstart.clone())
         if out.dim() == 1:
             out = out.unsqueeze(0)
         return out.to(pred_xstart.device)

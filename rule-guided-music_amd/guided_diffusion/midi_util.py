@@ -11,7 +11,7 @@ import torch
 import yaml
 
 from music_rule_guidance.rule_maps import FUNC_DICT, LOSS_DICT
-from music_rule_guidance.music_rules import MAX_PIANO, MIN_PIANO  # noqa: F401  (re-exported like the reference)
+from music_rule_guidance.music_rules import IND2KEY, KEY_DICT, MAX_PIANO, MIN_PIANO  # noqa: F401  (re-exported like the reference)
 from rgm import native as _rgm
 
 
@@ -120,7 +120,7 @@ def eval_rule_loss(generated_samples, target_rules):
         target = target.to(generated_samples.device)
         if "chord" in name:
             gen, key, corr = FUNC_DICT[name](generated_samples, return_key=True)
-            results[name + ".key_str"] = list(key)
+            results[name + ".key_str"] = [IND2KEY.get(k, k) for k in key]
             results[name + ".key_corr"] = corr
         else:
             gen = FUNC_DICT[name](generated_samples)

@@ -9,6 +9,7 @@ Semantics kept from the reference, including the surprising ones:
 CPU tensors are accepted (the CLI evaluates final rolls from numpy): they are staged to the HIP device,
 processed there, and the in-place writes are copied back -- the computation never runs on the CPU.
 """
+import numpy as np
 import torch
 
 from rgm import native as _rgm
@@ -93,18 +94,76 @@ def note_density_class(piano_roll, interval=128, quantize_factor=1, horizontal_s
     return out.to(piano_roll.device)
 
 
+# ---- chord rule (a11): device-side preamble + a host analyser.  The reference's analyser is symbolic-music code on music21
+# (piano_roll_to_chord.py:307-359), which is not vendored and cannot be restated: it stays a plug-in with the reference's own
+# per-excerpt signature, so `register_chord_backend(piano_roll_to_chords)` with the reference's function is all a user with
+# music21 needs.  What IS arithmetic on the roll -- mask, background snap, 0..127 quantisation -- runs on the GPU.
+KEY_DICT = {"D major": 0, "g minor": 1, "B- major": 2, "G major": 3, "d minor": 4, "c# minor": 5, "F major": 6, "E- major": 7,
+            "e minor": 8, "f# minor": 9, "C major": 10, "F# major": 11, "g# minor": 12, "A major": 13, "a minor": 14,
+            "B major": 15, "A- major": 16, "b- minor": 17, "E major": 18, "c minor": 19, "b minor": 20, "e- minor": 21,
+            "f minor": 22, "C# major": 23, "no key": 24}      # the chord classifier's key classes (piano_roll_to_chord.py:15-18)
+IND2KEY = {v: k for k, v in KEY_DICT.items()}
+
 _CHORD_BACKEND = None
+_CHORD_WORKERS = 4          # the reference chunks the batch over a 4-process pool (gaussian_diffusion.py:1365-1371)
+_CHORD_POOL = None
 
 
-def register_chord_backend(fn):
-    """Install the host-side chord analyser (reference: piano_roll_to_chord.py via music21 + pretty_midi).
-    It is symbolic-music analysis on the CPU, not GPU work, and its dependencies are not vendored."""
-    global _CHORD_BACKEND
-    _CHORD_BACKEND = fn
+def register_chord_backend(fn, workers=4):
+    """fn(piano_roll (128,T) int array in [0,127], given_key=None, return_key=False, fs=100., window_size=1.28) ->
+    {"chords": LongTensor (T/fs/window_size,), ["key": int, "correlationCoefficient": float]} -- the signature of the reference's
+    piano_roll_to_chords (music21).  workers > 1 evaluates the excerpts of a batch in a persistent spawn-context process pool
+    (fn must be picklable, i.e. a module-level function); 0/1 = in this process."""
+    global _CHORD_BACKEND, _CHORD_WORKERS, _CHORD_POOL
+    if _CHORD_POOL is not None:
+        _CHORD_POOL.terminate()
+        _CHORD_POOL = None
+    _CHORD_BACKEND, _CHORD_WORKERS = fn, int(workers)
+
+
+def chord_quantise(piano_roll_batch):
+    """(N,C,128,T) roll -> (N,128,T) uint8 integer roll of channel 0 (get_chords' preamble, music_rules.py:100-110); writes the
+    piano_like mask and the < -0.95 -> -1 snap into the caller's roll like the reference."""
+    d, back = _stage(piano_roll_batch)
+    N, Cc, _, T = d.shape
+    q = torch.empty((N, 128, T), dtype=torch.uint8, device=d.device)
+    with torch.cuda.device(d.device):
+        _rgm.check(_rgm.lib.rgm_rule_chord_quantise(_rgm.ptr(d), _rgm.ptr(q), N, Cc, T, _rgm.current_stream()))
+    back(d)
+    return q
+
+
+def _chord_job(args):
+    fn, roll, kw = args
+    return fn(roll, **kw)
 
 
 def get_chords(piano_roll_batch, given_key=None, fs=100, window_size=1.28, return_key=False):
+    """FUNC_DICT['chord_progression']: (N,C,128,T) roll -> chords (N, windows) LongTensor [(windows,) when N == 1]
+    (+ keys, correlation coefficients with return_key) -- reference music_rules.py:97-130."""
+    global _CHORD_POOL
     if _CHORD_BACKEND is None:
-        raise ImportError("chord rules need a host plugin (music21 / mido based); install one with "
-                          "music_rule_guidance.music_rules.register_chord_backend(fn)")
-    return _CHORD_BACKEND(piano_roll_batch, given_key=given_key, fs=fs, window_size=window_size, return_key=return_key)
+        raise ImportError("chord rules need a host analyser (the reference's is music21-based and not vendored): "
+                          "music_rule_guidance.music_rules.register_chord_backend(piano_roll_to_chords)")
+    rolls = chord_quantise(piano_roll_batch).cpu().numpy().astype(np.intc)
+    kw = dict(given_key=given_key, fs=fs, window_size=window_size, return_key=return_key)
+    jobs = [(_CHORD_BACKEND, rolls[i], kw) for i in range(rolls.shape[0])]
+    outs = None
+    if _CHORD_WORKERS > 1 and len(jobs) > 1:
+        try:
+            if _CHORD_POOL is None:
+                import multiprocessing
+                _CHORD_POOL = multiprocessing.get_context("spawn").Pool(_CHORD_WORKERS)
+            outs = _CHORD_POOL.map(_chord_job, jobs)
+        except (AttributeError, TypeError, ImportError) as e:      # an unpicklable backend (lambda / closure): run it here
+            if "pickle" not in str(e).lower() and "local object" not in str(e).lower():
+                raise
+            outs = None
+    if outs is None:
+        outs = [_chord_job(j) for j in jobs]
+    chords = torch.stack([torch.as_tensor(o["chords"], dtype=torch.long) for o in outs], dim=0)
+    if chords.shape[0] == 1:
+        chords = chords.squeeze(0)
+    if return_key:
+        return chords, [o["key"] for o in outs], [o["correlationCoefficient"] for o in outs]
+    return chords

@@ -60,6 +60,7 @@ def _load():
         "rgm_rule_pitch_hist": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "rgm_rule_pitch_hist_vag": (C.c_int, [vp, vp, f32, vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_rule_note_density": (C.c_int, [vp, vp, i32, i32, i32, i32, f32, vp]),
+        "rgm_rule_chord_quantise": (C.c_int, [vp, vp, i32, i32, i32, vp]),
         "rgm_bucketize": (C.c_int, [vp, vp, i32, vp, i32, vp]),
         "rgm_row_loss": (C.c_int, [vp, vp, vp, i32, i32, i32, vp]),
         "rgm_collage_split": (C.c_int, [vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),

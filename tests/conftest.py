@@ -43,3 +43,12 @@ def precision(request):
     R.set_gemm_precision(request.param)
     yield request.param
     R.set_gemm_precision("fp32")
+
+
+def chord_test_roll(seed):
+    """The input of tests/golden/chord_quantise.npz, rebuilt from its seed (make_golden.py chord_test_roll)."""
+    rng = np.random.RandomState(seed)
+    roll = (rng.rand(3, 3, 128, 256).astype(np.float32) * 2.4 - 1.2)
+    roll[rng.rand(*roll.shape) < 0.3] = -0.95
+    roll[rng.rand(*roll.shape) < 0.1] = np.float32(-0.9500001)
+    return roll

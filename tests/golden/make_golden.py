@@ -679,6 +679,48 @@ def g_midi():
     save("midi_events", **out)
 
 
+def chord_test_roll(seed):
+    """(3,3,128,256) roll with values on both sides of the -0.95 snap, outside [-1,1] and in the non-piano rows (the tests
+    rebuild it from the seed: tests/conftest.py chord_test_roll is this function)."""
+    rng = np.random.RandomState(seed)
+    roll = (rng.rand(3, 3, 128, 256).astype(F32) * 2.4 - 1.2)
+    roll[rng.rand(*roll.shape) < 0.3] = -0.95
+    roll[rng.rand(*roll.shape) < 0.1] = np.float32(-0.9500001)
+    return roll
+
+
+def g_chordq():
+    """The integer piano roll get_chords hands to the music21 analyser (music_rules.py:97-110) and its in-place side effects on
+    the roll -- captured by replacing the analyser (piano_roll_to_chords) with a recorder; music21 itself is never reached."""
+    print("[chord quantisation]")
+    from music_rule_guidance import music_rules as rmr
+    seed = 1300
+    roll = chord_test_roll(seed)
+    seen = []
+
+    def recorder(pr, given_key=None, fs=100, window_size=1.28, return_key=False):
+        seen.append(np.array(pr))
+        out = {"chords": torch.arange(int(pr.shape[-1] / fs / window_size)) + len(seen)}
+        if return_key:
+            out.update(key=len(seen), correlationCoefficient=0.5 * len(seen))
+        return out
+    old = rmr.piano_roll_to_chords
+    rmr.piano_roll_to_chords = recorder
+    try:
+        t = torch.from_numpy(roll.copy())
+        chords, keys, corr = rmr.get_chords(t, return_key=True)
+        one = rmr.get_chords(torch.from_numpy(roll[:1].copy()))
+    finally:
+        rmr.piano_roll_to_chords = old
+    q = np.stack(seen[:3])
+    assert q.min() >= 0 and q.max() <= 127
+    after = t.numpy()
+    save("chord_quantise", seed=np.array(seed), q=q.astype(np.uint8), after_sum=np.array(after.astype(np.float64).sum()),
+         after_minus1=np.array(int((after == -1).sum())), after_ch0_row60=after[:, 0, 60], chords=chords.numpy(),
+         keys=np.array(keys), corr=np.array(corr), one_shape=np.array(one.shape))
+    print(f"    quantised {q.shape}, nonzero {float((q > 0).mean()):.3f}, chords {tuple(chords.shape)}, N=1 -> {tuple(one.shape)}")
+
+
 def g_collage():
     print("[diff_collage]")
     m, sd = ref_dit(SM, 11)
@@ -776,7 +818,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -803,6 +845,8 @@ if __name__ == "__main__":
         g_dpsrule()
     if "midi" in which:
         g_midi()
+    if "chordq" in which:
+        g_chordq()
     if "cli" in which:
         g_cli()
     if "e2e" in which:

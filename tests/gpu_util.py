@@ -48,3 +48,17 @@ def load_module(module, sd_np_or_torch):
     sd = {k: (v if torch.is_tensor(v) else torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd_np_or_torch.items()}
     module.load_state_dict(sd, strict=True)
     return module.to(DEV).eval()
+
+
+def fake_chord_backend(pr, given_key=None, return_key=False, fs=100., window_size=1.28):
+    """Stand-in for the reference's music21 analyser with its signature (module level: the worker pool pickles it).  Encodes
+    what it was given into its answer so that tests can check the plumbing: chords[w] = (sum of window w) % 7."""
+    import numpy as np
+    import torch
+    assert pr.shape[0] == 128 and pr.dtype == np.intc and pr.min() >= 0 and pr.max() <= 127
+    nw = int(pr.shape[-1] / fs / window_size)
+    w = int(window_size * fs)
+    out = {"chords": torch.tensor([int(pr[:, i * w:(i + 1) * w].sum()) % 7 for i in range(nw)], dtype=torch.long)}
+    if return_key:
+        out.update(key=int(pr.sum()) % 24, correlationCoefficient=float(pr.mean()))
+    return out

@@ -298,3 +298,44 @@ def test_full_size_batch_is_row_independent_of_the_small_pinned_batches(precisio
     dec = vae.decode(z)
     for i in (0, 31, 62):
         assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < 2e-6, i
+
+
+def test_chord_rule_device_preamble_and_host_plugin():
+    """a11: the roll arithmetic of get_chords (mask, background snap, 0..127 quantisation) is a kernel, bit-exact with the reference
+    incl. the writes into the caller's roll; the symbolic analysis is the registered host function, called once per excerpt with
+    the reference's piano_roll_to_chords signature, in this process or in the spawn-context worker pool -- same answers."""
+    from conftest import chord_test_roll
+    from gpu_util import dev, fake_chord_backend
+    from guided_diffusion.gaussian_diffusion import _extract_rule
+    from guided_diffusion.midi_util import eval_rule_loss
+    from music_rule_guidance import music_rules
+    g = load_golden("chord_quantise")
+    roll = dev(chord_test_roll(int(g["seed"])))
+    q = music_rules.chord_quantise(roll)
+    assert q.dtype == torch.uint8 and np.array_equal(q.cpu().numpy(), g["q"])
+    after = roll.cpu().numpy()
+    assert float(after.astype(np.float64).sum()) == float(g["after_sum"]) and int((after == -1).sum()) == int(g["after_minus1"])
+    assert np.array_equal(after[:, 0, 60], g["after_ch0_row60"])
+    with pytest.raises(ImportError):
+        music_rules.register_chord_backend(None)
+        music_rules.get_chords(roll)
+    expect = [fake_chord_backend(g["q"][i].astype(np.intc), return_key=True) for i in range(3)]
+    try:
+        for workers in (0, 2):
+            music_rules.register_chord_backend(fake_chord_backend, workers=workers)
+            fresh = dev(chord_test_roll(int(g["seed"])))
+            chords, keys, corr = music_rules.get_chords(fresh, return_key=True)
+            assert chords.shape == (3, 2) and chords.dtype == torch.long
+            assert torch.equal(chords, torch.stack([e["chords"] for e in expect]))
+            assert keys == [e["key"] for e in expect] and corr == [e["correlationCoefficient"] for e in expect]
+            assert music_rules.get_chords(dev(chord_test_roll(int(g["seed"]))[:1])).shape == (2,)       # N == 1 squeezes
+        # the sampler evaluates chord rules on a copy (the reference's .cpu() chunks): the caller's roll keeps its values
+        keep = dev(chord_test_roll(int(g["seed"])))
+        before = keep.clone()
+        out = _extract_rule("chord_progression", keep)
+        assert torch.equal(keep, before) and out.shape == (3, 2) and out.device == keep.device
+        # the report path: key indices become key names
+        df = eval_rule_loss(dev(chord_test_roll(int(g["seed"]))), {"chord_progression": torch.zeros(3, 2, dtype=torch.long)})
+        assert list(df["chord_progression.key_str"]) == [music_rules.IND2KEY[e["key"]] for e in expect]
+    finally:
+        music_rules.register_chord_backend(None)

@@ -115,6 +115,17 @@ def test_pitch_hist_gradient_matches_reference_autograd():
     assert rel_err(lp2, 2.5 * logp) < 1e-6 and rel_err(g2, 2.5 * grad) < 1e-6
 
 
+def test_chord_quantisation_matches_reference():
+    """The integer roll get_chords hands to the (music21) analyser, and the side effects on the caller's roll."""
+    from conftest import chord_test_roll
+    g = load_golden("chord_quantise")
+    roll = chord_test_roll(int(g["seed"]))
+    q = orl.chord_quantise(roll)
+    assert np.array_equal(q, g["q"].astype(np.intc))
+    assert float(roll.astype(np.float64).sum()) == float(g["after_sum"]) and int((roll == -1).sum()) == int(g["after_minus1"])
+    assert np.array_equal(roll[:, 0, 60], g["after_ch0_row60"])
+
+
 def _np_model(sd, arch):
     def f(x, t, y=None, rule=None):
         return odit.dit_forward(sd, x, t, y, depth=arch["depth"], heads=arch["heads"])
