@@ -1,4 +1,5 @@
-// vae.hip -- taming KL-VAE decoder (f8, z=4ch): weight arena, glue kernels and the decode schedule.
+// vae.hip -- taming KL-VAE (f8, z=4ch): weight arena, glue kernels, the decode schedule, the encoder (editing) and the
+// decoder's input-gradient pass (DPS through a rule on the decoded roll).
 //
 // Reference: taming/models/klvae_pedal.py:80-85 (AutoencoderKL.decode = post_quant_conv -> Decoder),
 // taming/modules/diffusionmodules/model.py:436-537 (Decoder), :78-137 (ResnetBlock), :140-192 (AttnBlock),
