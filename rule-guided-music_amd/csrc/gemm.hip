@@ -377,6 +377,9 @@ int gemm_launch(const GemmParams& p, hipStream_t s) {
       // 64x64 below (small grids), 128x128 only pays at M >= 16k.
       const long long work = (long long)p.M * p.N * p.batch;
       tile = work >= (long long)16384 * 4096 ? 1 : (work >= (long long)2048 * 1152 ? 2 : 3);
+      // short-K dense GEMMs over millions of rows (the VAE's 1x1 nin_shortcut convs and their input gradients) are HBM-bound:
+      // the smaller tile keeps more loads in flight per CU (tools/nin_shapes.py: 2.9 vs 2.3 TB/s at K = 256)
+      if (tile == 1 && !p.aload && p.K <= 512) tile = 2;
     } else {
       // fp32: pick the tile that wastes the fewest CU-rounds; smaller tiles pay more L2->LDS traffic
       const double e1 = wave_eff(p.M, p.N, 128, 128, p.batch) * 0.90;
