@@ -141,6 +141,12 @@ struct GemmParams {
   int prec = -1;
   // gemm2 (pre-split operands): write C in split-row format (N bf16 hi | N bf16 lo per row) for the next GEMM
   int out_split = 0;
+  // gemm2, 128-row tiles: also write per-tile GroupNorm partial sums of the OUTPUT (after bias / residual):
+  // stats[(tile_m * (N / stats_gw) + col / stats_gw) * 2 + {0, 1}] = sum, sum of squares over the tile's rows of the stats_gw
+  // (4, 8 or 16) channels of group col / stats_gw -- fp64, fixed-order tree, no atomics (deterministic, and the same to 1e-16
+  // whatever tile shape the heuristic picked: results stay independent of the batch size); vae.hip group_norm consumes them
+  double* stats = nullptr;
+  int stats_gw = 0;
 };
 int gemm_launch(const GemmParams& p, hipStream_t stream);
 // gemm2.hip: the same contraction on operands already in split-row format (K bf16 hi | K bf16 lo per row)

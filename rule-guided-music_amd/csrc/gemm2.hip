@@ -597,6 +597,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
     const bool col_ok = col < p.N;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (biasb && col_ok) bv = *reinterpret_cast<const float4*>(biasb + col);
+    double gs[8] = {0., 0., 0., 0., 0., 0., 0., 0.};   // p.stats: this lane's column sums / sums of squares (fp64: see common.h)
     static_for<0, TM>([&](auto im_c) {
       constexpr int im = decltype(im_c)::value;
       static_for<0, TN>([&](auto in_c) {
@@ -631,6 +632,13 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
             const float4 r4 = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
             v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
           }
+          if (p.stats) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              gs[q4] += (double)v[q4];
+              gs[4 + q4] += (double)v[q4] * (double)v[q4];
+            }
+          }
           if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             bf16x4 hi, lo;
@@ -648,6 +656,37 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
         }
       }
     });
+    if (p.stats) {   // GroupNorm partial sums of this tile (uniform branch): lanes -> waves -> groups, all in a fixed order
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
+      }
+      __syncthreads();                                                // every wave is done with its staging slab
+      double* sred = reinterpret_cast<double*>(ring);                 // [wave][quad of its WCOLS columns][8]
+      if (lr == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sred[(wave * LPR + lane) * 8 + k] = gs[k];
+      }
+      __syncthreads();
+      const int qpg = p.stats_gw >> 2;                                // column quads per group
+      const int ngrp = BN / p.stats_gw;
+      if (tid < ngrp && n0 + tid * p.stats_gw < p.N) {
+        double sum = 0., sq = 0.;
+        for (int qq = 0; qq < qpg; ++qq) {
+          const int quad = tid * qpg + qq;                            // quad index inside the BN columns of the tile
+          const int wc_ = quad / LPR, l = quad - wc_ * LPR;
+          for (int wr_ = 0; wr_ < WM; ++wr_) {
+            const double* r = sred + ((wr_ * WN + wc_) * LPR + l) * 8;
+            sum += (r[0] + r[1]) + (r[2] + r[3]);
+            sq += (r[4] + r[5]) + (r[6] + r[7]);
+          }
+        }
+        double* o2 = p.stats + ((long long)(m0 / BM) * (p.N / p.stats_gw) + n0 / p.stats_gw + tid) * 2;
+        o2[0] = sum;
+        o2[1] = sq;
+      }
+    }
   } else
   static_for<0, TM>([&](auto im_c) {
     static_for<0, TN>([&](auto in_c) {
@@ -842,7 +881,12 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm2: operands must be 16-byte aligned with ld%%4==0");
   RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
-  const int S = splitk_factor(p);
+  RGM_REQUIRE(!p.stats || ((p.stats_gw == 4 || p.stats_gw == 8 || p.stats_gw == 16) && p.N % 64 == 0 && p.batch == 1 &&
+                           ((p.tile == 0 && p.aload) || p.tile == 21 || p.tile == 22 || p.tile == 43 || p.tile == 44) &&
+                           ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
+                           (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate | (uintptr_t)p.aux) & 15) == 0),
+              "gemm2: GroupNorm partial sums need 128-row tiles, N%%64==0, group width 4/8/16 and 16-byte aligned rows");
+  const int S = (p.stats ? 1 : splitk_factor(p));
   if (S > 1) {
     const size_t need = (size_t)S * p.M * p.N * sizeof(float);
     SplitKBuf& sk = g_splitk[s];

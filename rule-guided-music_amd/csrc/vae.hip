@@ -142,6 +142,26 @@ __global__ void gn_finalize_kernel(const double* __restrict__ part, float* __res
   stats[idx * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// The same statistics from the per-tile partial sums the producing conv GEMM's epilogue left (gemm2.hip, GemmParams::stats):
+// tp[(m * tiles + t) * 32 + g][2] fp64 sums over 128 pixels x (C/32) channels; summed over the image's tiles in a fixed order
+__global__ void gn_finalize_tiles_kernel(const double* __restrict__ tp, float* __restrict__ stats, int M, int tiles, double count,
+                                         float eps) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // over M*32
+  if (idx >= M * 32) return;
+  const int m = idx >> 5, g = idx & 31;
+  double s = 0.0, ss = 0.0;
+  for (int t = 0; t < tiles; ++t) {
+    const double* r = tp + (((long long)m * tiles + t) * 32 + g) * 2;
+    s += r[0];
+    ss += r[1];
+  }
+  const double mean = s / count;
+  double var = ss / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  stats[idx * 2] = (float)mean;
+  stats[idx * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // y = act((x - mean) * rstd * gamma + beta), act = swish (1) or identity (0); NHWC float4 pass
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, long long total4, int P, int C,
@@ -741,7 +761,7 @@ namespace {
 constexpr int GN_CHUNKS = 16;
 struct VPlan {
   float *pq, *b0, *b1, *b2, *q, *k, *v, *vt, *sc, *stats;
-  double* part;
+  double *part, *tpart;
   size_t bytes;
 };
 VPlan vplan(int M, void* ws) {
@@ -766,6 +786,7 @@ VPlan vplan(int M, void* ws) {
   p.sc = (float*)take((size_t)M * 256 * 256 * sizeof(float));
   p.stats = (float*)take((size_t)M * 32 * 2 * sizeof(float));
   p.part = (double*)take((size_t)M * GN_CHUNKS * 32 * 2 * sizeof(double));
+  p.tpart = (double*)take((size_t)M * 128 * 32 * 2 * sizeof(double));   // per-tile GroupNorm sums from a conv epilogue (<= 128 row tiles)
   p.bytes = off;
   return p;
 }
@@ -776,17 +797,28 @@ struct Ctx {
   int M;
   hipStream_t s;
   int split = 0;   // bf16x3_presplit: GroupNorm writes split rows, the 3x3 convs run on gemm2.hip
+  // GroupNorm statistics fused into the producing conv: the pre-split conv GEMM leaves per-tile sums of its output in p.tpart;
+  // a group_norm that is the very next op on that tensor finalises them instead of re-reading the tensor from HBM
+  int seq = 0, tp_seq = -1;
+  const float* tp_for = nullptr;
 };
 
 // stats: where (mean, rstd) of the M x 32 groups go (kept for the backward when given; default the shared scratch)
 int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish, int out_split = 0,
                float* stats = nullptr) {
   if (!stats) stats = c.p.stats;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_CHUNKS, c.M), dim3(256), 0, c.s, x, c.p.part, P, C, GN_CHUNKS);
-  RGM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, stats, c.M, GN_CHUNKS,
-                     (double)P * (C / 32), 1e-6f);
-  RGM_LAUNCH_CHECK();
+  const int my = ++c.seq;
+  if (c.tp_for == x && c.tp_seq == my - 1) {
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.tpart, stats, c.M, P / 128,
+                       (double)P * (C / 32), 1e-6f);
+    RGM_LAUNCH_CHECK();
+  } else {
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(GN_CHUNKS, c.M), dim3(256), 0, c.s, x, c.p.part, P, C, GN_CHUNKS);
+    RGM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, stats, c.M, GN_CHUNKS,
+                       (double)P * (C / 32), 1e-6f);
+    RGM_LAUNCH_CHECK();
+  }
   const long long total4 = (long long)c.M * P * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, y, stats,
                      c.h->p(key + ".weight"), c.h->p(key + ".bias"), total4, P, C, swish, out_split);
@@ -810,11 +842,22 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
   g.bias = c.h->p(key + ".bias");
   g.res = res; g.ldres = Cout;
   g.aload = 1; g.H = H; g.W = H; g.Cin = Cin; g.logH = ilog2(H); g.logW = ilog2(H); g.ups = ups;
-  if (in_split) g.tile = RGM_EXP_ENV("RGM_CONV_TILE");   // 0 = gemm2's heuristic (timing experiments: common.h)
-  return in_split ? gemm2_launch(g, c.s) : gemm_launch(g, c.s);
+  const int my = ++c.seq;
+  if (in_split) {
+    g.tile = RGM_EXP_ENV("RGM_CONV_TILE");   // 0 = gemm2's heuristic (timing experiments: common.h)
+    if (g.tile == 0 && Cout % 128 == 0 && Cout <= 512 && (H * H) % 128 == 0) {   // 128-row tiles never straddle an image
+      g.stats = c.p.tpart;
+      g.stats_gw = Cout / 32;
+      c.tp_for = out;
+      c.tp_seq = my;
+    }
+    return gemm2_launch(g, c.s);
+  }
+  return gemm_launch(g, c.s);
 }
 
 int conv1(Ctx& c, const float* in, float* out, int rows, int Cin, int Cout, const std::string& key, const float* res) {
+  ++c.seq;
   GemmParams g;
   g.A = in; g.lda = Cin; g.B = c.h->p(key + ".weight"); g.ldb = Cin; g.C = out; g.ldc = Cout;
   g.M = rows; g.N = Cout; g.K = Cin; g.bias = c.h->p(key + ".bias");
