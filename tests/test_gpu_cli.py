@@ -33,6 +33,15 @@ COMMON = ["--model", "DiTRotary_B_8", "--image_size", "128", "16", "--in_channel
     ("cond_table/single/dps_nn/nd.yml", ["--diffusion_steps", "25"], ["note_density"]),
     ("cond_table/single/dps_rule/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
     ("cond_table/single/dps_rule/nd.yml", ["--diffusion_steps", "20"], ["note_density"]),
+    # from the generated part of the tree (tools/make_configs.py): SCG on one rule, DDIM-respaced SCG, scheduled guidance
+    # every 5 steps, early stopping, the unguided baseline, classifier + SCG with a different candidate count
+    ("cond_table/single/scg/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
+    ("cond_table/abla/sampling/ddim/ddim25.yml", [], ["note_density"]),
+    ("cond_table/abla/sampling/ddpm/every5.yml", ["--diffusion_steps", "20"], ["note_density"]),
+    ("cond_table/abla/sampling/ddpmes/s750_400.yml", ["--diffusion_steps", "430"], ["note_density"]),   # stops at t = 400: 30 steps
+    ("cond_table/no_guidance/nd.yml", ["--diffusion_steps", "20"], ["note_density"]),
+    ("cond_table/abla/combine/nd_scg_cls_num4.yml", ["--diffusion_steps", "20"], ["note_density"]),
+    ("cond_table/single/dps_nn/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
 ])
 def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
     monkeypatch.chdir(tmp_path)

@@ -259,3 +259,36 @@ def test_midi_file_round_trip_and_default_io(tmp_path):
     finally:
         midi_util.register_midi_writer(None)
         midi_util.register_midi_reader(None)
+
+
+def test_every_shipped_config_has_the_reference_name_and_usable_targets():
+    """The config tree mirrors the reference's file names (62 files, tools/make_configs.py) and every sampling config carries
+    explicit targets the CLI can turn into rule tensors (the reference draws Null targets from its dataset)."""
+    import importlib.util
+    from guided_diffusion.midi_util import load_config
+    spec = importlib.util.spec_from_file_location("sample_rule_cli_cfg", os.path.join(PKG, "scripts", "sample_rule.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    base = os.path.join(PKG, "scripts", "configs")
+    names = sorted(os.path.relpath(os.path.join(dp, f), base) for dp, _, fs in os.walk(base) for f in fs)
+    assert len(names) >= 62
+    for must in ("cond_demo/demo1.yml", "cond_table/all/scg.yml", "cond_table/abla/sampling/ddim/ddim25.yml",
+                 "cond_table/abla/num_samples/nd_scg_num4.yml", "cond_table/single/scg/chord.yml", "edit/nd_600_num16.yml",
+                 "cond_table/all/weights/scg_classifier_all_bf4_40_1_4.yml", "cond_table/abla/latent/dps_rule/pitch_step_0_1.yml"):
+        assert must in names, must
+    width = {"pitch_hist": 12, "note_density": 16, "note_density_hr_2": 16, "chord_progression": 8, "chord_progression_pixel": 8}
+    for rel in names:
+        cfg = load_config(os.path.join(base, rel))
+        if rel.startswith("edit/"):
+            assert cfg.edit.source in ("synthetic",) and 0 <= cfg.edit.l_start < cfg.edit.l_end <= 128
+            continue
+        rules = cli.build_target_rules(vars(cfg.target_rules), 3, "cpu")
+        assert rules, rel
+        long = 4 if "long" in rel else 1                       # demo_long: a 4x longer sequence -> 4x the windows
+        for k, v in rules.items():
+            assert v.shape == (3, width[k] * (1 if k == "pitch_hist" else long)), (rel, k, tuple(v.shape))
+        if cfg.guidance.cond_fn is not None:
+            for name in cfg.guidance.cond_fn.rule_names:       # every guided rule has a target (pixel variants share the keys)
+                assert name.replace("_pixel", "") in rules or name in rules, (rel, name)
+        if getattr(cfg.sampling, "use_ddim", False) and hasattr(cfg.sampling, "timestep_respacing"):
+            assert cfg.sampling.timestep_respacing.startswith("ddim")
