@@ -29,19 +29,19 @@ COMMON = ["--model", "DiTRotary_B_8", "--image_size", "128", "16", "--in_channel
     ("cond_demo/demo2.yml", ["--diffusion_steps", "25"], ["pitch_hist", "note_density"]),
     ("cond_table/single/classifier/nd.yml", ["--diffusion_steps", "25"], ["note_density"]),
     ("cond_table/all/scg_classifier_all.yml", ["--diffusion_steps", "25"], ["pitch_hist", "note_density"]),
-    ("cond_demo/demo_long.yml", ["--diffusion_steps", "20"], ["pitch_hist", "note_density"]),
+    ("cond_demo/demo_long.yml", ["--diffusion_steps", "24"], ["pitch_hist", "note_density"]),
     ("cond_table/single/dps_nn/nd.yml", ["--diffusion_steps", "25"], ["note_density"]),
-    ("cond_table/single/dps_rule/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
-    ("cond_table/single/dps_rule/nd.yml", ["--diffusion_steps", "20"], ["note_density"]),
+    ("cond_table/single/dps_rule/pitch.yml", ["--diffusion_steps", "24"], ["pitch_hist"]),
+    ("cond_table/single/dps_rule/nd.yml", ["--diffusion_steps", "24"], ["note_density"]),
     # from the generated part of the tree (tools/make_configs.py): SCG on one rule, DDIM-respaced SCG, scheduled guidance
     # every 5 steps, early stopping, the unguided baseline, classifier + SCG with a different candidate count
-    ("cond_table/single/scg/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
+    ("cond_table/single/scg/pitch.yml", ["--diffusion_steps", "24"], ["pitch_hist"]),
     ("cond_table/abla/sampling/ddim/ddim25.yml", [], ["note_density"]),
-    ("cond_table/abla/sampling/ddpm/every5.yml", ["--diffusion_steps", "20"], ["note_density"]),
+    ("cond_table/abla/sampling/ddpm/every5.yml", ["--diffusion_steps", "24"], ["note_density"]),
     ("cond_table/abla/sampling/ddpmes/s750_400.yml", ["--diffusion_steps", "430"], ["note_density"]),   # stops at t = 400: 30 steps
-    ("cond_table/no_guidance/nd.yml", ["--diffusion_steps", "20"], ["note_density"]),
-    ("cond_table/abla/combine/nd_scg_cls_num4.yml", ["--diffusion_steps", "20"], ["note_density"]),
-    ("cond_table/single/dps_nn/pitch.yml", ["--diffusion_steps", "20"], ["pitch_hist"]),
+    ("cond_table/no_guidance/nd.yml", ["--diffusion_steps", "24"], ["note_density"]),
+    ("cond_table/abla/combine/nd_scg_cls_num4.yml", ["--diffusion_steps", "24"], ["note_density"]),
+    ("cond_table/single/dps_nn/pitch.yml", ["--diffusion_steps", "24"], ["pitch_hist"]),
 ])
 def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
     monkeypatch.chdir(tmp_path)
@@ -62,7 +62,7 @@ def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
 
 
 def test_edit_cli_keeps_the_fixed_part_and_rewrites_the_excerpt(tmp_path, monkeypatch):
-    """scripts/edit.py end to end (synthetic weights, synthetic source, 20-step chain, noise_level from the YAML clipped to
+    """scripts/edit.py end to end (synthetic weights, synthetic source, 24-step chain, noise_level from the YAML clipped to
     the chain): the latent rows outside [l_start, l_end) are the encoded source (replacement conditioning), the
     report covers the edited excerpt only."""
     import torch
@@ -74,7 +74,7 @@ def test_edit_cli_keeps_the_fixed_part_and_rewrites_the_excerpt(tmp_path, monkey
     cfg = os.path.join(str(tmp_path), "configs", "edit", "nd_short.yml")
     os.makedirs(os.path.dirname(cfg))
     open(cfg, "w").write(open(cfg_src).read().replace("noise_level: 500", "noise_level: 12"))
-    res, sample = cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "20"] + COMMON)
+    res, sample = cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "24"] + COMMON)
     assert len(res) == 2 and {"note_density.loss", "note_density.orig_rule"} <= set(res.columns)
     assert np.isfinite(res["note_density.loss"]).all()
     out_dir = os.path.join("loggings", "edit_demo", "edit", "nd_short_cls_1")
@@ -98,9 +98,32 @@ def test_edit_cli_reads_a_midi_source(tmp_path, monkeypatch):
     os.makedirs(os.path.dirname(cfg))
     text = open(cfg_src).read().replace("noise_level: 500", "noise_level: 12").replace("source: synthetic", f"source: {src}")
     open(cfg, "w").write(text)
-    res, sample = cli.main(["--config_path", cfg, "--batch_size", "1", "--num_samples", "1", "--diffusion_steps", "20"] + COMMON)
+    res, sample = cli.main(["--config_path", cfg, "--batch_size", "1", "--num_samples", "1", "--diffusion_steps", "24"] + COMMON)
     assert len(res) == 1 and np.isfinite(res["note_density.loss"]).all()
     gt_dir = os.path.join("loggings", "edit_demo", "edit", "nd_midi_cls_1", "gt")
     assert os.path.exists(os.path.join(gt_dir, "sample_0_y_1.midi")) and os.path.exists(os.path.join(gt_dir, "sample_0_y_1.npy"))
     gt = np.load(os.path.join(gt_dir, "sample_0_y_1.npy"))
     assert gt.shape == (3, 128, 1024) and (gt[0, :, 384:] == 0).all() and gt[0, :, :384].max() > 0
+
+
+@pytest.mark.parametrize("flags", [["--cfg", "True", "--w", "4.", "--class_cond", "True"], ["--class_cond", "False", "--use_ddim", "True",
+                                                                                       "--timestep_respacing", "ddim12"]])
+def test_cfg_sample_cli(tmp_path, monkeypatch, flags):
+    """scripts/cfg_sample.py (reference :26-127): unguided / classifier-free-guided batches -> uint8 rolls -> files of rank 0."""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("OPENAI_LOGDIR", str(tmp_path / "log"))
+    spec = importlib.util.spec_from_file_location("cfg_sample_cli", os.path.join(PKG, "scripts", "cfg_sample.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    arr = cli.main(["--model", "DiTRotary_B_8", "--image_size", "128", "16", "--in_channels", "4", "--scale_factor", "1.2465",
+                    "--num_classes", "3", "--class_label", "2", "--synthetic_weights", "True", "--progress", "False",
+                    "--batch_size", "2", "--num_samples", "3", "--diffusion_steps", "24", "--save_name", "_t"] + flags)
+    assert arr.shape == (3, 3, 128, 1024) and arr.dtype == np.uint8 and arr.max() <= 127
+    assert not np.array_equal(arr[0], arr[1])                                  # different noise per sample
+    out = [os.path.join(dp, f) for dp, _, fs in os.walk(str(tmp_path)) for f in fs if f.startswith("sample_")]
+    stems = sorted(os.path.basename(f) for f in out)
+    if "--cfg" in flags:
+        assert stems == ["sample_0_y_2.midi", "sample_0_y_2.npy", "sample_1_y_2.midi", "sample_1_y_2.npy", "sample_2_y_2.midi", "sample_2_y_2.npy"]
+    else:
+        assert stems == ["sample_0.midi", "sample_0.npy", "sample_1.midi", "sample_1.npy", "sample_2.midi", "sample_2.npy"]
+    assert all("gen_cls_2_t" in f for f in out)
