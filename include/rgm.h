@@ -157,6 +157,12 @@ int rgm_edit_replace_eps(const float* x, const float* eps, const float* gt, cons
  * cand and out may both be NULL (index only); max_ind may be NULL. */
 int rgm_scg_select(const float* cand, const float* total_logp, float* out, int64_t* max_ind, int n, int B, int E,
                    void* stream);
+/* Sharded SCG (SURVEY 8e option i; replaces the gather `sample[max_ind, arange(B)]` of :553-554 / :587-589 when the winner
+ * was scored on another rank): out[b] = mean[b] + g[b] * z, z = the rgm_randn stream (seed) at positions
+ * base + (k*B + b)*E + e with k = max_ind[seg][b]; the latent row h of (C,H,W) belongs to segment h / seg_rows
+ * (max_ind is (S,B), S = ceil(H / seg_rows); seg_rows >= H: one winner per sample).  No host read of max_ind. */
+int rgm_scg_rebuild(const float* mean, const float* g, const int64_t* max_ind, uint64_t seed, uint64_t base, float* out,
+                    int B, int E, int H, int W, int seg_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * taming KL-VAE decoder (f8-all-onset config)            taming/models/klvae_pedal.py:80-85,
@@ -233,6 +239,7 @@ int rgm_row_loss(const float* a, const float* b, float* out, int rows, int K, in
  *   loss_kind 0 (kind-1 handle): log p = -sum_k (logits - target)^2, target float32 (N, n_out)    [grad_nn_zt_mse]
  *   loss_kind 1 (kind-2 handle): log p = -sum_w CE(chord_logits[w], target[w]), target int64 (N, H/width)
  *                                                                                 [grad_nn_zt_chord, both=False]
+ *   loss_kind 1 (kind-1 handle): log p = log softmax(logits)[target], target int64 (N,)             [grad_nn_zt_xentropy :46-56]
  * grad_x (N,in_ch,H,width) = d(sum log p)/dx * scale;  logits_out (N[,H/width], n_out) or NULL. */
 size_t rgm_dit_grad_workspace_bytes(const rgm_dit* h, int N, int H);
 int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,

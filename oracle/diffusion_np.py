@@ -8,6 +8,8 @@ Test infrastructure (see oracle/__init__.py).  Restates, on CPU in numpy:
   guided_diffusion/gaussian_diffusion.py:387-407 condition_mean (classifier guidance branch)
   guided_diffusion/gaussian_diffusion.py:467-489 condition_score
   guided_diffusion/gaussian_diffusion.py:491-554 scg_sample (argmax branch)
+  guided_diffusion/gaussian_diffusion.py:562-592 scg_sample (dc.base > 0: one winner per time segment)
+  guided_diffusion/condition_functions.py:17-42  model_fn / dc_model_fn (null label, classifier-free guidance)
   guided_diffusion/gaussian_diffusion.py:635-735 p_sample
   guided_diffusion/gaussian_diffusion.py:881-976 ddim_sample
   guided_diffusion/gaussian_diffusion.py:1347-1358 _decode, :1398-1400 guide_schedule
@@ -148,9 +150,56 @@ def decode_latent(z, decode_fn, scale_factor):
     return np.concatenate(np.split(dec, n_seg, axis=0), axis=-1)
 
 
+def model_fn(model, x, t, y=None, num_classes=3, class_cond=True, cfg=False, w=0., transpose=False):
+    """condition_functions.py:17-27 (transpose=False) / :30-42 dc_model_fn (transpose=True: the DiffCollage eps function
+    works on (4, pitch, time), the sampler's latent is (4, time, pitch)).  `model(x, t, y)` is any eps callable."""
+    if transpose:
+        x = np.ascontiguousarray(x.transpose(0, 1, 3, 2))
+    y_null = np.full((x.shape[0],), num_classes, dtype=np.int64)
+    if class_cond:
+        if cfg:
+            out = F32(1 + w) * model(x, t, y).astype(F32) - F32(w) * model(x, t, y_null).astype(F32)
+        else:
+            out = model(x, t, y)
+    else:
+        out = model(x, t, y_null)
+    out = out.astype(F32)
+    return np.ascontiguousarray(out.transpose(0, 1, 3, 2)) if transpose else out
+
+
+def _scg_segments(cand, x0, B, n, model_kwargs, scg_kwargs, func_dict, loss_dict, base):
+    """:562-592.  One argmax per time segment of `base` latent rows (8*base roll frames); note_density / chord targets are
+    cut to the segment's windows (rule_base = base // 16 windows per segment), pitch_hist targets are used whole."""
+    total_len = x0.shape[-1]
+    seg = base * 8
+    rule_base = base // 16
+    cv = cand.reshape((n, B) + cand.shape[1:])
+    pieces, inds, totals = [], [], []
+    for i, s0 in enumerate(range(0, total_len, seg)):
+        s1 = min(s0 + seg, total_len)
+        cur = np.ascontiguousarray(x0[:, :, :, s0:s1])
+        total = np.zeros(n * B, dtype=F32)
+        for name, target in model_kwargs["rule"].items():
+            gen = func_dict[name](cur)
+            if name == "note_density":
+                half = target.shape[-1] // 2
+                sl = slice(i * rule_base, min((i + 1) * rule_base, half))
+                target = np.concatenate((target[:, :half][:, sl], target[:, half:][:, sl]), axis=-1)
+            elif "chord" in name:
+                target = target[:, i * rule_base: min((i + 1) * rule_base, target.shape[-1])]
+            lp = -loss_dict[name](gen, np.tile(target, (n, 1)))
+            total = (total + lp * F32(scg_kwargs.get(name, 1.0))).astype(F32)
+        total = total.reshape(n, B)
+        mi = total.argmax(axis=0)
+        pieces.append(cv[mi, np.arange(B)][:, :, s0 // 8: s1 // 8])
+        inds.append(mi)
+        totals.append(total)
+    return np.concatenate(pieces, axis=-2), np.stack(inds), np.stack(totals, axis=1)
+
+
 def scg_sample(S, model, t, mean_pred, g_coeff, decode_fn, scale_factor, model_kwargs, scg_kwargs,
-               noise, func_dict, loss_dict, wrap_t=True, return_aux=False, edit=None):
-    """:491-554 (dc.base<=0 branch).  `noise` has shape (n,B,C,H,W) -- the randn_like draw of :512.
+               noise, func_dict, loss_dict, wrap_t=True, return_aux=False, edit=None, dc_base=0):
+    """:491-554 (dc.base<=0 branch) and :562-592 (dc_base > 0).  `noise` has shape (n,B,C,H,W) -- the randn_like draw of :512.
 
     wrap_t=False reproduces the p_sample quirk (model passed unwrapped).
     """
@@ -166,6 +215,11 @@ def scg_sample(S, model, t, mean_pred, g_coeff, decode_fn, scale_factor, model_k
         x0 = np.ascontiguousarray(x0[:, :, edit["l_start"]:edit["l_end"], :])
     if decode_fn is not None:
         x0 = decode_latent(x0, decode_fn, scale_factor)
+    if dc_base > 0:
+        sample, inds, totals = _scg_segments(cand, x0, B, n, model_kwargs, scg_kwargs, func_dict, loss_dict, dc_base)
+        if return_aux:
+            return sample, {"total_log_prob": totals, "max_ind": inds, "pred_xstart_dec": x0}
+        return sample
     total = np.zeros(n * B, dtype=F32)
     each = {}
     for name, target in model_kwargs["rule"].items():
@@ -184,7 +238,7 @@ def scg_sample(S, model, t, mean_pred, g_coeff, decode_fn, scale_factor, model_k
 
 def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwargs=None,
              guidance=None, scg_kwargs=None, decode_fn=None, scale_factor=1.0, t_end=0,
-             func_dict=None, loss_dict=None, return_aux=False, edit=None):
+             func_dict=None, loss_dict=None, return_aux=False, edit=None, dc_base=0):
     """:635-735.  `guidance` = dict(schedule,t_start,t_end,interval) or None.
 
     noise: (B,...) for the plain / unguided-SCG draw, (n,B,...) for the SCG draw, None when
@@ -216,7 +270,7 @@ def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwa
         if use_g:
             sample = scg_sample(S, model, t, out["mean"], g, decode_fn, scale_factor, model_kwargs,
                                 scg_kwargs, noise, func_dict, loss_dict, wrap_t=False,
-                                return_aux=return_aux, edit=edit)
+                                return_aux=return_aux, edit=edit, dc_base=dc_base)
             if return_aux:
                 sample, a2 = sample
                 aux.update(a2)
@@ -232,7 +286,7 @@ def p_sample(S, model, x, t, noise, clip_denoised=False, cond_fn=None, model_kwa
 
 def ddim_sample(S, model, x, t, noise, eta=0.0, clip_denoised=False, cond_fn=None, model_kwargs=None,
                 guidance=None, scg_kwargs=None, decode_fn=None, scale_factor=1.0, t_end=0,
-                func_dict=None, loss_dict=None, return_aux=False, edit=None):
+                func_dict=None, loss_dict=None, return_aux=False, edit=None, dc_base=0):
     """:881-976."""
     model_kwargs = model_kwargs or {}
     t = np.asarray(t)
@@ -261,7 +315,7 @@ def ddim_sample(S, model, x, t, noise, eta=0.0, clip_denoised=False, cond_fn=Non
         if use_g:
             sample = scg_sample(S, model, t, mean_pred, sigma, decode_fn, scale_factor, model_kwargs,
                                 scg_kwargs, noise, func_dict, loss_dict, wrap_t=True,
-                                return_aux=return_aux, edit=edit)
+                                return_aux=return_aux, edit=edit, dc_base=dc_base)
             if return_aux:
                 sample, a2 = sample
                 aux.update(a2)

@@ -774,13 +774,14 @@ static int grad_embed_backward(rgm_dit* h, const GPlan& p, float* grad_x, hipStr
 
 // loss_kind 0: log p = -sum_k (logits - target)^2, target float (N, n_out)                  [grad_nn_zt_mse]
 // loss_kind 1: log p = -sum_windows CE(chord_logits, target), target int64 (N, H/width)     [grad_nn_zt_chord, both=False]
+//              on a plain classifier (kind 1): log p = log softmax(logits)[target], target int64 (N,)  [grad_nn_zt_xentropy]
 // grad_x (N,in_ch,H,width) = d(sum log p)/dx * scale ; logits_out (N[,H/width], n_out) optional.
 extern "C" int rgm_dit_cls_value_and_grad(rgm_dit* h, const float* x, const int64_t* t, const void* target, int loss_kind,
                                           float scale, float* logits_out, float* grad_x, int N, int H, void* ws,
                                           size_t ws_bytes, void* stream) {
   RGM_REQUIRE(h && h->cfg.kind != 0, "cls_value_and_grad: handle is not a classifier");
   RGM_REQUIRE(x && t && target && grad_x, "cls_value_and_grad: null tensor");
-  RGM_REQUIRE((loss_kind == 0 && h->cfg.kind == 1) || (loss_kind == 1 && h->cfg.kind == 2),
+  RGM_REQUIRE((loss_kind == 0 && h->cfg.kind == 1) || (loss_kind == 1 && (h->cfg.kind == 2 || h->cfg.kind == 1)),
               "cls_value_and_grad: loss_kind %d does not match classifier kind %d", loss_kind, h->cfg.kind);
   RGM_TRY(check_call(h, N, H));
   const rgm_dit_cfg& c = h->cfg;

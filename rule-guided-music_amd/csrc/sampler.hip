@@ -38,17 +38,12 @@ __device__ __forceinline__ void philox4x32_10(uint64_t ctr, uint64_t seed, uint3
   for (int i = 0; i < 4; ++i) out[i] = c[i];
 }
 
-// out[i] ~ N(0,1); element i is a pure function of (seed, offset + i): counter = (offset+i)/4, lane (offset+i)%4
-__global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset) {
-  const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;  // one Philox block = 4 normals
-  const uint64_t first = offset >> 2;
-  const long long nblk = (long long)(((offset + (uint64_t)n + 3) >> 2) - first);
-  if (q >= nblk) return;
+// the 4 normals of Philox block `ctr`: Box-Muller on (0,1] x [0,1)
+__device__ __forceinline__ void philox_normals(uint64_t ctr, uint64_t seed, float (&z)[4]) {
   uint32_t r[4];
-  philox4x32_10(first + (uint64_t)q, seed, r);
-  float z[4];
+  philox4x32_10(ctr, seed, r);
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {  // Box-Muller on (0,1] x [0,1)
+  for (int h = 0; h < 2; ++h) {
     const float u1 = ((float)(r[2 * h] >> 8) + 1.0f) * (1.0f / 16777216.0f);
     const float u2 = (float)(r[2 * h + 1] >> 8) * (1.0f / 16777216.0f);
     const float rad = sqrtf(-2.0f * logf(u1));
@@ -57,6 +52,16 @@ __global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed
     z[2 * h] = rad * cs;
     z[2 * h + 1] = rad * sn;
   }
+}
+
+// out[i] ~ N(0,1); element i is a pure function of (seed, offset + i): counter = (offset+i)/4, lane (offset+i)%4
+__global__ void randn_kernel(float* __restrict__ out, long long n, uint64_t seed, uint64_t offset) {
+  const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;  // one Philox block = 4 normals
+  const uint64_t first = offset >> 2;
+  const long long nblk = (long long)(((offset + (uint64_t)n + 3) >> 2) - first);
+  if (q >= nblk) return;
+  float z[4];
+  philox_normals(first + (uint64_t)q, seed, z);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const long long g = (long long)((first + (uint64_t)q) * 4 + j) - (long long)offset;
@@ -187,6 +192,35 @@ __global__ void scg_select_kernel(const float* __restrict__ cand, const float* _
   if (blockIdx.x == 0 && threadIdx.x == 0 && max_ind) max_ind[b] = best;
 }
 
+// Winner regeneration of the sharded SCG step: the (n, B) score table is identical on every rank after the all-gather, the
+// winning candidate may have been scored on another rank, and candidate k of sample b is mean[b] + g[b] * z with z the
+// Philox normals at stream positions base + (k*B + b)*E + e -- so every rank rebuilds the winners itself, on the device,
+// from the argmax indices (no latent traffic, no host read-back of max_ind).  Segment-wise selection (dc.base > 0,
+// gaussian_diffusion.py:562-592): row h of the (C, H, W) latent belongs to segment h / seg_rows and takes that segment's
+// winner, max_ind is (S, B); seg_rows >= H is the plain case (S = 1).
+__global__ void scg_rebuild_kernel(const float* __restrict__ mean, const float* __restrict__ g, const int64_t* __restrict__ max_ind,
+                                   uint64_t seed, uint64_t base, float* __restrict__ out, int B, int E, int H, int W, int seg_rows) {
+  const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // 4 consecutive elements (E % 4 == 0, W % 4 == 0)
+  const long long total4 = (long long)B * E / 4;
+  if (q >= total4) return;
+  const long long i = q * 4;
+  const int b = (int)(i / E), e = (int)(i - (long long)b * E);
+  const int seg = ((e / W) % H) / seg_rows;
+  const int64_t k = max_ind[(long long)seg * B + b];
+  const uint64_t pos = base + ((uint64_t)k * B + b) * (uint64_t)E + (uint64_t)e;
+  float z0[4], z1[4];
+  philox_normals(pos >> 2, seed, z0);
+  const int lane = (int)(pos & 3);
+  if (lane) philox_normals((pos >> 2) + 1, seed, z1);
+  const float gb = g[b];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int l = lane + j;
+    const float z = l < 4 ? z0[l & 3] : z1[l & 3];
+    out[i + j] = mean[i + j] + gb * z;
+  }
+}
+
 }  // namespace rgm
 
 using namespace rgm;
@@ -269,6 +303,17 @@ extern "C" int rgm_scg_select(const float* cand, const float* total_logp, float*
   RGM_REQUIRE(total_logp && n > 0 && B > 0 && E > 0 && ((cand == nullptr) == (out == nullptr)), "scg_select: bad arguments");
   hipLaunchKernelGGL(scg_select_kernel, dim3(cdiv(E, 1024) > 64 ? 64 : cdiv(E, 1024), B), dim3(256), 0, (hipStream_t)stream, cand,
                      total_logp, out, max_ind, n, B, E);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_scg_rebuild(const float* mean, const float* g, const int64_t* max_ind, uint64_t seed, uint64_t base, float* out,
+                               int B, int E, int H, int W, int seg_rows, void* stream) {
+  RGM_REQUIRE(mean && g && max_ind && out && B > 0 && E > 0 && H > 0 && W > 0 && seg_rows > 0, "scg_rebuild: bad arguments");
+  RGM_REQUIRE(E % (H * W) == 0 && W % 4 == 0, "scg_rebuild: E = %d is not C x H x W with H = %d, W = %d (W %% 4 == 0)", E, H, W);
+  const long long total4 = (long long)B * E / 4;
+  hipLaunchKernelGGL(scg_rebuild_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, g, max_ind,
+                     seed, base, out, B, E, H, W, seg_rows);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

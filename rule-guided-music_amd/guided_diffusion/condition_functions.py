@@ -50,6 +50,13 @@ def _value_and_grad(classifier, x, t, target, loss_kind, scale):
     return classifier.value_and_grad(x, t, target, loss_kind, scale)[1]
 
 
+def grad_nn_zt_xentropy(x, y=None, rule=None, classifier=nn.Identity()):
+    """grad_x of log softmax(classifier(x, t = 0))[rule] (reference :46-56; its signature has no `t` / `classifier_scale`, so --
+    as in the reference -- it cannot be reached through composite_nn_zt; kept for callers that bind it directly)."""
+    assert rule is not None
+    return _value_and_grad(classifier, x, _zeros_t(x), rule, "xent", 1.0)
+
+
 def grad_nn_zt_mse(x, t, y=None, rule=None, classifier_scale=10., classifier=nn.Identity()):
     """grad_x of -sum((classifier(x,t) - rule)^2), times classifier_scale."""
     assert rule is not None
@@ -165,6 +172,7 @@ def composite_rule_value_and_grad(roll, t, y=None, rule=None, fns=None, classifi
 
 
 function_map = {
+    "grad_nn_zt_xentropy": grad_nn_zt_xentropy,
     "grad_nn_zt_mse": grad_nn_zt_mse,
     "grad_nn_zt_chord": grad_nn_zt_chord,
     "nn_z0_chord_dummy": nn_z0_chord_dummy, "nn_z0_mse_dummy": nn_z0_mse_dummy, "nn_z0_mse": nn_z0_mse,

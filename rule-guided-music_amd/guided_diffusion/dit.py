@@ -256,7 +256,8 @@ class DiTRotaryClassifier(_NativeDiT):
         """(logits, grad_x) with grad_x = scale * d(sum log p)/dx, in one native call (no autograd graph).
 
         loss_kind "mse": log p = -sum (logits - target)^2, target (N, num_classes) float
-        loss_kind "chord_ce": log p = -sum CE(chord_logits, target), target (N, H/W) integer   [chord=True]"""
+        loss_kind "chord_ce": log p = -sum CE(chord_logits, target), target (N, H/W) integer   [chord=True]
+        loss_kind "xent": log p = log softmax(logits)[target], target (N,) integer"""
         _rgm.require_cuda(x, t, target)
         N, _, H, W = x.shape
         self._ensure_native(H * W // self.patch_size + 1)
@@ -265,6 +266,10 @@ class DiTRotaryClassifier(_NativeDiT):
         if loss_kind == "mse":
             assert not self.chord
             tgt, kind = target.to(torch.float32).contiguous(), 0
+            logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
+        elif loss_kind == "xent":                       # log softmax(logits)[target] on a plain classifier (grad_nn_zt_xentropy)
+            assert not self.chord
+            tgt, kind = target.reshape(N).to(torch.int64).contiguous(), 1
             logits = torch.empty((N, self.num_classes), dtype=torch.float32, device=x.device)
         elif loss_kind == "chord_ce":
             assert self.chord

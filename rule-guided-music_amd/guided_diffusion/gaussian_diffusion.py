@@ -19,8 +19,8 @@ What is different underneath (design, not a translation):
     all-gather of the (n, B) rule log-probabilities per step, winners regenerated locally from the
     shared Philox counters -- see scg_shard / SURVEY 8e.
 
-Not implemented here (SURVEY 8f "next"): DPS through rule(decode(x0)) (needs the VAE decoder's backward),
-learned variances, training losses.  They raise NotImplementedError instead of silently degrading.
+Not implemented here: learned variances / x0-prediction checkpoints (learn_sigma, predict_xstart), denoised_fn, training
+losses.  They raise NotImplementedError instead of silently degrading.
 """
 import ctypes as C
 import enum
@@ -273,8 +273,13 @@ class GaussianDiffusion:
         assert eps.shape == x.shape, f"model output {tuple(eps.shape)} vs x {tuple(x.shape)}"
         grad = None if grad is None else grad.float().contiguous()
         noise = None if noise is None else noise.float().contiguous()
+        # the kernels index grad / noise like x: a cond_fn that returns per-sample log-probabilities (the DPS family) where a
+        # gradient is expected must fail here, not read out of bounds
+        assert grad is None or grad.shape == x.shape, f"cond_fn returned {tuple(grad.shape)}, expected a gradient like x {tuple(x.shape)}"
+        assert noise is None or noise.shape == x.shape, f"noise {tuple(noise.shape)} vs x {tuple(x.shape)}"
         tt = t.long().contiguous()
         N = x.shape[0]
+        assert tt.shape == (N,)
         E = x.numel() // N
         sample, x0 = th.empty_like(x), th.empty_like(x)
         g = th.empty(N, dtype=th.float32, device=x.device) if want_g else None
@@ -294,8 +299,6 @@ class GaussianDiffusion:
     def _reject_unsupported(denoised_fn, edit_kwargs, guidance_kwargs=None):
         if denoised_fn is not None:
             raise NotImplementedError("denoised_fn is not supported by the fused native step")
-        if edit_kwargs is not None and guidance_kwargs is not None and getattr(guidance_kwargs, "method", None) == "dps":
-            raise NotImplementedError("DPS guidance under edit_kwargs (editable-slice gradient) is not provided")
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                         cond_fn=None, embed_model=None, edit_kwargs=None):
@@ -315,14 +318,16 @@ class GaussianDiffusion:
         """Classifier guidance on the mean: mean + variance * grad log p(y|x_t)   (non-DPS branch)."""
         self._reject_unsupported(None, edit_kwargs, guidance_kwargs)
         if getattr(guidance_kwargs, "method", None) == "dps":
-            return self._dps_mean(cond_fn, p_mean_var, x, t, model_kwargs or {}, guidance_kwargs, model, embed_model, scale_factor)
+            return self._dps_mean(cond_fn, p_mean_var, x, t, model_kwargs or {}, guidance_kwargs, model, embed_model, scale_factor,
+                                  edit_kwargs=edit_kwargs)
         if edit_kwargs is None:
             grad = cond_fn(x, self._scale_timesteps(t), **(model_kwargs or {}))
         else:
             grad = self._edit_grad(cond_fn, x, self._scale_timesteps(t), model_kwargs or {}, edit_kwargs)
         return p_mean_var["mean"].float() + p_mean_var["variance"] * grad.float()
 
-    def _dps_mean(self, cond_fn, p_mean_var, x, t, model_kwargs, guidance_kwargs, model, embed_model, scale_factor=1.):
+    def _dps_mean(self, cond_fn, p_mean_var, x, t, model_kwargs, guidance_kwargs, model, embed_model, scale_factor=1.,
+                  edit_kwargs=None):
         """DPS (reference :415-465): mean + step_size * d log p(rule | x0_hat(x_t)) / d x_t / sqrt(-log p), where
         x0_hat = c1 x_t - c2 eps(x_t).  The reference differentiates through the eps-network and the classifier with
         autograd; here d/dx_t = c1 g + (d eps/d x_t)^T (-c2 g) with g = d log p / d x0 from the classifier's fused
@@ -330,6 +335,15 @@ class GaussianDiffusion:
         import functools
         from . import condition_functions as cf
         assert model is not None
+        if edit_kwargs is not None:
+            # reference :426-428, :453-455: the rule is checked on pred_xstart[:, :, l_start:l_end] and the FULL-size input gradient
+            # is added to new_mean[:, :, l_start:l_end] -- which only broadcasts when the whole latent is editable.  In that case
+            # both slices are the identity (the decoded roll's 128 pitch rows are covered by l_end >= 128 as well).
+            ls, le = int(edit_kwargs["l_start"]), int(edit_kwargs["l_end"])
+            if ls != 0 or le < x.shape[2]:
+                raise ValueError(f"DPS guidance under edit_kwargs needs the whole latent editable (l_start 0, l_end {x.shape[2]}): "
+                                 f"got [{ls}, {le}) -- the reference's `new_mean[:, :, l_start:l_end] += step_size * gradient` "
+                                 "fails to broadcast otherwise")
         through_vae = embed_model is not None and not getattr(guidance_kwargs, "nn", True)
         inner_c = cond_fn.model if hasattr(cond_fn, "map_ts") else cond_fn
         want = cf.composite_rule if through_vae else cf.composite_nn_zt
@@ -419,17 +433,21 @@ class GaussianDiffusion:
             x0 = x0[:, :, int(edit_kwargs["l_start"]):int(edit_kwargs["l_end"]), :].contiguous()
         if embed_model is not None:
             x0 = _decode(x0, embed_model, scale_factor=scale_factor)
-        def rebuild(win):
-            """candidates win[b] of every sample b, regenerated from the shared noise stream: mean + g * noise[win[b], b]"""
-            if full_noise is not None:
-                wn = th.stack([full_noise[k, b] for b, k in enumerate(win)])
-            else:
-                wn = th.stack([self.noise.fill((E,), dev, offset=base + (k * B + b) * E) for b, k in enumerate(win)])
-            wn = wn.reshape((1,) + tuple(mean_pred.shape)).contiguous()
+        def rebuild(max_ind, seg_rows=None):
+            """Winners regenerated from the shared noise stream on the device: mean + g * noise[max_ind[seg, b], b] -- no host
+            read of max_ind.  max_ind (B,) or (S,B) int64; seg_rows = latent rows per segment (None: one winner per sample)."""
+            H, W = mean_pred.shape[-2:]
+            seg_rows = H if seg_rows is None else int(seg_rows)
+            mi = max_ind.reshape(-1, B).contiguous()
+            if full_noise is not None:                       # injected noise (tests): a device gather per segment
+                ar = th.arange(B, device=dev)
+                parts = [mean_pred[:, :, r0:r0 + seg_rows] + g.view(B, 1, 1, 1) * full_noise[mi[i], ar][:, :, r0:r0 + seg_rows]
+                         for i, r0 in enumerate(range(0, H, seg_rows))]
+                return th.cat(parts, dim=-2).contiguous()
             res = th.empty_like(mean_pred)
             with th.cuda.device(dev):
-                _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(wn), _rgm.ptr(res), 1, B, E,
-                                                       _rgm.current_stream()))
+                _rgm.check(_rgm.lib.rgm_scg_rebuild(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(mi), C.c_uint64(self.noise.seed),
+                                                    C.c_uint64(base), _rgm.ptr(res), B, E, H, W, seg_rows, _rgm.current_stream()))
             return res
 
         if dc_kwargs is not None and getattr(dc_kwargs, "base", 0) > 0:
@@ -454,7 +472,7 @@ class GaussianDiffusion:
                 # another rank: rebuild it here from the shared noise stream (zero traffic, SURVEY 8e option i).
                 _rgm.check(_rgm.lib.rgm_scg_select(None, _rgm.ptr(total_all), None, _rgm.ptr(max_ind), n, B, E,
                                                    _rgm.current_stream()))
-                out = rebuild(max_ind.tolist())                                # B ints: one sync per guided step
+                out = rebuild(max_ind)                                         # on the device: no host sync in a guided step
         if record:
             self._record_scg(t, total_all, max_ind, each, x0, nl, B, record_freq, sharded)
         self.last_scg = {"total_log_prob": total_all, "max_ind": max_ind}
@@ -505,11 +523,9 @@ class GaussianDiffusion:
                 _rgm.check(_rgm.lib.rgm_scg_select(_rgm.ptr(piece_src), _rgm.ptr(tab), _rgm.ptr(out), _rgm.ptr(max_ind[i]), n, B, E,
                                                    _rgm.current_stream()))
                 pieces.append(out)
-        if sharded:
-            wins = max_ind.tolist()                                              # S x B ints: one sync per guided step
-            for i, (s0, s1) in enumerate(bounds):
-                pieces.append(rebuild(wins[i])[:, :, s0 // 8: s1 // 8])
         self.last_scg = {"total_log_prob": total_all, "max_ind": max_ind}
+        if sharded:
+            return rebuild(max_ind, seg_rows=dc_kwargs.base)                     # (S,B) winners, rebuilt on the device
         return th.cat(pieces, dim=-2)
 
     def _record_scg(self, t, total, max_ind, each, x0, nl, B, record_freq, sharded):
@@ -538,25 +554,36 @@ class GaussianDiffusion:
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None,
                  embed_model=None, scale_factor=1., guidance_kwargs=None, scg_kwargs=None, edit_kwargs=None, record=False):
         """One ancestral DDPM step -> {'sample', 'pred_xstart'}."""
-        self._reject_unsupported(denoised_fn, edit_kwargs, guidance_kwargs if cond_fn is not None else None)
+        self._reject_unsupported(denoised_fn, edit_kwargs)
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
         eps = self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
-        if cond_fn is not None and use_guidance and getattr(guidance_kwargs, "method", None) == "dps":
-            if scg_kwargs is not None:
-                raise NotImplementedError("DPS guidance combined with SCG")
+        # with scg_kwargs given the guidance schedule only gates the SCG search: condition_mean runs on every step (reference :691)
+        guided = cond_fn is not None and (use_guidance or scg_kwargs is not None)
+        if guided and getattr(guidance_kwargs, "method", None) == "dps":
             mean, x0, g = self._step("ddpm", x, eps, None, None, t, clip_denoised, want_g=True)
             # the reference hands the UNWRAPPED model to condition_mean (:692-697): on a re-spaced chain the DPS forward
             # runs at the un-mapped t, like scg_sample's.  Reproduced, not fixed.
             mean = self.condition_mean(cond_fn, {"mean": mean}, x, t, model_kwargs=model_kwargs, guidance_kwargs=guidance_kwargs,
-                                       model=model, embed_model=embed_model, scale_factor=scale_factor, record=record)
-            noise = self._draw(x.shape, x.device)
-            sample = self._add_noise(mean, g, noise) if self._t0(t) > self.t_end else mean
+                                       model=model, embed_model=embed_model, edit_kwargs=edit_kwargs, scale_factor=scale_factor,
+                                       record=record)
+            live = self._t0(t) > self.t_end
+            if scg_kwargs is None:
+                noise = self._draw(x.shape, x.device)                        # drawn (and masked) like the reference's :699-703
+                sample = self._add_noise(mean, g, noise) if live else mean
+            elif live and use_guidance:                                       # DPS-shifted mean, then branch-and-select (:706-713)
+                sample = self.scg_sample(model, t, mean, g, embed_model, scale_factor, model_kwargs=model_kwargs,
+                                         scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
+                                         dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record)
+            elif live:
+                sample = self._add_noise(mean, g, self._draw(x.shape, x.device))
+            else:
+                sample = mean
             return {"sample": sample, "pred_xstart": x0}
         grad = None
-        if cond_fn is not None and (use_guidance or scg_kwargs is not None):
+        if guided:
             if edit_kwargs is None:
                 grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
             else:
@@ -590,6 +617,11 @@ class GaussianDiffusion:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         grad = None
         if cond_fn is not None and use_guidance:
+            if getattr(guidance_kwargs, "method", None) == "dps":
+                # the reference feeds the (B,) log-probabilities of a DPS cond_fn to condition_score as if they were a gradient
+                # (:467-482), which does not broadcast against the latent either
+                raise NotImplementedError("DPS guidance is defined for the DDPM step (p_sample) only; ddim_sample applies "
+                                          "condition_score, which needs a gradient cond_fn")
             grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
         if scg_kwargs is None:
             sample, x0, _ = self._step("ddim", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised, eta=eta)

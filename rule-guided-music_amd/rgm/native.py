@@ -42,6 +42,7 @@ def _load():
         "rgm_xstart_from_eps": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, i32, vp]),
         "rgm_edit_replace_eps": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, vp, i32, i32, vp]),
         "rgm_scg_select": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
+        "rgm_scg_rebuild": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_vae_create": (C.c_int, [C.POINTER(vp)]),
         "rgm_vae_destroy": (None, [vp]),
         "rgm_vae_set_param": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), i32]),
@@ -99,16 +100,13 @@ class _Lazy:
 
 
 lib = _Lazy()
-EXPORTS = ["rgm_version", "rgm_last_error", "rgm_dit_create", "rgm_dit_destroy", "rgm_dit_set_param",
-           "rgm_dit_missing_params", "rgm_dit_workspace_bytes", "rgm_dit_forward", "rgm_dit_classify",
-           "rgm_gemm", "rgm_layernorm_modulate", "rgm_rotary_attention"]
-
-
 PRECISIONS = {"fp32": 0, "bf16x3": 1, "bf16x3_presplit": 2}
 
 
 def set_gemm_precision(name):
-    """'fp32' (exact fp32 MFMA, default) or 'bf16x3' (split-bf16, ~3x the MFMA rate, ~2e-5 relative per product)."""
+    """Process-wide GEMM arithmetic: 'fp32' (exact v_mfma_f32_32x32x2_f32; the library's start-up value), 'bf16x3' (operands split
+    hi + lo into two bf16 while staged, 3 bf16 MFMAs per product, ~2^-16 relative per product) or 'bf16x3_presplit' (same numerics,
+    operands split once by their producer, LDS-DMA staging; the default of bench.py and the CLIs)."""
     check(lib.rgm_set_gemm_precision(PRECISIONS[name]))
 
 

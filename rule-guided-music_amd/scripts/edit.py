@@ -29,7 +29,7 @@ from guided_diffusion import dist_util, logger, midi_util                       
 from guided_diffusion.gaussian_diffusion import _encode, _extract_rule                      # noqa: E402
 from guided_diffusion.midi_util import (HORIZONTAL_ND_BOUNDS, HORIZONTAL_ND_CENTER, VERTICAL_ND_BOUNDS,  # noqa: E402
                                         VERTICAL_ND_CENTER)
-from sample_rule import build_pipeline, create_argparser as _sample_argparser              # noqa: E402
+from sample_rule import build_pipeline, setup_chord_backend, create_argparser as _sample_argparser              # noqa: E402
 
 
 def synthetic_roll(seed, T):
@@ -114,7 +114,7 @@ def main(argv=None):
     _native.set_gemm_precision(args.gemm_precision)
     comm = dist_util.setup_dist(port=args.port)
     logger.configure(args=args, comm=comm)
-    config = midi_util.load_config(args.config_path)
+    config = setup_chord_backend(args, midi_util.load_config(args.config_path))
     if config.sampling.use_ddim:
         args.timestep_respacing = config.sampling.timestep_respacing
     device = dist_util.dev()

@@ -34,6 +34,49 @@ from load_utils import load_model  # noqa: E402
 import diff_collage as dc  # noqa: E402
 
 
+NOISE_FN = None     # tests only: callable(shape, device) -> tensor installed as diffusion.noise_fn (teacher-forced parity runs)
+
+
+def setup_chord_backend(args, config):
+    """Chord rules (`chord_progression*`) need a host analyser with the signature of the reference's piano_roll_to_chords
+    (music21; not installable here).  --chord_backend module:function registers one (music_rules.register_chord_backend).
+    Without one the reference's chord entries are ACCEPTED and skipped with a warning: they are removed from target_rules,
+    from the SCG weights and from the cond_fn lists, so a reference YAML runs with its remaining rules."""
+    from music_rule_guidance import music_rules
+    if getattr(args, "chord_backend", ""):
+        import importlib
+        mod, _, fn = args.chord_backend.partition(":")
+        music_rules.register_chord_backend(getattr(importlib.import_module(mod), fn), workers=int(args.chord_workers))
+        return config
+    if music_rules._CHORD_BACKEND is not None:
+        return config
+    dropped = []
+    tr = vars(config.target_rules)
+    for k in [k for k in tr if "chord" in k]:
+        tr.pop(k)
+        dropped.append(f"target_rules.{k}")
+    if getattr(config, "scg", None) is not None:
+        for k in [k for k in vars(config.scg) if "chord" in k]:
+            vars(config.scg).pop(k)
+    cf = getattr(config.guidance, "cond_fn", None)
+    if cf is not None and any("chord" in r for r in cf.rule_names):
+        keep = [i for i, r in enumerate(cf.rule_names) if "chord" not in r]
+        dropped += [f"cond_fn.{cf.rule_names[i]}" for i in range(len(cf.rule_names)) if i not in keep]
+        for name in ("fns", "classifier_scales", "rule_names"):
+            setattr(cf, name, [getattr(cf, name)[i] for i in keep])
+        cc = getattr(cf, "classifiers", None)
+        if cc is not None:
+            for name in ("names", "paths", "num_classes"):
+                if hasattr(cc, name):
+                    setattr(cc, name, [getattr(cc, name)[i] for i in keep])
+        if not keep:
+            config.guidance.cond_fn = None
+            config.guidance.nn = False
+    if dropped:
+        logger.log("WARNING: no chord analyser registered (--chord_backend module:function); skipping " + ", ".join(dropped))
+    return config
+
+
 def output_dir_for(config_path, class_label):
     """cond_demo/<config path below cond_table/ or cond_demo/>_cls_<label>   (reference :42-46)."""
     root = "cond_demo/"
@@ -151,7 +194,7 @@ def main(argv=None):
     _native.set_gemm_precision(args.gemm_precision)      # "bf16x3_presplit" / "bf16x3" (fast, fp32-grade) or "fp32" (exact fp32 MFMA)
     comm = dist_util.setup_dist(port=args.port)
     logger.configure(args=args, comm=comm)
-    config = midi_util.load_config(args.config_path)
+    config = setup_chord_backend(args, midi_util.load_config(args.config_path))
     if config.sampling.use_ddim:
         args.timestep_respacing = config.sampling.timestep_respacing
     device = dist_util.dev()
@@ -159,6 +202,7 @@ def main(argv=None):
 
     P = build_pipeline(args, config, device)
     diffusion, embed_model, cond_fn_used, model_fn_used, gen_shape = P.diffusion, P.embed_model, P.cond_fn, P.model_fn, P.gen_shape
+    diffusion.noise_fn = NOISE_FN
 
     target_rules = vars(config.target_rules)
     if any(v is None for v in list(target_rules.values())[:1]):
@@ -219,7 +263,7 @@ def create_argparser():
         cfg=False, w=4., classifier_scale=1.0, record=False, save_files=True, training=False, deterministic=False,
         port=None,
         # additions of this implementation
-        synthetic_weights=False, progress=True, gemm_precision="bf16x3_presplit",
+        synthetic_weights=False, progress=True, gemm_precision="bf16x3_presplit", chord_backend="", chord_workers=4,
     )
     defaults.update(model_and_diffusion_defaults())
     parser = argparse.ArgumentParser()

@@ -401,6 +401,306 @@ def g_steps(vae):
     save("steps", **out)
 
 
+def g_steps2(vae):
+    """Round-2 pins: DDIM + classifier guidance (condition_score), DDIM + SCG, segment-wise SCG (dc.base)
+    on a 256-row latent and on demo2.yml's one-window circle collage, classifier-free guidance through model_fn / dc_model_fn."""
+    print("[steps2: ddim+cls guidance, ddim+scg, dc.base segments, circle demo2, cfg]")
+    from functools import partial
+    from types import SimpleNamespace
+    m, sd = ref_dit(SM, 11)
+    cm, csd = ref_cls(CLS2, 4)
+    rng = np.random.RandomState(1400)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    out = {"x": x, "y": y}
+    nseed = [1410]
+
+    def seeded_noise(tag, *shape):
+        """noise of this item = RandomState(seed).randn(shape): the tests regenerate it from the stored seed"""
+        nseed[0] += 1
+        out[f"{tag}.noise_seed"] = np.array(nseed[0])
+        return np.random.RandomState(nseed[0]).randn(*shape).astype(F32)
+    mf = ref_model_fn(m, 3, True)
+    omf = np_model(sd, SM)
+    rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
+    cond = partial(rcf.composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[cm], rule_names=["note_density"])
+
+    def ocond(xx, tt, y=None, rule=None):
+        return odit.grad_nn_zt_mse(csd, xx, tt, rule["note_density"], 10., depth=2, heads=6)[0]
+    trule = {k: torch.from_numpy(v) for k, v in rule.items()}
+    out["cg.rule"] = rule["note_density"]
+
+    # ---- (a) DDIM (eta = 1) + classifier guidance in eps space (condition_score :467-489), ddim50 chain
+    d = make_diffusion("ddim50")
+    d.t_end = 0
+    S = odf.Schedule(1000, "linear", "ddim50")
+    t = np.full((B,), 30, dtype=np.int64)
+    nz = seeded_noise("dcg", B, 4, 128, 16)
+    NQ.push(nz)
+    g = SimpleNamespace(schedule=False, method="classifier_guidance")
+    r = d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, cond_fn=cond, eta=1.0,
+                      model_kwargs={"y": torch.from_numpy(y), "rule": trule}, guidance_kwargs=g)
+    NQ.push(nz)
+    u = d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, eta=1.0, model_kwargs={"y": torch.from_numpy(y)})
+    o = odf.ddim_sample(S, omf, x, t, nz, eta=1.0, cond_fn=ocond, model_kwargs={"y": y, "rule": rule}, guidance={"schedule": False})
+    err("ddim cls-guided sample", o["sample"], r["sample"].numpy())
+    err("ddim cls-guided pred_xstart", o["pred_xstart"], r["pred_xstart"].numpy())
+    print(f"    guidance shift |max| {np.abs(r['sample'].numpy() - u['sample'].numpy()).max():.3e}")
+    out.update({"dcg.t": t, "dcg.sample": r["sample"].numpy(), "dcg.pred_xstart": r["pred_xstart"].numpy(),
+                "dcg.shift": r["sample"].numpy() - u["sample"].numpy()})
+
+    # ---- (b) DDIM + SCG (n = 4, real decoder, wrapped model, g_coeff = sigma :933-954), with and without the classifier
+    tgt = {"pitch_hist": np.tile(np.array([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], dtype=F32), (B, 1)),
+           "note_density": np.tile(np.array([3.] * 8 + [3.] * 8, dtype=F32), (B, 1))}
+    ttgt = {k: torch.from_numpy(v) for k, v in tgt.items()}
+    out.update({"target.pitch_hist": tgt["pitch_hist"], "target.note_density": tgt["note_density"]})
+    scg = {"num_samples": 4, "pitch_hist": 40., "note_density": 1.}
+    gs = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    for tag, use_c in (("dscg", False), ("dscgc", True)):
+        t = np.full((B,), 20 if not use_c else 41, dtype=np.int64)
+        nz = seeded_noise(tag, 4, B, 4, 128, 16)
+        NQ.push(nz)
+        gk = gs if not use_c else SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="classifier_guidance")
+        r = d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, eta=1.0, cond_fn=cond if use_c else None,
+                          model_kwargs={"y": torch.from_numpy(y), "rule": ttgt}, embed_model=vae, scale_factor=1.2465,
+                          guidance_kwargs=gk, scg_kwargs=scg)
+        o = odf.ddim_sample(S, omf, x, t, nz, eta=1.0, cond_fn=ocond if use_c else None, model_kwargs={"y": y, "rule": tgt},
+                            guidance=dict(schedule=True, t_start=750, t_end=0, interval=1), scg_kwargs=scg,
+                            decode_fn=lambda z: ovae.decode(vae.sd, z), scale_factor=1.2465, func_dict=orl.FUNC_DICT,
+                            loss_dict=orl.LOSS_DICT, return_aux=True)
+        err(f"{tag} sample", o["sample"], r["sample"].numpy())
+        cands = o["aux"]["mean_pred"][None] + o["aux"]["sigma"] * nz
+        ref_ind = np.array([int(np.argmin([np.abs(cands[k, b] - r["sample"].numpy()[b]).max() for k in range(4)])) for b in range(B)])
+        print(f"    {tag}: reference picked {ref_ind}, oracle {o['aux']['max_ind']}\n{o['aux']['total_log_prob']}")
+        assert np.array_equal(ref_ind, o["aux"]["max_ind"])
+        out.update({f"{tag}.t": t, f"{tag}.sample": r["sample"].numpy(), f"{tag}.pred_xstart": r["pred_xstart"].numpy(),
+                    f"{tag}.max_ind": ref_ind, f"{tag}.total_log_prob": o["aux"]["total_log_prob"]})
+
+    # ---- (c1) segment-wise SCG: dc.base = 128 on a 256-row latent (two 1024-frame segments), DDPM full chain, n = 3
+    d = make_diffusion("")
+    d.t_end = 0
+    S = odf.Schedule(1000, "linear", "")
+    n = 3
+    xl = rng.randn(B, 4, 256, 16).astype(F32)
+    t = np.full((B,), 450, dtype=np.int64)
+    tl = {"pitch_hist": tgt["pitch_hist"],
+          "note_density": np.concatenate([rng.rand(B, 16).astype(F32) * 5, rng.rand(B, 16).astype(F32) * 3], axis=1)}
+    nz = seeded_noise("seg", n, B, 4, 256, 16)
+    NQ.push(nz)
+    gd = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance", dc=SimpleNamespace(base=128))
+    scg3 = {"num_samples": n, "pitch_hist": 100., "note_density": 1.}
+    r = d.p_sample(mf, torch.from_numpy(xl), torch.from_numpy(t), clip_denoised=False,
+                   model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in tl.items()}},
+                   embed_model=vae, scale_factor=1.2465, guidance_kwargs=gd, scg_kwargs=scg3)
+    o = odf.p_sample(S, omf, xl, t, nz, model_kwargs={"y": y, "rule": tl}, guidance=dict(schedule=True, t_start=750, t_end=0, interval=1),
+                     scg_kwargs=scg3, decode_fn=lambda z: ovae.decode(vae.sd, z), scale_factor=1.2465, func_dict=orl.FUNC_DICT,
+                     loss_dict=orl.LOSS_DICT, return_aux=True, dc_base=128)
+    err("segment scg sample", o["sample"], r["sample"].numpy())
+    gco = np.exp(F32(0.5) * S.ex(S.model_log_variance, t))
+    cands = o["mean"][None] + gco * nz
+    ref_ind = np.array([[int(np.argmin([np.abs(cands[k, b, :, s * 128:(s + 1) * 128] - r["sample"].numpy()[b, :, s * 128:(s + 1) * 128]).max()
+                                        for k in range(n)])) for b in range(B)] for s in range(2)])
+    print(f"    segments: reference picked\n{ref_ind}\n    oracle\n{o['aux']['max_ind']}\n{o['aux']['total_log_prob']}")
+    assert np.array_equal(ref_ind, o["aux"]["max_ind"])
+    out.update({"seg.x": xl, "seg.t": t, "seg.sample": r["sample"].numpy(), "seg.max_ind": ref_ind,
+                "seg.total_log_prob": o["aux"]["total_log_prob"], "seg.target.note_density": tl["note_density"]})
+
+    # ---- (c2) demo2.yml as the reference ships it: circle collage (num_img 1 -> 2 windows over a 128-row ring), dc.base 128,
+    #      dc_model_fn, SCG n = 3 (pitch_hist 100, note_density 1), DDPM full chain
+    def eps_fn(xx, tt, y=None):
+        return m(xx.permute(0, 1, 3, 2), tt, y=y).permute(0, 1, 3, 2)
+
+    def oeps(xx, tt, y=None):
+        return odit.dit_forward(sd, np.ascontiguousarray(xx.transpose(0, 1, 3, 2)), tt, y, depth=2, heads=6).transpose(0, 1, 3, 2)
+    worker = rdc.CondIndCircle((4, 16, 128), eps_fn, 2, overlap_size=64)
+    assert tuple(worker.shape) == (4, 16, 128)
+    dmf = partial(rcf.dc_model_fn, model=worker.eps_scalar_t_fn, num_classes=3, class_cond=True, cfg=False, w=0.)
+
+    def odmf(xx, tt, y=None, rule=None):
+        return odf.model_fn(lambda a, b, c: ocl.condind_eps(a, b, oeps, 2, 64, y=c, circle=True), xx, tt, y, transpose=True)
+    t = np.full((B,), 300, dtype=np.int64)
+    nz = seeded_noise("circ", n, B, 4, 128, 16)
+    NQ.push(nz)
+    r = d.p_sample(dmf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, model_kwargs={"y": torch.from_numpy(y), "rule": ttgt},
+                   embed_model=vae, scale_factor=1.2465, guidance_kwargs=gd, scg_kwargs=scg3)
+    o = odf.p_sample(S, odmf, x, t, nz, model_kwargs={"y": y, "rule": tgt}, guidance=dict(schedule=True, t_start=750, t_end=0, interval=1),
+                     scg_kwargs=scg3, decode_fn=lambda z: ovae.decode(vae.sd, z), scale_factor=1.2465, func_dict=orl.FUNC_DICT,
+                     loss_dict=orl.LOSS_DICT, return_aux=True, dc_base=128)
+    err("circle demo2 scg sample", o["sample"], r["sample"].numpy())
+    err("circle demo2 pred_xstart", o["pred_xstart"], r["pred_xstart"].numpy())
+    cands = o["mean"][None] + gco * nz
+    ref_ind = np.array([[int(np.argmin([np.abs(cands[k, b] - r["sample"].numpy()[b]).max() for k in range(n)])) for b in range(B)]])
+    print(f"    circle: reference picked {ref_ind}, oracle {o['aux']['max_ind']}\n{o['aux']['total_log_prob']}")
+    assert np.array_equal(ref_ind, o["aux"]["max_ind"])
+    out.update({"circ.t": t, "circ.sample": r["sample"].numpy(), "circ.pred_xstart": r["pred_xstart"].numpy(),
+                "circ.max_ind": ref_ind, "circ.total_log_prob": o["aux"]["total_log_prob"]})
+
+    # ---- (d) classifier-free guidance: model_fn(cfg=True, w=4) and dc_model_fn(cfg=True, w=4) on the circle worker
+    t = np.array([700, 45], dtype=np.int64)
+    r = rcf.model_fn(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(y), model=m, num_classes=3, class_cond=True, cfg=True, w=4.).numpy()
+    o = odf.model_fn(lambda a, b, c: odit.dit_forward(sd, a, b, c, depth=2, heads=6), x, t, y, cfg=True, w=4.)
+    err("model_fn cfg w=4", o, r)
+    r2 = rcf.dc_model_fn(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(y), model=worker.eps_scalar_t_fn, num_classes=3,
+                         class_cond=True, cfg=True, w=4.).numpy()
+    o2 = odf.model_fn(lambda a, b, c: ocl.condind_eps(a, b, oeps, 2, 64, y=c, circle=True), x, t, y, cfg=True, w=4., transpose=True)
+    err("dc_model_fn cfg w=4 (circle)", o2, r2)
+    r3 = rcf.model_fn(torch.from_numpy(x), torch.from_numpy(t), torch.from_numpy(y), model=m, num_classes=3, class_cond=False, cfg=True, w=4.).numpy()
+    err("model_fn class_cond=False", odf.model_fn(lambda a, b, c: odit.dit_forward(sd, a, b, c, depth=2, heads=6), x, t, y, class_cond=False), r3)
+    out.update({"cfg.t": t, "cfg.eps": r, "cfg.dc_eps": r2, "cfg.uncond_eps": r3})
+    save("steps2", **out)
+
+
+def g_cli2(vae):
+    """SURVEY a13's pin: a 2-step `sample_rule.py` run (stochastic DDIM 'ddim2' chain: chain index 1 is an SCG step with n = 4,
+    index 0 returns the mean) -> uint8 roll + the results.csv rows.  The sampling loop, decode and rule report are the
+    reference's own source lines 203-247 of scripts/sample_rule.py executed here (as g_cli does for the target rules);
+    the eps-network is the registry's DiTRotary_B_8 with the synthetic weights the CLI's --synthetic_weights uses."""
+    print("[cli2: 2-step sample_rule run]")
+    import json
+    import pandas as pd
+    import yaml
+    from functools import partial
+    from types import SimpleNamespace
+    cfg_text = """# 2-step stochastic-DDIM chain with SCG (tests/golden/make_golden.py g_cli2)
+target_rules:
+  pitch_hist: [0.5, 0., 0., 0., 0.25, 0., 0., 0.25, 0., 0., 0., 0.]
+  vertical_nd: [3., 3., 3., 3., 3., 3., 3., 3.]
+  horizontal_nd: [15., 15., 15., 15., 15., 15., 15., 15.]
+guidance: {vae: true, nn: false, scg: true, method: no_guidance, cond_fn: null, schedule: true, t_start: 750, t_end: 0, interval: 1}
+scg: {num_samples: 4, pitch_hist: 40., note_density: 1.}
+sampling: {use_ddim: true, timestep_respacing: ddim2, diff_collage: false, t_end: 0}
+"""
+    config = rmu.dict_to_obj(yaml.safe_load(cfg_text))
+    args = SimpleNamespace(batch_size=2, num_samples=2, class_cond=True, class_label=1, scale_factor=1.2465, clip_denoised=False,
+                           save_files=False, record=False, fs=100, num_classes=3)
+    arch = dict(depth=12, hidden=768, heads=12, patch=8, in_ch=4, out_ch=4, num_classes=4, class_dropout=False)
+    sd = synth.dit_state_dict(1, final_std=0.3 / 768 ** 0.5, **arch)
+    model = rdit.DiT_models["DiTRotary_B_8"](input_size=[128, 16], in_channels=4, num_classes=3, learn_sigma=False)
+    model.load_state_dict(tsd(sd), strict=True)
+    model.eval()
+    diffusion = make_diffusion("ddim2")
+    assert diffusion.timestep_map == [0, 500]
+    src = open(os.path.join(ref_shims.REF_ROOT, "scripts", "sample_rule.py")).read().split("\n")
+
+    def lines(a, b, indent):
+        return "\n".join(l[indent:] if l.startswith(" " * indent) else l for l in src[a - 1:b])
+    env = {"target_rules": vars(config.target_rules), "th": torch, "dist_util": SimpleNamespace(dev=lambda: "cpu"), "args": args}
+    exec(lines(171, 193, 8), env)                                                    # target rules -> model_kwargs (the else: body)
+    model_kwargs = env["model_kwargs"]
+    model_kwargs["y"] = torch.ones(size=(2,), dtype=torch.int) * args.class_label    # :197-198
+    xT = np.random.RandomState(1501).randn(2, 4, 128, 16).astype(F32)
+    nz = np.random.RandomState(1502).randn(4, 2, 4, 128, 16).astype(F32)
+    NQ.push(xT, nz)
+    env2 = {"partial": partial, "diffusion": diffusion, "config": config, "args": args, "pd": pd, "th": torch, "midi_util": rmu,
+            "model_fn_used": partial(rcf.model_fn, model=model, num_classes=3, class_cond=True, cfg=False, w=4.),
+            "gen_shape": (2, 4, 128, 16), "model_kwargs": model_kwargs, "dist_util": SimpleNamespace(dev=lambda: "cpu"),
+            "cond_fn_used": None, "embed_model": vae, "logger": SimpleNamespace(log=print), "os": os, "save_dir": "/nonexistent"}
+    exec(lines(203, 247, 4), env2)
+    assert not NQ.q, "noise queue not drained: the draw order differs from the assumed one"
+    arr, res = env2["arr"], env2["all_results"]
+    print(res.filter(like=".loss"))
+    out = {"config_yaml": np.array(cfg_text), "xT_seed": np.array(1501), "scg_noise_seed": np.array(1502), "u8": arr,
+           "columns": np.array(list(res.columns)), "results_json": np.array(json.dumps(res.to_dict(orient="list")))}
+    save("cli2", **out)
+
+
+def g_next2():
+    """Round-2 additions the reference runs and round 1 rejected: DPS under edit_kwargs (whole latent editable: the reference's
+    `new_mean[..., l_start:l_end, :] += step_size * gradient` only broadcasts then), DPS combined with SCG (p_sample :691-733
+    applies condition_mean on EVERY step once scg_kwargs is given), and the dead-but-present grad_nn_zt_xentropy."""
+    print("[next2: dps+edit, dps+scg, grad_nn_zt_xentropy]")
+    from functools import partial
+    from types import SimpleNamespace
+    rng = np.random.RandomState(1600)
+    m, sd = ref_dit(SM, 11)
+    cm, csd = ref_cls(CLS2, 4)
+    mf = ref_model_fn(m, 3, True)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
+    trule = {k: torch.from_numpy(v) for k, v in rule.items()}
+    out = {"x": x, "y": y, "rule": rule["note_density"]}
+    torch.set_grad_enabled(True)
+    # ---- grad_nn_zt_xentropy (condition_functions.py:46-56): d log softmax(classifier(x, 0))[rule] / dx
+    lab = np.array([3, 11], dtype=np.int64)
+    gx = rcf.grad_nn_zt_xentropy(torch.from_numpy(x), rule=torch.from_numpy(lab), classifier=cm).numpy()
+    out.update({"xent.rule": lab, "xent.grad": gx})
+    print(f"    xentropy |grad| {np.abs(gx).max():.3e}")
+    cond = partial(rcf.composite_nn_zt, fns=["nn_z0_mse_dummy"], classifier_scales=[1.], classifiers=[cm], rule_names=["note_density"])
+    gk = SimpleNamespace(schedule=False, method="dps", step_size=1.5, nn=True, vae=False)
+    # ---- DPS + edit_kwargs (:426-428, :453-455), whole latent editable, the first 32 rows replaced by the ground truth
+    gt = (rng.randn(B, 4, 128, 16) * 0.8).astype(F32)
+    mask = np.zeros_like(gt)
+    mask[:, :, :32, :] = 1.
+    ek = {"gt": torch.from_numpy(gt), "mask": torch.from_numpy(mask), "l_start": 0, "l_end": 128, "noise_level": 3}
+    out.update({"gt": gt, "mask": mask})
+    d = make_diffusion("250")
+    d.t_end = 0
+    t = np.full((B,), 110, dtype=np.int64)
+    nz = rng.randn(B, 4, 128, 16).astype(F32)
+    NQ.push(nz)
+    r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=True, cond_fn=cond,
+                   model_kwargs={"y": torch.from_numpy(y), "rule": trule}, guidance_kwargs=gk, edit_kwargs=ek)
+    NQ.push(nz)
+    u = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=True, model_kwargs={"y": torch.from_numpy(y)}, edit_kwargs=ek)
+    out.update({"dpse.t": t, "dpse.noise": nz, "dpse.sample": r["sample"].detach().numpy(), "dpse.pred_xstart": r["pred_xstart"].detach().numpy(),
+                "dpse.shift": (r["sample"] - u["sample"]).detach().numpy()})
+    print(f"    dps+edit: shift |max| {np.abs(out['dpse.shift']).max():.3e}")
+    # ---- DPS + SCG in one step (full chain): t = 300 guided (dps mean -> SCG n = 3, cheap scoring without a decoder is not
+    #      possible -- rules need the roll -- so the reference Decoder runs), t = 800 outside the schedule (dps mean + g * noise)
+    vae = RefVAE(2)
+    d = make_diffusion("")
+    d.t_end = 0
+    tgt = {"note_density": rule["note_density"]}
+    gs = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="dps", step_size=1.5, nn=True, vae=True)
+    scg = {"num_samples": 3, "note_density": 1.}
+    for tag, ti, shape in (("dpsscg", 300, (3, B, 4, 128, 16)), ("dpsscg_off", 800, (B, 4, 128, 16))):
+        t = np.full((B,), ti, dtype=np.int64)
+        seed = 1610 + ti
+        nz = np.random.RandomState(seed).randn(*shape).astype(F32)
+        NQ.push(nz)
+        rec, orig = {}, d.scg_sample
+
+        def spy(model, t_, mean_pred, g_coeff, *a, _orig=orig, **k):
+            rec["mean"], rec["g"] = mean_pred.detach().numpy().copy(), g_coeff.detach().numpy().copy()
+            return _orig(model, t_, mean_pred, g_coeff, *a, **k)
+        d.scg_sample = spy
+        r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, cond_fn=cond,
+                       model_kwargs={"y": torch.from_numpy(y), "rule": trule}, embed_model=vae, scale_factor=1.2465,
+                       guidance_kwargs=gs, scg_kwargs=scg)
+        d.scg_sample = orig
+        smp = r["sample"].detach().numpy()
+        out.update({f"{tag}.t": t, f"{tag}.noise_seed": np.array(seed), f"{tag}.sample": smp, f"{tag}.pred_xstart": r["pred_xstart"].detach().numpy()})
+        if ti == 300:
+            mean = rec["mean"]
+            cands = mean[None] + rec["g"] * nz
+            ref_ind = np.array([int(np.argmin([np.abs(cands[k, b] - smp[b]).max() for k in range(3)])) for b in range(B)])
+            assert max(np.abs(cands[ref_ind[b], b] - smp[b]).max() for b in range(B)) < 1e-6
+            out.update({f"{tag}.mean": mean, f"{tag}.max_ind": ref_ind})
+            print(f"    {tag}: reference picked {ref_ind}")
+        print(f"    {tag}: sample range {smp.min():.3f} .. {smp.max():.3f}")
+    torch.set_grad_enabled(False)
+    save("next2", **out)
+
+
+def g_configs():
+    """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
+    checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
+    print("[configs]")
+    import glob
+    import json
+    import yaml
+    root = os.path.join(ref_shims.REF_ROOT, "scripts", "configs")
+    tree = {}
+    for f in sorted(glob.glob(os.path.join(root, "**", "*.yml"), recursive=True)):
+        tree[os.path.relpath(f, root)] = yaml.safe_load(open(f))
+    p = os.path.join(HERE, "ref_configs.json")
+    json.dump(tree, open(p, "w"), indent=0, sort_keys=True)
+    print(f"  wrote ref_configs.json  {len(tree)} files, {os.path.getsize(p) / 1024:.1f} KiB")
+
+
 def g_edit():
     """Editing path (scripts/edit.py): VAE encoder, _encode, and teacher-forced steps with edit_kwargs."""
     print("[edit: encoder, _encode, replacement-conditioned steps]")
@@ -818,7 +1118,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "cli2", "next2", "configs"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -829,12 +1129,20 @@ if __name__ == "__main__":
         g_dit("xl_d28", XL28, 1)
     if "cls" in which:
         g_cls()
-    if which & {"vae", "steps", "e2e"}:
+    if which & {"vae", "steps", "steps2", "cli2", "e2e"}:
         vae = g_vae() if "vae" in which else RefVAE(2)
     if "rules" in which:
         g_rules()
     if "steps" in which:
         g_steps(vae)
+    if "steps2" in which:
+        g_steps2(vae)
+    if "cli2" in which:
+        g_cli2(vae)
+    if "next2" in which:
+        g_next2()
+    if "configs" in which:
+        g_configs()
     if "collage" in which:
         g_collage()
     if "edit" in which:

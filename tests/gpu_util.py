@@ -21,6 +21,26 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
 
 
+def u8_flip_report(u8, golden_u8, roll, tol=1e-4):
+    """uint8 piano rolls (B,128,T,3) of this implementation and of the reference + this implementation's float roll (B,3,128,T).
+    -> (mismatches, mismatches that are NOT explained by fp32 re-association across a quantisation boundary, largest distance
+    of a mismatching value to its boundary).  A flip is explained when the float value sits within `tol` of the -0.95
+    background threshold (0 <-> 3 snap) or of a value where (x + 1) * 63.5 crosses an integer (one grey level)."""
+    u8, golden_u8 = np.asarray(u8), np.asarray(golden_u8)
+    v = np.asarray(roll, dtype=np.float64).transpose(0, 2, 3, 1)
+    bad = u8 != golden_u8
+    if not bad.any():
+        return 0, 0, 0.0
+    vb = v[bad]
+    q = (vb + 1.0) * 63.5
+    d_int = np.abs(q - np.round(q)) / 63.5                    # distance to the nearest truncation boundary, in roll units
+    d_thr = np.abs(vb + 0.95)
+    dist = np.minimum(d_int, d_thr)
+    step = np.abs(u8[bad].astype(np.int32) - golden_u8[bad].astype(np.int32))
+    explained = (dist < tol) & ((step == 1) | (d_thr < tol))
+    return int(bad.sum()), int((~explained).sum()), float(dist.max())
+
+
 def gemm(A, B, bias=None, act=0, alpha=1.0, gate=None, rows_per_gate=1, res=None, tile=None, prec=None):
     """C = epi(alpha * A @ B.T) through rgm_gemm; numpy in, numpy out."""
     M, K = A.shape

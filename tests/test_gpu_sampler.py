@@ -85,11 +85,15 @@ def test_vae_decoder_matches_reference_and_uint8_roll(precision):
     assert rel(out.cpu().numpy(), g["out"]) < 5e-5
     u8 = decode_sample_for_midi(dev(g["lat"]), embed_model=vae, scale_factor=1.2465, threshold=-0.95)
     assert u8.shape == (1, 128, 256, 3) and u8.dtype == torch.uint8
-    bad = u8.cpu().numpy() != g["u8"]
-    assert bad.mean() < (3e-4 if precision == 'fp32' else 1e-3), bad.sum()          # fp32 re-association across a truncation/threshold boundary (oracle: 5/98304)
     # the integer stage itself is bit-exact: quantise the float roll with the oracle's quantiser
+    from gpu_util import u8_flip_report
     from oracle import vae_np
     roll = _decode(dev(g["lat"]), vae, scale_factor=1.2465)
+    # every entry that differs from the reference's uint8 roll sits on a quantisation boundary (fp32 re-association; the numpy
+    # oracle itself: 5 of 98304), by one grey level or the background snap -- anything else would be a bug
+    n_bad, n_unexplained, dist = u8_flip_report(u8.cpu().numpy(), g["u8"], roll.cpu().numpy(), tol=2e-5)
+    print(f"[decoder {precision}] uint8 mismatches {n_bad} / {g['u8'].size}, max boundary distance {dist:.1e}")
+    assert n_unexplained == 0 and n_bad <= (16 if precision == 'fp32' else 40), (n_bad, n_unexplained, dist)
     assert np.array_equal(vae_np.quantise_roll(roll.cpu().numpy()), u8.cpu().numpy())
     # fused latent path == generic tile path
     lat = dev(g["lat"])
@@ -194,10 +198,20 @@ def test_end_to_end_ddim50_latents_and_uint8_roll(tag, arch, seed, precision):
     lat = d.ddim_sample_loop(_model_fn(m), (2, 4, 128, 16), clip_denoised=False, model_kwargs={"y": dev(g["y"])},
                              device="cuda", eta=1.0)
     assert rel(lat.cpu().numpy(), g["latent"]) < 1e-3
-    u8 = decode_sample_for_midi(lat, embed_model=_vae(2), scale_factor=1.2465, threshold=-0.95).cpu().numpy()
-    bad = u8 != g["u8"]
-    assert bad.mean() < 1e-3, bad.sum()
-    print(f"[{tag} {precision}] latent rel err {rel(lat.cpu().numpy(), g['latent']):.2e}; uint8 mismatches {bad.sum()} / {bad.size}")
+    from gpu_util import u8_flip_report
+    from guided_diffusion.gaussian_diffusion import _decode
+    vae = _vae(2)
+    u8 = decode_sample_for_midi(lat, embed_model=vae, scale_factor=1.2465, threshold=-0.95).cpu().numpy()
+    roll = _decode(lat, vae, scale_factor=1.2465).cpu().numpy()
+    # "integer piano-roll decode bit-exact under fixed seed": the integer stage is (tested above); end to end, the entries that
+    # differ from the reference's roll must ALL sit on a quantisation boundary of the float roll (two fp32 summation orders of
+    # the same 50-step chain disagree there: numpy oracle vs torch reference ~70 of 786432) -- by one grey level or the
+    # background snap, within the float agreement of the two rolls.  Count bound = 2x the measured figures of round 1.
+    n_bad, n_unexplained, dist = u8_flip_report(u8, g["u8"], roll, tol=1e-4)
+    print(f"[{tag} {precision}] latent rel err {rel(lat.cpu().numpy(), g['latent']):.2e}; uint8 mismatches {n_bad} / {u8.size} "
+          f"({n_unexplained} not boundary-adjacent, max boundary distance {dist:.1e})")
+    assert n_unexplained == 0, (n_bad, n_unexplained, dist)
+    assert n_bad / u8.size <= (1.5e-4 if precision == "fp32" else 7e-4), n_bad
 
 
 def test_sharded_scg_rank_sees_same_winner_and_rebuilds_it(monkeypatch):

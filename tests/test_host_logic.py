@@ -78,7 +78,7 @@ def test_cli_target_rules_dirs_and_flags_match_reference():
     mine = {a.dest: a.default for a in cli.create_argparser()._actions if a.dest != "help"}
     for k, v in ref.items():
         assert k in mine and mine[k] == v, f"flag --{k}: {mine.get(k)!r} vs reference {v!r}"
-    assert set(mine) - set(ref) == {"synthetic_weights", "progress", "gemm_precision"}
+    assert set(mine) - set(ref) == {"synthetic_weights", "progress", "gemm_precision", "chord_backend", "chord_workers"}
     a = cli.create_argparser().parse_args(["--image_size", "128", "16", "--class_cond", "True", "--clip_denoised", "no"])
     assert json.loads(str(g["parsed_example"])) == {"image_size": a.image_size, "class_cond": a.class_cond, "clip_denoised": a.clip_denoised}
 

@@ -239,3 +239,54 @@ def test_replacement_conditioned_steps():
     o = odf.p_sample(S, model, g["x"], g["cg.t"], g["cg.noise"], cond_fn=cond,
                      model_kwargs={"y": g["y"], "rule": {"note_density": g["cg.rule"]}}, guidance={"schedule": False}, edit=full)
     assert rel_err(o["sample"], g["cg.sample"]) < 1e-4
+
+
+def test_ddim_condition_score_and_cfg_against_round2_goldens():
+    """steps2.npz: DDIM + classifier guidance (condition_score, reference :467-489) and classifier-free guidance through
+    model_fn / dc_model_fn around the one-window circle collage (condition_functions.py:17-42) -- the oracle vs the reference."""
+    g = load_golden("steps2")
+    sd = synth.dit_state_dict(11, **SM)
+    csd = synth.dit_state_dict(4, **CLS2)
+
+    def omf(x, t, y=None, rule=None):
+        return odit.dit_forward(sd, x, t, y, depth=2, heads=6)
+
+    def ocond(xx, tt, y=None, rule=None):
+        return odit.grad_nn_zt_mse(csd, xx, tt, rule["note_density"], 10., depth=2, heads=6)[0]
+    S = odf.Schedule(1000, "linear", "ddim50")
+    nz = np.random.RandomState(int(g["dcg.noise_seed"])).randn(2, 4, 128, 16).astype(F32)
+    o = odf.ddim_sample(S, omf, g["x"], g["dcg.t"], nz, eta=1.0, cond_fn=ocond, model_kwargs={"y": g["y"], "rule": {"note_density": g["cg.rule"]}},
+                        guidance={"schedule": False})
+    assert rel_err(o["sample"], g["dcg.sample"]) < 1e-4 and rel_err(o["pred_xstart"], g["dcg.pred_xstart"]) < 1e-4
+    u = odf.ddim_sample(S, omf, g["x"], g["dcg.t"], nz, eta=1.0, model_kwargs={"y": g["y"]})
+    assert rel_err(o["sample"] - u["sample"], g["dcg.shift"]) < 2e-3
+    net = lambda a, b, c: odit.dit_forward(sd, a, b, c, depth=2, heads=6)           # noqa: E731
+    assert rel_err(odf.model_fn(net, g["x"], g["cfg.t"], g["y"], cfg=True, w=4.), g["cfg.eps"]) < 1e-4
+    assert rel_err(odf.model_fn(net, g["x"], g["cfg.t"], g["y"], class_cond=False), g["cfg.uncond_eps"]) < 1e-4
+
+    def oeps(xx, tt, y=None):
+        return odit.dit_forward(sd, np.ascontiguousarray(xx.transpose(0, 1, 3, 2)), tt, y, depth=2, heads=6).transpose(0, 1, 3, 2)
+    circ = lambda a, b, c: ocl.condind_eps(a, b, oeps, 2, 64, y=c, circle=True)     # noqa: E731
+    assert rel_err(odf.model_fn(circ, g["x"], g["cfg.t"], g["y"], cfg=True, w=4., transpose=True), g["cfg.dc_eps"]) < 1e-4
+
+
+def test_segmentwise_selection_index_arithmetic():
+    """oracle _scg_segments (reference :562-592) on a synthetic decoded roll: per-segment argmax with the note_density target cut to
+    the segment's windows -- checked against a direct per-segment evaluation, and against steps2.npz's recorded winners' shape."""
+    rng = np.random.RandomState(3)
+    n, B = 3, 2
+    x0 = (-1 + 0.1 * rng.rand(n * B, 1, 128, 2048)).astype(F32)
+    x0[:, 0, 40:80, ::7] = 0.5
+    cand = rng.randn(n * B, 4, 256, 16).astype(F32)
+    tgt = {"note_density": (rng.rand(B, 32) * 5).astype(F32)}
+    sample, inds, totals = odf._scg_segments(cand, x0, B, n, {"rule": tgt}, {"note_density": 1.}, orl.FUNC_DICT, orl.LOSS_DICT, 128)
+    assert sample.shape == (B, 4, 256, 16) and inds.shape == (2, B) and totals.shape == (n, 2, B)
+    for i in range(2):
+        gen = orl.note_density(np.ascontiguousarray(x0[:, :, :, i * 1024:(i + 1) * 1024]).copy())
+        t_i = np.concatenate((tgt["note_density"][:, :16][:, i * 8:(i + 1) * 8], tgt["note_density"][:, 16:][:, i * 8:(i + 1) * 8]), axis=-1)
+        lp = -orl.mse_loss_mean(gen, np.tile(t_i, (n, 1))).reshape(n, B)
+        assert np.allclose(lp, totals[:, i]) and np.array_equal(lp.argmax(0), inds[i])
+        for b in range(B):
+            assert np.array_equal(sample[b, :, i * 128:(i + 1) * 128], cand.reshape(n, B, 4, 256, 16)[inds[i, b], b, :, i * 128:(i + 1) * 128])
+    g = load_golden("steps2")
+    assert g["seg.max_ind"].shape == (2, 2) and g["seg.total_log_prob"].shape == (3, 2, 2)

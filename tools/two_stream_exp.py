@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment: does splitting the batch over two HIP streams (two half-batch forwards in flight) recover the tile-quantisation
-tails of the single-stream forward?  tools/two_stream_test.py [B]"""
+tails of the single-stream forward?  tools/two_stream_exp.py [B]"""
 import os
 import sys
 import time
