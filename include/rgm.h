@@ -116,6 +116,12 @@ int rgm_gemm_split(const float* A_split, const float* B_split, float* C, int M, 
 int rgm_split_rows_ld(const float* x, int ld_in, float* out, int ld_out, int64_t rows, int K, void* stream);
 int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
                       const float* bias, int act, int tile, int out_split, void* stream);
+/* Workspace-backed decompositions of the pre-split GEMM (csrc/gemm4.hip stream-K, csrc/gemm2.hip deterministic split-K): the
+ * scratch is caller memory like every other workspace.  rgm_gemm_streamk_workspace_bytes() bytes, 16-byte aligned; tile 0 lets
+ * the heuristic choose, 47 forces the persistent stream-K kernel.  The entry zeroes the scratch's flag words on `stream`. */
+size_t rgm_gemm_streamk_workspace_bytes(void);
+int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias, int act,
+                      int tile, int out_split, void* ws, size_t ws_bytes, void* stream);
 /* Same as rgm_gemm without gate/residual but with an explicit tile shape in the low 4 bits (1: 128x128,
  * 2: 128x64, 3: 64x64, 4: 32x128, 0: auto) and an explicit precision in bits 4.. (0: library default,
  * 1: fp32, 2: bf16x3) -- used by the parity tests and tile-selection experiments. */

@@ -59,6 +59,8 @@ struct rgm_dit {
   size_t ada_rows = 0;       // (6*depth + 2 or 0) * D
   float* arena_t = nullptr;  // eps-network only, allocated by rgm_dit_enable_grad: W^T copies for the input-gradient (DPS)
   size_t arena_t_floats = 0;
+  void* sk_ws = nullptr;     // scratch of the call in progress (points into the caller's workspace; see GemmParams::sk_ws)
+  size_t sk_ws_bytes = 0;
 
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
   float* sp(const Slot& sl) const { return (sl.in_t ? arena_t : arena) + sl.off; }
@@ -340,6 +342,8 @@ struct Plan {
   int N, H, T0, T, M0, M;
   size_t L;
   float *tok_in, *h1, *x, *xm, *qkv, *ao, *hid, *temb, *c1, *c, *cs, *mod, *tok_out, *pool, *pooln, *z1;
+  char* sk;          // stream-K / split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
+  size_t sk_bytes;
   size_t bytes;
 };
 
@@ -372,6 +376,8 @@ Plan make_plan(const rgm_dit* h, int N, int H, void* ws, size_t cap) {
   p.pool = w.take((size_t)N * groups * D);
   p.pooln = w.take((size_t)N * groups * D);
   p.z1 = w.take((size_t)N * groups * (D / 4));
+  p.sk_bytes = gemm2_scratch_bytes(p.M, 4 * (int)D);
+  p.sk = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
   p.bytes = w.off;
   return p;
 }
@@ -425,9 +431,11 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     g.tile = tile;
     g.A = A; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
     g.M = p.M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
+    g.sk_ws = p.sk; g.sk_ws_bytes = p.sk_bytes;
     if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
     return gemm2_launch(g, s);
   };
+  if (v2) RGM_CHECK_HIP(hipMemsetAsync(p.sk, 0, GEMM_SK_FLAG_BYTES, s));   // stream-K flag words: zero once per call, the kernels hand them back
   static const int dit_exp = RGM_EXP_ENV("RGM_DIT_EXP");   // timing experiments (common.h): 1 = fc1 without GELU/split, 2 = block-0 weights everywhere
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
@@ -553,6 +561,8 @@ struct GPlan {
   float *xs, *x1s, *qkvs, *aos, *pres, *lses;   // per-block saves (xs has depth+1 entries)
   float *xm, *hid, *dx, *dx1, *t1, *dbig, *dqkv, *dsmall;
   float *pool, *pooln, *z1pre, *z1, *logits, *dl, *dz1, *dpooln, *dpool, *dz, *dtin;
+  char* sk;          // stream-K / split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
+  size_t sk_bytes;
   size_t bytes;
 };
 
@@ -596,6 +606,8 @@ GPlan gplan(const rgm_dit* h, int N, int H, void* ws) {
   p.dz1 = w.take(R * (D / 4)); p.dpooln = w.take(R * D); p.dpool = w.take(R * D);
   p.dz = w.take((size_t)p.M0 * 256);
   p.dtin = w.take((size_t)p.M0 * c.in_ch * c.patch);
+  p.sk_bytes = gemm2_scratch_bytes(p.M, 4 * (int)D);
+  p.sk = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
   p.bytes = w.off;
   return p;
 }
@@ -628,6 +640,7 @@ int lin_split(rgm_dit* h, const float* A_split, const std::string& wkey, const f
   GemmParams g;
   g.A = A_split; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
   g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
+  g.sk_ws = h->sk_ws; g.sk_ws_bytes = h->sk_ws_bytes;
   if (gate) { g.gate = gate; g.gate_ld = gate_ld; g.rows_per_gate = rows_per_gate; g.res = res; g.ldres = N; }
   return gemm2_launch(g, s);
 }
@@ -667,6 +680,9 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
   RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, N, L, D, 0, s));
   const size_t lse_sz = (size_t)N * c.heads * T;
   const bool v2 = rgm_get_gemm_precision() == 2;
+  h->sk_ws = p.sk;
+  h->sk_ws_bytes = p.sk_bytes;
+  if (v2) RGM_CHECK_HIP(hipMemsetAsync(p.sk, 0, GEMM_SK_FLAG_BYTES, s));   // stream-K flag words (see run_backbone)
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string(i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;

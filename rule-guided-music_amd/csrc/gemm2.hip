@@ -20,7 +20,6 @@
 // Out-of-range rows (M / N tails, conv zero padding) read a zero page, so the kernel has no divergent loads.
 #include <stdlib.h>
 #include <stdint.h>
-#include <map>
 #include <vector>
 #include "common.h"
 
@@ -851,15 +850,9 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, GemmParams p, 
   }
 }
 
-// partial sums: one buffer per stream (launches on different streams may overlap), grown on demand (rare: hipMalloc synchronises)
-struct SplitKBuf {
-  float* p = nullptr;
-  size_t cap = 0;
-};
-static std::map<hipStream_t, SplitKBuf> g_splitk;
-
 // number of K slices for a dense, unbatched GEMM whose 128x64 grid leaves most of the chip idle; 1 = do not split
 static int splitk_factor(const GemmParams& p) {
+  if (!p.sk_ws) return 1;                        // the partial sums live in caller-provided scratch (include/rgm.h conventions)
   if (p.aload || p.batch != 1 || p.tile != 0 || p.act >= 3 || (p.N & 3) || (p.ldc & 3) || (p.ldres & 3) || (p.gate_ld & 3)) return 1;
   if ((((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) != 0) return 1;
   const long long t64 = (long long)cdiv(p.M, 128) * cdiv(p.N, 64);
@@ -889,31 +882,24 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   const int S = (p.stats ? 1 : splitk_factor(p));
   if (S > 1) {
     const size_t need = (size_t)S * p.M * p.N * sizeof(float);
-    SplitKBuf& sk = g_splitk[s];
-    if (need > sk.cap) {
-      if (sk.p) {
-        RGM_CHECK_HIP(hipStreamSynchronize(s));      // an earlier launch on this stream may still read the old buffer
-        RGM_CHECK_HIP(hipFree(sk.p));
-      }
-      sk.p = nullptr;
-      sk.cap = 0;
-      RGM_CHECK_HIP(hipMalloc(&sk.p, need));
-      sk.cap = need;
-    }
+    RGM_REQUIRE(p.sk_ws_bytes >= GEMM_SK_FLAG_BYTES + need, "gemm2: split-K scratch %zu bytes < %zu", p.sk_ws_bytes, GEMM_SK_FLAG_BYTES + need);
+    float* partial = reinterpret_cast<float*>(static_cast<char*>(p.sk_ws) + GEMM_SK_FLAG_BYTES);
     GemmParams q = p;                     // the K slices as a batch: raw partial sums, no epilogue
     q.K = p.K / S;
     q.batch = S;
     q.sA = q.K; q.sB = q.K;
-    q.C = sk.p; q.ldc = p.N; q.sC = (long long)p.M * p.N;
+    q.C = partial; q.ldc = p.N; q.sC = (long long)p.M * p.N;
+    q.sk_ws = nullptr; q.sk_ws_bytes = 0;
     q.bias = nullptr; q.act = 0; q.alpha = 1.0f; q.gate = nullptr; q.res = nullptr; q.out_split = 0;
     q.tile = 44;
     RGM_TRY(gemm2_launch(q, s));
     const long long total4 = (long long)p.M * (p.N >> 2);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)sk.p, p, S);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)partial, p, S);
     RGM_LAUNCH_CHECK();
     return RGM_OK;
   }
   int tile = p.tile;
+  if (tile == 0 && gemm4_eligible(p)) tile = 47;   // >= 1.5 CU-rounds of 128x128 tiles: equal K-tile ranges per workgroup (gemm4.hip)
   if (tile == 0) {
     // tools/gemm_sweep.py on MI355X: cross-iteration pipeline (PIPE 3) at 128x128 (2 workgroups per CU) once the grid
     // fills at least one round of the chip, at 128x64 (3 per CU) below that; grids that do not even fill the CUs
@@ -943,6 +929,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 45: return launch2<256, 128, 4, 2, 2, 3>(p, s, 45);   // 96 KB, 8 waves
     case 46: return launch2<64, 64, 2, 2, 3, 3>(p, s, 46);     // 48 KB: 3 per CU
     // loader/consumer split (PIPE == 4): NW MFMA waves + NW DMA waves, 3-stage ring
+    case 47: return gemm4_launch(p, s);                        // persistent stream-K 128x128 (gemm4.hip)
     case 51: return launch2<128, 128, 2, 2, 3, 4>(p, s, 51);   // 96 KB: 1 per CU
     case 52: return launch2<128, 64, 2, 2, 3, 4>(p, s, 52);    // 72 KB: 2 per CU
     // persistent loader/consumer kernel (gemm3.hip)
@@ -979,6 +966,14 @@ int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_
   hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, out, rows, K, ld_in, ld_out);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
+}
+
+size_t gemm2_scratch_bytes(int M, int N) {
+  // split-K: up to 8 slices of a grid below 384 128x64 tiles (splitk_factor); stream-K: one slot per resident workgroup
+  const long long rows = (long long)cdiv(384, cdiv(N, 64)) * 128;
+  const size_t splitk = (size_t)8 * (size_t)(M < rows ? M : rows) * N * sizeof(float);
+  const size_t streamk = gemm4_workspace_bytes() - GEMM_SK_FLAG_BYTES;
+  return GEMM_SK_FLAG_BYTES + (splitk > streamk ? splitk : streamk);
 }
 
 void gemm2_prof(bool on) { g2_prof_on = on; }

@@ -477,35 +477,14 @@ def g_steps2(vae):
         out.update({f"{tag}.t": t, f"{tag}.sample": r["sample"].numpy(), f"{tag}.pred_xstart": r["pred_xstart"].numpy(),
                     f"{tag}.max_ind": ref_ind, f"{tag}.total_log_prob": o["aux"]["total_log_prob"]})
 
-    # ---- (c1) segment-wise SCG: dc.base = 128 on a 256-row latent (two 1024-frame segments), DDPM full chain, n = 3
     d = make_diffusion("")
     d.t_end = 0
     S = odf.Schedule(1000, "linear", "")
     n = 3
-    xl = rng.randn(B, 4, 256, 16).astype(F32)
     t = np.full((B,), 450, dtype=np.int64)
-    tl = {"pitch_hist": tgt["pitch_hist"],
-          "note_density": np.concatenate([rng.rand(B, 16).astype(F32) * 5, rng.rand(B, 16).astype(F32) * 3], axis=1)}
-    nz = seeded_noise("seg", n, B, 4, 256, 16)
-    NQ.push(nz)
     gd = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance", dc=SimpleNamespace(base=128))
     scg3 = {"num_samples": n, "pitch_hist": 100., "note_density": 1.}
-    r = d.p_sample(mf, torch.from_numpy(xl), torch.from_numpy(t), clip_denoised=False,
-                   model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in tl.items()}},
-                   embed_model=vae, scale_factor=1.2465, guidance_kwargs=gd, scg_kwargs=scg3)
-    o = odf.p_sample(S, omf, xl, t, nz, model_kwargs={"y": y, "rule": tl}, guidance=dict(schedule=True, t_start=750, t_end=0, interval=1),
-                     scg_kwargs=scg3, decode_fn=lambda z: ovae.decode(vae.sd, z), scale_factor=1.2465, func_dict=orl.FUNC_DICT,
-                     loss_dict=orl.LOSS_DICT, return_aux=True, dc_base=128)
-    err("segment scg sample", o["sample"], r["sample"].numpy())
     gco = np.exp(F32(0.5) * S.ex(S.model_log_variance, t))
-    cands = o["mean"][None] + gco * nz
-    ref_ind = np.array([[int(np.argmin([np.abs(cands[k, b, :, s * 128:(s + 1) * 128] - r["sample"].numpy()[b, :, s * 128:(s + 1) * 128]).max()
-                                        for k in range(n)])) for b in range(B)] for s in range(2)])
-    print(f"    segments: reference picked\n{ref_ind}\n    oracle\n{o['aux']['max_ind']}\n{o['aux']['total_log_prob']}")
-    assert np.array_equal(ref_ind, o["aux"]["max_ind"])
-    out.update({"seg.x": xl, "seg.t": t, "seg.sample": r["sample"].numpy(), "seg.max_ind": ref_ind,
-                "seg.total_log_prob": o["aux"]["total_log_prob"], "seg.target.note_density": tl["note_density"]})
-
     # ---- (c2) demo2.yml as the reference ships it: circle collage (num_img 1 -> 2 windows over a 128-row ring), dc.base 128,
     #      dc_model_fn, SCG n = 3 (pitch_hist 100, note_density 1), DDPM full chain
     def eps_fn(xx, tt, y=None):
@@ -549,6 +528,60 @@ def g_steps2(vae):
     err("model_fn class_cond=False", odf.model_fn(lambda a, b, c: odit.dit_forward(sd, a, b, c, depth=2, heads=6), x, t, y, class_cond=False), r3)
     out.update({"cfg.t": t, "cfg.eps": r, "cfg.dc_eps": r2, "cfg.uncond_eps": r3})
     save("steps2", **out)
+
+
+def g_seg(vae):
+    """Segment-wise SCG (reference :562-592) the way the reference reaches a long latent: a linear DiffCollage of 3 windows
+    (CondIndSimple, overlap 64 -> 256 latent rows = 2048 frames) behind dc_model_fn, guidance.dc.base = 128 -> two 1024-frame
+    segments with their own argmax; note_density targets cut per segment (rule_base = 8), DDPM full chain, n = 3."""
+    print("[seg: dc.base segments on a 3-window linear collage]")
+    from functools import partial
+    from types import SimpleNamespace
+    m, sd = ref_dit(SM, 11)
+    rng = np.random.RandomState(1450)
+    B, n = 2, 3
+    y = np.array([1, 2], dtype=np.int64)
+    xl = rng.randn(B, 4, 256, 16).astype(F32)
+    t = np.full((B,), 450, dtype=np.int64)
+    tl = {"pitch_hist": np.tile(np.array([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], dtype=F32), (B, 1)),
+          "note_density": np.concatenate([rng.rand(B, 16).astype(F32) * 5, rng.rand(B, 16).astype(F32) * 3], axis=1)}
+
+    def eps_fn(xx, tt, y=None):
+        return m(xx.permute(0, 1, 3, 2), tt, y=y).permute(0, 1, 3, 2)
+
+    def oeps(xx, tt, y=None):
+        return odit.dit_forward(sd, np.ascontiguousarray(xx.transpose(0, 1, 3, 2)), tt, y, depth=2, heads=6).transpose(0, 1, 3, 2)
+    worker = rdc.CondIndSimple((4, 16, 128), eps_fn, 3, overlap_size=64)
+    assert tuple(worker.shape) == (4, 16, 256)
+    dmf = partial(rcf.dc_model_fn, model=worker.eps_scalar_t_fn, num_classes=3, class_cond=True, cfg=False, w=0.)
+
+    def odmf(xx, tt, y=None, rule=None):
+        return odf.model_fn(lambda a, b, c: ocl.condind_eps(a, b, oeps, 3, 64, y=c), xx, tt, y, transpose=True)
+    d = make_diffusion("")
+    d.t_end = 0
+    S = odf.Schedule(1000, "linear", "")
+    seed = 1451
+    nz = np.random.RandomState(seed).randn(n, B, 4, 256, 16).astype(F32)
+    NQ.push(nz)
+    gd = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance", dc=SimpleNamespace(base=128))
+    scg3 = {"num_samples": n, "pitch_hist": 100., "note_density": 1.}
+    r = d.p_sample(dmf, torch.from_numpy(xl), torch.from_numpy(t), clip_denoised=False,
+                   model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in tl.items()}},
+                   embed_model=vae, scale_factor=1.2465, guidance_kwargs=gd, scg_kwargs=scg3)
+    o = odf.p_sample(S, odmf, xl, t, nz, model_kwargs={"y": y, "rule": tl}, guidance=dict(schedule=True, t_start=750, t_end=0, interval=1),
+                     scg_kwargs=scg3, decode_fn=lambda z: ovae.decode(vae.sd, z), scale_factor=1.2465, func_dict=orl.FUNC_DICT,
+                     loss_dict=orl.LOSS_DICT, return_aux=True, dc_base=128)
+    err("segment scg sample", o["sample"], r["sample"].numpy())
+    err("segment scg pred_xstart", o["pred_xstart"], r["pred_xstart"].numpy())
+    gco = np.exp(F32(0.5) * S.ex(S.model_log_variance, t))
+    cands = o["mean"][None] + gco * nz
+    smp = r["sample"].numpy()
+    ref_ind = np.array([[int(np.argmin([np.abs(cands[k, b, :, s * 128:(s + 1) * 128] - smp[b, :, s * 128:(s + 1) * 128]).max()
+                                        for k in range(n)])) for b in range(B)] for s in range(2)])
+    print(f"    segments: reference picked\n{ref_ind}\n    oracle\n{o['aux']['max_ind']}\n{o['aux']['total_log_prob']}")
+    assert np.array_equal(ref_ind, o["aux"]["max_ind"])
+    save("seg", x=xl, y=y, t=t, noise_seed=np.array(seed), sample=smp, pred_xstart=r["pred_xstart"].numpy(), max_ind=ref_ind,
+         total_log_prob=o["aux"]["total_log_prob"], **{"target.pitch_hist": tl["pitch_hist"], "target.note_density": tl["note_density"]})
 
 
 def g_cli2(vae):
@@ -1118,7 +1151,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "cli2", "next2", "configs"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "configs"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1129,7 +1162,7 @@ if __name__ == "__main__":
         g_dit("xl_d28", XL28, 1)
     if "cls" in which:
         g_cls()
-    if which & {"vae", "steps", "steps2", "cli2", "e2e"}:
+    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e"}:
         vae = g_vae() if "vae" in which else RefVAE(2)
     if "rules" in which:
         g_rules()
@@ -1137,6 +1170,8 @@ if __name__ == "__main__":
         g_steps(vae)
     if "steps2" in which:
         g_steps2(vae)
+    if "seg" in which:
+        g_seg(vae)
     if "cli2" in which:
         g_cli2(vae)
     if "next2" in which:

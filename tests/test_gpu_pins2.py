@@ -91,22 +91,32 @@ def test_ddim_scg_step_selects_the_reference_candidates(tag, precision):
 
 
 def test_segmentwise_scg_picks_the_reference_winner_per_segment(precision):
-    """a8, guidance.dc.base = 128 on a 256-row latent: two 1024-frame segments, each with its own argmax; note_density targets
-    cut to the segment's windows (rule_base = 8), pitch_hist whole (reference :562-592)."""
+    """a8, guidance.dc.base = 128 on a 256-row latent reached the reference's way (a 3-window linear DiffCollage behind
+    dc_model_fn): two 1024-frame segments, each with its own argmax; note_density targets cut to the segment's windows
+    (rule_base = 8), pitch_hist whole (reference :562-592)."""
+    import diff_collage as dc
     from gpu_util import dev, rel
-    g = load_golden("steps2")
+    from guided_diffusion.condition_functions import dc_model_fn
+    g = load_golden("seg")
     m, vae = _dit(SM, 11), _vae(2)
+
+    def eps_fn(x, t, y=None):
+        return m(x.permute(0, 1, 3, 2).contiguous(), t, y=y).permute(0, 1, 3, 2)
+    worker = dc.CondIndSimple((4, 16, 128), eps_fn, 3, overlap_size=64)
+    assert tuple(worker.shape) == (4, 16, 256)
+    mf = partial(dc_model_fn, model=worker.eps_scalar_t_fn, num_classes=3, class_cond=True, cfg=False, w=0.)
     d = _diffusion("")
     d.t_end = 0
-    _inject(d, _noise(g, "seg", 3, 2, 4, 256, 16))
+    _inject(d, np.random.RandomState(int(g["noise_seed"])).randn(3, 2, 4, 256, 16).astype(F32))
     guid = SimpleNamespace(method="no_guidance", dc=SimpleNamespace(base=128), **SCHED)
-    out = d.p_sample(_model_fn(m), dev(g["seg.x"]), dev(g["seg.t"]), clip_denoised=False,
-                     model_kwargs={"y": dev(g["y"]), "rule": _targets(g, "seg.target.note_density")}, embed_model=vae,
-                     scale_factor=1.2465, guidance_kwargs=guid, scg_kwargs={"num_samples": 3, "pitch_hist": 100., "note_density": 1.})
-    assert d.last_scg["max_ind"].shape == (2, 2) and len(set(g["seg.max_ind"].reshape(-1).tolist())) > 1
-    assert np.array_equal(d.last_scg["max_ind"].cpu().numpy(), g["seg.max_ind"])
-    assert rel(d.last_scg["total_log_prob"].cpu().numpy(), g["seg.total_log_prob"]) < 1e-4
-    assert rel(out["sample"].cpu().numpy(), g["seg.sample"]) < 2e-4
+    out = d.p_sample(mf, dev(g["x"]), dev(g["t"]), clip_denoised=False, model_kwargs={"y": dev(g["y"]), "rule": _targets(g)},
+                     embed_model=vae, scale_factor=1.2465, guidance_kwargs=guid,
+                     scg_kwargs={"num_samples": 3, "pitch_hist": 100., "note_density": 1.})
+    assert d.last_scg["max_ind"].shape == (2, 2)
+    assert np.array_equal(d.last_scg["max_ind"].cpu().numpy(), g["max_ind"])
+    assert rel(d.last_scg["total_log_prob"].cpu().numpy(), g["total_log_prob"]) < 1e-4
+    assert rel(out["pred_xstart"].cpu().numpy(), g["pred_xstart"]) < 2e-4
+    assert rel(out["sample"].cpu().numpy(), g["sample"]) < 2e-4
 
 
 def _circle_worker(m):
