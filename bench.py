@@ -4,18 +4,30 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no torchrun environment re-executes itself through torch.distributed.run with N
+ranks on 127.0.0.1 (and fails loudly when the box has fewer than N devices); `n_gpus` in the JSON is the RCCL world size
+that actually ran.
+
 Metric (BASELINE.json): denoising steps/sec, whole node, DiTRotary_XL_8 on 4x128x16 latents.
-Workload at N=1 = BASELINE config[1] ("C2"): unconditional DDIM-50 (eta=1) on a batch of 16 latents, one
-"step" = one ddim_sample call over that batch (eps-network forward + fused step update + Philox noise).
-For N>1 every rank runs the same batch-16 chain on its own GPU (the path shards over samples; no data-path
-collective), scaling = weak, value = N*K / max-over-ranks time.  Other workloads (--workload scg) time the
-SCG branch-and-select step (config[3] shape) with the RCCL log-prob all-gather.
+Headline workload = BASELINE config[1] ("C2"): unconditional DDIM-50 (eta=1) on a batch of 16 latents per GPU, one "step" =
+one ddim_sample call over that batch (eps-network forward + fused step update + Philox noise).  W untimed warm-up steps,
+then three timed regions of exactly K steps each, each bracketed by barrier + device synchronise, MAX over ranks per
+region; `value` / `ms_per_step` are the MEDIAN region (all three are listed in config.repeats_ms_per_step).  For N > 1 every
+rank runs its own batch-16 chain (the path shards over samples; no data-path collective): scaling = weak.
 
 One JSON line on stdout (rank 0) per the driver contract, plus
-  roofline     : the dominant kernel (fp32-MFMA GEMM, 128x128 tile) -- algorithmic 2MNK FLOPs of its launches
-                 divided by their HIP-event durations measured live on the launch stream (separate short pass
-                 with rgm_prof_enable, same workload), against the 157.3 TFLOP/s f32 matrix peak;
-  cpu_baseline : the numpy oracle (oracle/, kind "port") timed on this box's host cores on a bounded sample.
+  roofline     : the dominant kernel of the headline run (pre-split bf16x3 GEMM) -- algorithmic 2MNK FLOPs of its launches
+                 divided by their HIP-event durations measured live on the launch stream (separate 2-step pass with
+                 rgm_prof_enable, same workload), against 2500 / 3 TFLOP/s (dense bf16 MFMA peak, 3 MFMAs per product);
+  fp32_exact   : the same C2 step in exact-fp32 MFMA arithmetic (v_mfma_f32_32x32x2_f32): steps/s, ms/step and its dominant
+                 kernel against the 157.3 TFLOP/s f32 matrix peak;
+  scg          : the north star's sharded step -- BASELINE config[3] shape, B = 4, n = 16 candidates, DiT-XL + KL-VAE decode +
+                 2 rules -- STRONG scaling over the N ranks (candidates partitioned, one RCCL all-gather of the (n, B)
+                 log-probabilities per step): ms/step, the all-gather's share, and whether every rank picked the same winners;
+  config.uint8_flips : the 50-step B = 2 XL-28 golden chain of tests/golden (reference-generated): entries of the decoded
+                 uint8 roll that differ from the reference's, and how many of them are NOT on a quantisation boundary;
+  cpu_baseline : BASELINE config[0] ("C1": the same DDIM-50 chain at batch 2) on this box's host cores with the torch-CPU
+                 restatement oracle/dit_torch.py (kind "port": the reference itself cannot travel), median of 3 steps.
 """
 import argparse
 import ctypes as C
@@ -246,6 +258,8 @@ def roofline_pass(work, steps=2):
           43: (1, 2, 3), 44: (2, 2, 3), 45: (5, 2, 3), 46: (3, 3, 3), 51: (1, 3, 4), 52: (2, 3, 4)}
 
     def kname(k):
+        if k == 47:
+            return "gemm4_kernel"                                  # persistent stream-K 128x128 (csrc/gemm4.hip)
         if k < 40:
             return f"gemm_kernel<{tiles[k % 10]},{(k // 10) % 2},{k // 20}>"
         t = k - 40
@@ -278,34 +292,137 @@ def roofline_pass(work, steps=2):
             "all_gemm_tflops": round(sum(v["flops"] for v in rows.values()) / (all_ms * 1e-3) / 1e12, 2)}
 
 
-def cpu_baseline(work, batch):
-    """The numpy oracle (a port; the reference itself cannot travel) on the host cores: DDIM steps of the same
-    chain on a bounded sample."""
-    from oracle import diffusion_np as odf, dit_np as odit
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [os.cpu_count() or 1])
-    except Exception:
-        cores = os.cpu_count() or 1
-    sd = {k: v.detach().cpu().numpy() for k, v in work.model.state_dict().items()}
+def cpu_baseline(work):
+    """BASELINE config[0] (C1): unconditional DDIM-50 (eta=1), batch 2, DiTRotary_XL_8, on the host cores -- the torch-CPU
+    restatement (oracle/dit_torch.py; same ATen operator set as the reference on CPU), three steps of the chain, median."""
+    from oracle import diffusion_np as odf, dit_torch as odt
+    cores = torch.get_num_threads()
+    sd = odt.to_torch({k: v.detach().cpu() for k, v in work.model.state_dict().items()})
     S = odf.Schedule(1000, "linear", "ddim50")
-    b = min(batch, 4)
-    rng = np.random.RandomState(0)
-    x = rng.randn(b, 4, 128, 16).astype(np.float32)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 4, 128, 16, generator=g)
 
-    def model(xx, tt, **kw):
-        return odit.dit_forward(sd, xx, tt, None, depth=28, heads=16)
-    n_steps, t0 = 0, time.perf_counter()
-    for i in (49, 48, 47):
-        t = np.full((b,), i, dtype=np.int64)
-        x = odf.ddim_sample(S, model, x, t, rng.randn(*x.shape).astype(np.float32), eta=1.0)["sample"]
-        n_steps += 1
-        if time.perf_counter() - t0 > 20:
-            break
+    def model(xx, tt):
+        return odt.dit_forward(sd, xx, tt, None, depth=28, heads=16)
+    times = []
+    for i in (49, 48, 47, 46):                       # the first one also pages the 2.7 GB of weights in: not timed
+        t = torch.full((2,), i, dtype=torch.int64)
+        t0 = time.perf_counter()
+        x, _ = odt.ddim_step(S, model, x, t, torch.randn(x.shape, generator=g), eta=1.0)
+        times.append(time.perf_counter() - t0)
+    med = sorted(times[1:])[1]
+    return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": int(cores), "kind": "port",
+            "sample": f"BASELINE C1: 3 DDIM-50 steps at batch 2 (DiTRotary_XL_8, torch CPU fp32, {cores} threads), median {med:.2f} s/step "
+                      f"(steps: {', '.join(f'{v:.2f}' for v in times[1:])} s)"}
+
+
+def uint8_flip_record(device):
+    """tests/golden/e2e_ddim50_xl28.npz (the reference's 50-step B=2 chain): decoded uint8 roll vs the reference's."""
+    from functools import partial
+    from guided_diffusion.condition_functions import model_fn
+    from guided_diffusion.gaussian_diffusion import _decode
+    from guided_diffusion.midi_util import decode_sample_for_midi
+    from rgm import synth
+    from taming.models.klvae_pedal import AutoencoderKL
+    g = dict(np.load(os.path.join(ROOT, "tests", "golden", "e2e_ddim50_xl28.npz")))
+    m = build_eps_model(3, device)
+    vae = AutoencoderKL()
+    vae.load_state_dict(synth.vae_state_dict(2, device=device), strict=False)
+    vae = vae.to(device).eval()
+    d = make_diffusion("ddim50")
+    rng = np.random.RandomState(701)
+    q = [rng.randn(2, 4, 128, 16).astype(np.float32) for _ in range(51)]
+    d.noise_fn = lambda shape, dev: torch.from_numpy(q.pop(0)).to(dev)
+    lat = d.ddim_sample_loop(partial(model_fn, model=m, num_classes=3, class_cond=True, cfg=False, w=0.), (2, 4, 128, 16),
+                             clip_denoised=False, model_kwargs={"y": torch.from_numpy(g["y"]).to(device)}, device=device, eta=1.0)
+    err = float((lat.cpu().numpy().astype(np.float64) - g["latent"]).__abs__().max() / np.abs(g["latent"]).max())
+    u8 = decode_sample_for_midi(lat, embed_model=vae, scale_factor=1.2465, threshold=-0.95).cpu().numpy()
+    roll = _decode(lat, vae, scale_factor=1.2465).cpu().numpy().astype(np.float64).transpose(0, 2, 3, 1)
+    bad = u8 != g["u8"]
+    qv = (roll[bad] + 1.0) * 63.5
+    dist = np.minimum(np.abs(qv - np.round(qv)) / 63.5, np.abs(roll[bad] + 0.95)) if bad.any() else np.zeros(1)
+    return {"mismatches": int(bad.sum()), "of": int(bad.size), "not_boundary_adjacent_1e-4": int((dist >= 1e-4).sum()),
+            "latent_rel_err": float(f"{err:.3g}")}
+
+
+def time_steps(work, steps, world, dist):
+    """One timed region of exactly `steps` steps: barrier + synchronise on both sides, MAX over ranks."""
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(steps):
+        work.step()
+    e1.record()
+    fence()
     dt = time.perf_counter() - t0
-    # one step of batch `batch` costs batch/b times a step of batch b (GEMM-bound, linear in batch)
-    return {"value": round(n_steps / dt * b / batch, 4), "unit": "steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"{n_steps} DDIM steps of the same chain at batch {b} with the numpy oracle ({dt:.1f} s), scaled to batch {batch}"}
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=work.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt, e0.elapsed_time(e1)
+
+
+def scg_record(device, world, rank, dist, steps=5, warmup=2):
+    """The sharded SCG step (north star): B = 4, n = 16, candidates partitioned over the ranks, one all-gather per step."""
+    from rgm import scg_shard
+    work = SCGWorkload(device, 4)
+    ag = {"events": []}
+    real_gather = scg_shard.gather_totals
+
+    def timed_gather(local):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        out = real_gather(local)
+        b.record()
+        ag["events"].append((a, b))
+        return out
+    scg_shard.gather_totals = timed_gather
+    try:
+        for _ in range(warmup):
+            work.step()
+        ag["events"].clear()
+        dt, _ = time_steps(work, steps, world, dist)
+        torch.cuda.synchronize()
+        ag_us = [1e3 * a.elapsed_time(b) for a, b in ag["events"]]
+        same = True
+        if world > 1:
+            mine = work.d.last_scg["max_ind"].to(torch.int64).contiguous()
+            allm = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(allm, mine)
+            same = all(bool(torch.equal(allm[0], m)) for m in allm)
+            tot = work.d.last_scg["total_log_prob"].contiguous()
+            allt = [torch.empty_like(tot) for _ in range(world)]
+            dist.all_gather(allt, tot)
+            same = same and all(bool(torch.equal(allt[0], m)) for m in allt)
+    finally:
+        scg_shard.gather_totals = real_gather
+    return {"workload": work.name, "scaling": "strong", "ranks": world, "candidates_per_rank": 16 // world if 16 % world == 0 else 16,
+            "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3), "steps_per_s": round(steps / dt, 4),
+            "allgather_us_per_step": round(float(np.median(ag_us)), 1) if ag_us else None,
+            "same_winners_on_every_rank": bool(same),
+            "algorithmic_tflops": round(work.flop_per_step * steps / dt / 1e12, 2)}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: re-execute through torch.distributed.run, one rank per GPU, on 127.0.0.1."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        sys.exit(f"bench.py: --gpus {n} requested but this box has {have} HIP device(s)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("bench.py: spawning", " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -316,26 +433,31 @@ def main():
     ap.add_argument("--batch", type=int, default=None)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "scg", "long", "dps_rule"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip fp32_exact, scg, uint8_flips, cpu_baseline)")
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="--workload scg on ONE GPU: time the per-rank work of an R-GPU run (this process scores candidates "
                          "[0, n/R) like rank 0 would, the all-gather is a local stand-in): an estimate of the sharded step "
                          "time without the fabric; marked 'simulated' in the JSON, never the headline metric")
     ap.add_argument("--precision", default=os.environ.get("RGM_BENCH_PRECISION", "bf16x3_presplit"), choices=["fp32", "bf16x3", "bf16x3_presplit"],
-                    help="GEMM arithmetic: bf16x3 split (default; fp32-grade: 2.5e-6 latent error on the 50-step golden, "
-                         "parity suite runs in both modes) or exact fp32 MFMA")
+                    help="GEMM arithmetic of the headline run: bf16x3 split on pre-split operands (default; fp32-grade: 2.5e-6 latent "
+                         "error on the 50-step golden, the whole parity suite runs in all three modes) or exact fp32 MFMA")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)                                   # does not return
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)"
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=device)
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+        world = dist.get_world_size()                            # n_gpus = the RCCL world that actually runs
 
     from rgm import native as R
     R.set_gemm_precision(args.precision)
@@ -351,31 +473,42 @@ def main():
         scg_shard.gather_totals = lambda local: local.repeat(Rn, 1)     # same table shape and selection work as the real all-gather
     for _ in range(args.warmup):
         work.step()
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
-        work.step()
-    e1.record()
-    fence()
-    dt = time.perf_counter() - t0
-    gpu_ms = e0.elapsed_time(e1)
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    regions = [time_steps(work, args.steps, world, dist) for _ in range(max(1, args.repeats))]
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    dt, gpu_ms = regions[order[len(order) // 2]]
     try:                                                         # every rank runs it (SCG steps hold a collective)
         roof = roofline_pass(work)
     except Exception as e:                                       # never lose the headline number
         log("roofline pass failed:", repr(e))
         roof = None
+
+    extras = {}
+    if args.workload == "c2" and not args.no_extras and args.simulate_ranks <= 1:
+        def attempt(name, fn):
+            try:
+                extras[name] = fn()
+            except Exception as e:
+                log(f"{name} failed:", repr(e))
+                extras[name] = None
+        # exact-fp32 arithmetic of the same step (every rank: same model, other kernels)
+        def fp32_exact():
+            R.set_gemm_precision("fp32")
+            try:
+                for _ in range(2):
+                    work.step()
+                k = max(3, min(args.steps, 10))
+                d32, _ = time_steps(work, k, world, dist)
+                r32 = roofline_pass(work)
+            finally:
+                R.set_gemm_precision(args.precision)
+            return {"dtype": "f32 (v_mfma_f32_32x32x2_f32)", "steps": k, "value": round(k * world / d32, 4), "unit": "steps/s",
+                    "ms_per_step": round(1e3 * d32 / k, 3), "roofline": r32}
+        attempt("fp32_exact", fp32_exact)
+        attempt("scg", lambda: scg_record(device, world, rank, dist))
+        if rank == 0:
+            attempt("uint8_flips", lambda: uint8_flip_record(device))
+            if world == 1 and not args.no_cpu_baseline:
+                attempt("cpu_baseline", lambda: cpu_baseline(work))
     if rank == 0:
         sharded = args.workload in ("scg", "long")
         units = args.steps * (1 if sharded else world)           # SCG shards ONE chain; C2 runs one chain per GPU
@@ -389,16 +522,17 @@ def main():
             "config": {"workload": work.name + (f" [SIMULATED rank 0 of {args.simulate_ranks}: per-rank work only, no fabric]"
                                                 if args.simulate_ranks > 1 else ""), "batch_per_gpu": batch, "sample_steps_per_s": round(units * batch / dt, 2),
                        "weights": "synthetic random-init (rgm.synth seed 1; adaLN/final layers re-randomised)",
+                       "timing": f"median of {len(regions)} timed regions of {args.steps} steps",
+                       "repeats_ms_per_step": [round(1e3 * r[0] / args.steps, 3) for r in regions],
                        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
                        "algorithmic_tflops": round(work.flop_per_step * units / dt / 1e12, 2)},
         }
+        if "uint8_flips" in extras:
+            res["config"]["uint8_flips"] = extras.pop("uint8_flips")
         res["roofline"] = roof
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
-            try:
-                res["cpu_baseline"] = cpu_baseline(work, batch)
-            except Exception as e:
-                log("cpu baseline failed:", repr(e))
-                res["cpu_baseline"] = None
+        for k in ("fp32_exact", "scg", "cpu_baseline"):
+            if k in extras:
+                res[k] = extras[k]
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

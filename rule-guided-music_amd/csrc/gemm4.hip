@@ -11,7 +11,7 @@
 //   * the (tile, K-tile) iteration space -- tiles in the grouped raster, K-tiles inside -- is cut into gridDim.x EQUAL
 //     contiguous ranges, one per workgroup ("stream-K"): every CU does the same number of MFMAs whatever M, N, K are;
 //   * a workgroup's K-tiles form ONE stream through its 2-stage LDS ring: the DMA of the next tile's first K-tiles is
-//     issued during the last MFMAs of the current tile and lands during its epilogue (own 16 KB staging slab);
+//     issued during the last MFMAs of the current tile and lands during its epilogue (own 8 KB staging slab);
 //   * a tile cut between workgroups is finished by the workgroup that holds its FIRST K-tile (it reaches the tile last):
 //     the others store their raw fp32 accumulators write-through (sc1) to a workspace slot and raise a flag; the
 //     finisher polls the flag (relaxed), takes ONE agent-scope acquire, adds the slots in workgroup order (fixed
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
   constexpr int NM = TM * TN * 3;               // MFMAs per k16 step
   constexpr int WCOLS = TN * 32;
   static_assert(SPW <= NM, "one DMA piece per MFMA slot of the second k16 step");
-  extern __shared__ __attribute__((aligned(16))) char ring[];   // 2 stages, then 4 epilogue slabs of 16 x WCOLS floats
+  extern __shared__ __attribute__((aligned(16))) char ring[];   // 2 stages, then 4 epilogue slabs of 8 x WCOLS floats
 
   const int KT = p.K >> 5;
   const int ntiles = tiles_m * tiles_n;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
     int ln = lane;
     asm volatile("" : "+v"(ln));                        // epilogue addressing is recomputed here, not carried through the K loop
     const int l31 = ln & 31, hh = ln >> 5;
-    float* stg = reinterpret_cast<float*>(ring + 2 * STAGE) + wave * (16 * WCOLS);
+    float* stg = reinterpret_cast<float*>(ring + 2 * STAGE) + wave * (8 * WCOLS);
     const float* first_slot = reinterpret_cast<const float*>(slots + (long long)(w + 1) * G4_SLOT_BYTES);
     {
       constexpr int LPR = WCOLS / 4, RPI = 64 / LPR;   // 16 lanes per row, 4 rows per wave-instruction
@@ -185,20 +185,18 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (!publish && p.bias && col_ok) bv = *reinterpret_cast<const float4*>(p.bias + col);
       __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(slots + (long long)w * G4_SLOT_BYTES, 0, G4_SLOT_BYTES, 0x00020000);
-      static_for<0, TM * 2>([&](auto hc) {
-        constexpr int im = decltype(hc)::value >> 1, half = decltype(hc)::value & 1;   // rows 16*half .. 16*half+15 of block im
+      static_for<0, TM * 4>([&](auto hc) {
+        constexpr int im = decltype(hc)::value >> 2, oct = decltype(hc)::value & 3;    // rows 8*oct .. 8*oct+7 of 32-row block im
         static_for<0, TN>([&](auto in_c) {
           constexpr int in = decltype(in_c)::value;
 #pragma unroll
-          for (int e8 = 0; e8 < 8; ++e8) {
-            const int e = half * 8 + e8;             // (e & 3) + 8 * (e >> 2) = 16 * half + (e8 & 3) + 8 * (e8 >> 2)
-            stg[((e8 & 3) + 8 * (e8 >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
-          }
+          for (int e4 = 0; e4 < 4; ++e4)               // register e = 4*oct + e4 holds row 8*oct + e4 + 4*hh
+            stg[(e4 + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][oct * 4 + e4];
         });
 #pragma unroll
-        for (int j = 0; j < 16 / RPI; ++j) {
+        for (int j = 0; j < 8 / RPI; ++j) {
           const int r = j * RPI + lr;
-          const int trow = arow0 + im * 32 + half * 16 + r;                            // row / first column inside the tile
+          const int trow = arow0 + im * 32 + oct * 8 + r;                              // row / first column inside the tile
           const int tcol = bcol0 + lc;
           const int row = m0 + trow;
           float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
@@ -389,7 +387,10 @@ int gemm4_launch(const GemmParams& p, hipStream_t s) {
     RGM_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g4_grid = cus * 2 > 512 ? 512 : (cus * 2) & ~7;          // the resident set: 2 workgroups per CU, a multiple of the 8 XCDs
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768 + 16384));
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768 + 8192));
+    int per_cu = 0;
+    RGM_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(gemm4_kernel), 256, 2 * 32768 + 8192));
+    RGM_REQUIRE(per_cu >= 2, "gemm4: only %d workgroup(s) per CU are resident; the stream-K grid needs 2", per_cu);
   }
   const int tm = cdiv(p.M, 128), tn = cdiv(p.N, 128);
   const long long total = (long long)tm * tn * (p.K >> 5);
@@ -397,7 +398,7 @@ int gemm4_launch(const GemmParams& p, hipStream_t s) {
   int grid = g4_grid;
   if (total < grid) grid = (int)(total < 8 ? 8 : total & ~7LL);
   const int rec = gemm2_prof_begin(47, 2.0 * p.M * (double)p.N * p.K, s);
-  hipLaunchKernelGGL(gemm4_kernel, dim3(grid), dim3(256), 2 * 32768 + 16384, s, p, (const char*)g4_zero_page, tm, tn, (char*)p.sk_ws);
+  hipLaunchKernelGGL(gemm4_kernel, dim3(grid), dim3(256), 2 * 32768 + 8192, s, p, (const char*)g4_zero_page, tm, tn, (char*)p.sk_ws);
   RGM_LAUNCH_CHECK();
   gemm2_prof_end(rec, s);
   return RGM_OK;

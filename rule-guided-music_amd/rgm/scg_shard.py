@@ -33,8 +33,13 @@ def partition(n, world_size=None, rank=None):
 def gather_totals(total_local):
     """(n/R, B) float32 per rank -> (n, B) on every rank, rank-major (== candidate order)."""
     R, _ = world()
+    total_local = total_local.contiguous()
+    if total_local.is_cuda:                      # RCCL: one all-gather straight into the (n, B) table
+        out = torch.empty((R * total_local.shape[0],) + tuple(total_local.shape[1:]), dtype=total_local.dtype, device=total_local.device)
+        dist.all_gather_into_tensor(out, total_local)
+        return out
     parts = [torch.empty_like(total_local) for _ in range(R)]
-    dist.all_gather(parts, total_local.contiguous())
+    dist.all_gather(parts, total_local)
     return torch.cat(parts, dim=0)
 
 

@@ -290,3 +290,22 @@ def test_segmentwise_selection_index_arithmetic():
             assert np.array_equal(sample[b, :, i * 128:(i + 1) * 128], cand.reshape(n, B, 4, 256, 16)[inds[i, b], b, :, i * 128:(i + 1) * 128])
     g = load_golden("steps2")
     assert g["seg.max_ind"].shape == (2, 2) and g["seg.total_log_prob"].shape == (3, 2, 2)
+
+
+def test_torch_cpu_restatement_for_the_cpu_baseline_leg():
+    """oracle/dit_torch.py (what bench.py's cpu_baseline times): DiTRotary forward at XL width and a teacher-forced DDIM step
+    against the reference's goldens -- the same fixtures that pin the numpy oracle."""
+    import torch
+    from oracle import dit_torch as odt
+    g = load_golden("dit_xl_d2")
+    sd = odt.to_torch(synth.dit_state_dict(int(g["seed"]), **XL2))
+    for H in (128, 64):
+        out = odt.dit_forward(sd, torch.from_numpy(g[f"x{H}"]), torch.from_numpy(g[f"t{H}"]), torch.from_numpy(g[f"y{H}"]), depth=2, heads=16)
+        assert rel_err(out.numpy(), g[f"out{H}"]) < 1e-4
+    s = load_golden("steps")
+    sm = odt.to_torch(synth.dit_state_dict(11, **SM))
+    S = odf.Schedule(1000, "linear", "ddim50")
+    y = torch.from_numpy(s["y"])
+    smp, x0 = odt.ddim_step(S, lambda x, t: odt.dit_forward(sm, x, t, y, depth=2, heads=6), torch.from_numpy(s["x"]),
+                            torch.from_numpy(s["ddim.t"]), torch.from_numpy(s["ddim.noise"]), eta=1.0)
+    assert rel_err(smp.numpy(), s["ddim.sample"]) < 1e-4 and rel_err(x0.numpy(), s["ddim.pred_xstart"]) < 1e-4
