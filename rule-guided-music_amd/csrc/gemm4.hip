@@ -8,8 +8,11 @@
 // prologue (a first DMA round trip) and launch slot.  Here:
 //
 //   * the grid is exactly the resident set (2 workgroups per CU), alive for the whole launch;
-//   * the (tile, K-tile) iteration space -- tiles in the grouped raster, K-tiles inside -- is cut into gridDim.x EQUAL
-//     contiguous ranges, one per workgroup ("stream-K"): every CU does the same number of MFMAs whatever M, N, K are;
+//   * hybrid "data-parallel + stream-K" decomposition: with G = gridDim.x workgroups and tiles = F*G + R, every workgroup
+//     first computes F WHOLE tiles (round r: XCD-contiguous raster tile chunk + r*G/8 + its slot, so that the workgroups
+//     that run together work on neighbouring tiles at the same K position and share the A / B panels in L2 exactly like
+//     the tiled launch), then the (tile, K-tile) iteration space of the R leftover tiles is cut into G EQUAL contiguous
+//     ranges, one per workgroup ("stream-K"): every CU does the same number of MFMAs whatever M, N, K are;
 //   * a workgroup's K-tiles form ONE stream through its 2-stage LDS ring: the DMA of the next tile's first K-tiles is
 //     issued during the last MFMAs of the current tile and lands during its epilogue (own 8 KB staging slab);
 //   * a tile cut between workgroups is finished by the workgroup that holds its FIRST K-tile (it reaches the tile last):
@@ -36,6 +39,8 @@ constexpr int G4_SLOT_BYTES = 128 * 128 * 4;     // one raw accumulator tile
 constexpr int G4_FLAG_BYTES = 4096;              // flags[gridDim.x] + error word, ahead of the slots
 constexpr unsigned G4_SPIN_LIMIT = 1u << 22;
 
+// EDGE: M or N is not a multiple of 128 (rows beyond the edge read a zero page; per-piece validity is carried per lane)
+template <bool EDGE>
 __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m, int tiles_n,
                                                       char* __restrict__ ws) {
   constexpr int BM = 128, BN = 128, NW = 4, WN = 2, TM = 2, TN = 2;
@@ -48,15 +53,20 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
 
   const int KT = p.K >> 5;
   const int ntiles = tiles_m * tiles_n;
-  const int total = ntiles * KT;                // < 2^31 (checked by the launcher)
-  const int G = gridDim.x;
+  const int G = gridDim.x, G8 = G >> 3;
+  const int F = ntiles / G, R = ntiles - F * G;  // whole-tile rounds, leftover tiles
+  const int total = R * KT;                      // stream-K space: the leftover tiles' K-tiles (< 2^31, checked by the launcher)
   const int rq_ = total / G, rr_ = total - rq_ * G;   // the first rr_ workgroups take rq_ + 1 K-tiles, the others rq_
   auto range_begin = [&](int wi) __attribute__((always_inline)) { return wi * rq_ + min(wi, rr_); };
-  // workgroup b lives on XCD b % 8 (observed; used for speed only): give every XCD one contiguous chunk of the stream
-  const int w = ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3);
+  // workgroup b lives on XCD b % 8 (observed; used for speed only): every XCD owns one contiguous chunk of the tiles / stream
+  const int xcd = (int)blockIdx.x & 7, loc = (int)blockIdx.x >> 3;
+  const int w = xcd * G8 + loc;
   const int it0 = range_begin(w), it1 = range_begin(w + 1);
-  const int Gw = it1 - it0;
+  const int sk_t0 = total ? it0 / KT : 0, sk_k0 = total ? it0 - sk_t0 * KT : 0;
+  const int Gw = F * KT + (it1 - it0);           // K-tiles this workgroup streams
   if (Gw <= 0) return;
+  // segment i of this workgroup's stream: i < F a whole tile of round i, then the tiles its stream-K range touches
+  auto tile_of = [&](int i) __attribute__((always_inline)) { return i < F ? xcd * F * G8 + i * G8 + loc : F * G + sk_t0 + (i - F); };
 
   auto coords = [&](int t, int& m0, int& n0) __attribute__((always_inline)) {   // grouped raster: 8 row-tiles per column sweep
     constexpr int GROUP = 8;
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
 
   // ---------------------------------------------------------------- DMA side: this wave's pieces of the K-tile stream
   const char* src[SPW];
-  int inc[SPW];
+  int inc[EDGE ? SPW : 1];
   auto aim = [&](int t, int kt) __attribute__((always_inline)) {                 // per-lane source of every piece at K-tile kt of output tile t
     int m0, n0;
     coords(t, m0, n0);
@@ -93,17 +103,17 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
       const int row_l = s * 8 + r8;                              // LDS row within the stage
       const int cs = ((ln & 7) ^ ((row_l >> 1) & 7)) << 4;       // XOR swizzle applied on the source side (gemm2.hip)
       const int row = isA ? m0 + row_l : n0 + row_l - BM;
-      const bool ok = isA ? row < p.M : row < p.N;
+      const bool ok = !EDGE || (isA ? row < p.M : row < p.N);
       src[i] = ok ? (isA ? Ab + (long long)row * p.lda * 4 : Bb + (long long)row * p.ldb * 4) + (long long)kt * 128 + cs : zero_page + cs;
-      inc[i] = ok ? 128 : 0;
+      if (EDGE) inc[i] = ok ? 128 : 0;
     }
   };
-  int l_tile = it0 / KT, l_kt = it0 - l_tile * KT;
+  int l_seg = 0, l_kt = F == 0 ? sk_k0 : 0;      // the DMA side's position in the stream: (segment, K-tile) of the next issue
   bool l_aim = false;
   auto advance = [&]() __attribute__((always_inline)) {                           // the K-tile just issued is behind us
     if (++l_kt == KT) {
-      l_kt = 0;
-      ++l_tile;
+      ++l_seg;
+      l_kt = l_seg == F ? sk_k0 : 0;
       l_aim = true;
     }
   };
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
       if constexpr (st == 1 && m < SPW) {
         if (issue) {
           dma16_g4(src[m], dst + (wave + m * NW) * 1024);
-          src[m] += inc[m];
+          src[m] += EDGE ? inc[m] : 128;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -248,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
 
   // the finisher of a cut tile: wait for the slots of the workgroups after this one (G16 / R1: relaxed poll of ONE word by
   // one wave, ONE agent-scope acquire, barrier), returns how many there are; release_slots() hands their flags back
-  auto wait_partials = [&](int tile) __attribute__((always_inline)) {
-    const int tile_end = (tile + 1) * KT;
+  auto wait_partials = [&](int sk_tile) __attribute__((always_inline)) {   // sk_tile: index among the leftover tiles
+    const int tile_end = (sk_tile + 1) * KT;
     int n = 0;
     for (int w2 = w + 1; w2 < G && range_begin(w2) < tile_end; ++w2) ++n;
     if (wave == 0) {
@@ -282,25 +292,25 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
 
   // ---------------------------------------------------------------- the stream
   Frags f0, f1;
-  int c_tile = l_tile, seg_k0 = l_kt, m0, n0;
-  coords(c_tile, m0, n0);
+  int c_seg = 0, seg_k0 = l_kt, m0, n0;
+  coords(tile_of(0), m0, n0);
   zero_acc();
-  aim(l_tile, l_kt);
+  aim(tile_of(0), l_kt);
   static_for<0, SPW>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     dma16_g4(src[i], ring + (wave + i * NW) * 1024);
-    src[i] += inc[i];
+    src[i] += EDGE ? inc[i] : 128;
   });
   advance();
   if (Gw > 1) {
     if (l_aim) {
-      aim(l_tile, 0);
+      aim(tile_of(l_seg), l_kt);
       l_aim = false;
     }
     static_for<0, SPW>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       dma16_g4(src[i], ring + STAGE + (wave + i * NW) * 1024);
-      src[i] += inc[i];
+      src[i] += EDGE ? inc[i] : 128;
     });
     advance();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
   auto body = [&](Frags& cur, Frags& nxt, int g, bool last) __attribute__((always_inline)) {
     const bool more1 = g + 1 < Gw, more2 = g + 2 < Gw;
     if (more2 && l_aim) {                          // K-tile g+2 opens a new output tile: re-aim the pieces
-      aim(l_tile, 0);
+      aim(tile_of(l_seg), l_kt);
       l_aim = false;
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -332,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
   };
   int g = 0;
   while (true) {
-    // the segment of output tile c_tile this workgroup owns: K-tiles seg_k0 .. seg_k0 + n_seg - 1; f0 holds the first one's fragments
+    // the segment of output tile tile_of(c_seg) this workgroup owns: K-tiles seg_k0 .. seg_k0 + n_seg - 1; f0 holds the first one's fragments
     const int n_seg = min(KT - seg_k0, Gw - g);
     for (int j = 0; j < n_seg; j += 2) {
       body(f0, f1, g + j, j + 1 == n_seg);
@@ -341,14 +351,14 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
     g += n_seg;
     const bool publish = seg_k0 != 0;             // not the tile's first K-tile: another workgroup finishes it
     int nc = 0;
-    if (!publish && n_seg != KT) nc = wait_partials(c_tile);   // cut tile: the later workgroups' parts are added in workgroup order
+    if (!publish && n_seg != KT) nc = wait_partials(sk_t0 + (c_seg - F));   // cut tile: the later workgroups' parts, in workgroup order
     emit(m0, n0, publish, nc);
     if (publish) publish_done();
     else if (nc) release_slots(nc);
     if (g >= Gw) break;
-    ++c_tile;
-    seg_k0 = 0;
-    coords(c_tile, m0, n0);
+    ++c_seg;
+    seg_k0 = c_seg == F ? sk_k0 : 0;
+    coords(tile_of(c_seg), m0, n0);
     zero_acc();
     load_frags(f0, ring + (g & 1) * STAGE);       // K-tile g landed before the barrier of the segment's last K-tile
   }
@@ -387,18 +397,23 @@ int gemm4_launch(const GemmParams& p, hipStream_t s) {
     RGM_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     g4_grid = cus * 2 > 512 ? 512 : (cus * 2) & ~7;          // the resident set: 2 workgroups per CU, a multiple of the 8 XCDs
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768 + 8192));
-    int per_cu = 0;
-    RGM_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(gemm4_kernel), 256, 2 * 32768 + 8192));
-    RGM_REQUIRE(per_cu >= 2, "gemm4: only %d workgroup(s) per CU are resident; the stream-K grid needs 2", per_cu);
+    for (const void* k : {reinterpret_cast<const void*>(gemm4_kernel<false>), reinterpret_cast<const void*>(gemm4_kernel<true>)}) {
+      RGM_CHECK_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 32768 + 8192));
+      int per_cu = 0;
+      RGM_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 256, 2 * 32768 + 8192));
+      RGM_REQUIRE(per_cu >= 2, "gemm4: only %d workgroup(s) per CU are resident; the stream-K grid needs 2", per_cu);
+    }
   }
   const int tm = cdiv(p.M, 128), tn = cdiv(p.N, 128);
   const long long total = (long long)tm * tn * (p.K >> 5);
   RGM_REQUIRE(total < (1LL << 31), "gemm4: %lld K-tiles exceed the 31-bit stream index", total);
   int grid = g4_grid;
-  if (total < grid) grid = (int)(total < 8 ? 8 : total & ~7LL);
+  if (total < grid) grid = (int)(total < 8 ? 8 : total & ~7LL);   // tiny problems: no more workgroups than K-tiles
   const int rec = gemm2_prof_begin(47, 2.0 * p.M * (double)p.N * p.K, s);
-  hipLaunchKernelGGL(gemm4_kernel, dim3(grid), dim3(256), 2 * 32768 + 8192, s, p, (const char*)g4_zero_page, tm, tn, (char*)p.sk_ws);
+  if ((p.M & 127) || (p.N & 127))
+    hipLaunchKernelGGL(gemm4_kernel<true>, dim3(grid), dim3(256), 2 * 32768 + 8192, s, p, (const char*)g4_zero_page, tm, tn, (char*)p.sk_ws);
+  else
+    hipLaunchKernelGGL(gemm4_kernel<false>, dim3(grid), dim3(256), 2 * 32768 + 8192, s, p, (const char*)g4_zero_page, tm, tn, (char*)p.sk_ws);
   RGM_LAUNCH_CHECK();
   gemm2_prof_end(rec, s);
   return RGM_OK;

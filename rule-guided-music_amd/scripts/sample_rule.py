@@ -68,7 +68,8 @@ def setup_chord_backend(args, config):
         if cc is not None:
             for name in ("names", "paths", "num_classes"):
                 if hasattr(cc, name):
-                    setattr(cc, name, [getattr(cc, name)[i] for i in keep])
+                    v = getattr(cc, name)
+                    setattr(cc, name, [v[i] for i in keep if i < len(v)])
         if not keep:
             config.guidance.cond_fn = None
             config.guidance.nn = False
@@ -145,7 +146,10 @@ def build_pipeline(args, config, device):
     if config.guidance.nn:
         logger.log("loading classifier...")
         cc = cond_fn_config.classifiers
-        for i, name in enumerate(cc.names):
+        # the reference loads one classifier per entry of `names` (:88-104; cond_demo/demo3.yml lists three cond_fns but two
+        # names, so two run); its pixel-space ablation configs carry no names at all: inferred from the cond_fn here
+        names = getattr(cc, "names", None) or ["DiTRotary-S/8-chord-cls" if "chord" in f else "DiTRotary-S/8-cls" for f in cond_fn_config.fns]
+        for i, name in enumerate(names):
             clf = DiT_models[name](input_size=args.image_size, in_channels=args.in_channels, num_classes=cc.num_classes[i])
             if args.synthetic_weights:
                 from rgm import synth

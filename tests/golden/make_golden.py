@@ -730,7 +730,7 @@ def g_configs():
     for f in sorted(glob.glob(os.path.join(root, "**", "*.yml"), recursive=True)):
         tree[os.path.relpath(f, root)] = yaml.safe_load(open(f))
     p = os.path.join(HERE, "ref_configs.json")
-    json.dump(tree, open(p, "w"), indent=0, sort_keys=True)
+    json.dump(tree, open(p, "w"), indent=0)      # key order kept: rule order matters (in-place roll writes, first-key source test)
     print(f"  wrote ref_configs.json  {len(tree)} files, {os.path.getsize(p) / 1024:.1f} KiB")
 
 

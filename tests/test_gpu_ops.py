@@ -218,7 +218,7 @@ def test_streamk_gemm_matches_the_tiled_kernel(M, N, K, act, split):
     c2 = torch.empty((M, N), device="cuda")
     R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(c2), M, N, K, R.ptr(bd), act, 43, split, st))
     torch.cuda.synchronize()
-    assert rel(outs[0], _unsplit(c2) if split else c2.cpu().numpy()) < (3e-5 if split else 2e-6)
+    assert rel(outs[0], _unsplit(c2) if split else c2.cpu().numpy()) < (3e-5 if split else 5e-6)
 
 
 def test_streamk_gemm_gate_and_residual_in_place():

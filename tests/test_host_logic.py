@@ -95,14 +95,58 @@ def test_yaml_configs_follow_the_reference_schema():
             assert hasattr(cfg.sampling, "use_ddim") and hasattr(cfg.sampling, "diff_collage") and hasattr(cfg.sampling, "t_end")
             if cfg.guidance.nn:
                 c = cfg.guidance.cond_fn
-                assert len(c.rule_names) == len(c.fns) == len(c.classifier_scales) == len(c.classifiers.names)
+                assert len(c.rule_names) == len(c.fns) == len(c.classifier_scales)
             if getattr(cfg.guidance, "scg", False):
                 assert cfg.scg.num_samples >= 1
             if cfg.sampling.diff_collage:
                 assert cfg.dc.type in ("linear", "circle") and cfg.dc.overlap_size == 64
-    assert n >= 5
-    cfg = load_config(os.path.join(base, "cond_demo", "demo2.yml"))
-    assert vars(cfg.scg) == {"num_samples": 16, "pitch_hist": 40.0, "note_density": 1.0} and cfg.guidance.cond_fn is None
+    assert n >= 62
+
+
+def test_shipped_config_tree_carries_the_reference_values():
+    """a13: every YAML of the reference's scripts/configs tree (tests/golden/ref_configs.json = those files, parsed by
+    make_golden.py) is shipped under the same name with the same VALUES in guidance / scg / sampling / dc / edit; the one
+    intended difference is target_rules that the reference leaves Null (drawn from its dataset), which carry explicit example
+    targets here -- targets the reference does give are identical."""
+    import yaml
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_configs.json")))
+    base = os.path.join(PKG, "scripts", "configs")
+    assert len(ref) == 62
+    for rel, r in ref.items():
+        mine = yaml.safe_load(open(os.path.join(base, rel)))
+        assert set(mine) == set(r), (rel, set(mine) ^ set(r))
+        for sec in r:
+            if sec != "target_rules":
+                assert mine[sec] == r[sec], (rel, sec, mine[sec], r[sec])
+                continue
+            assert list(mine[sec]) == list(r[sec]), (rel, "target rule names")
+            for k, v in r[sec].items():
+                if v is not None or "edit" in r:
+                    assert mine[sec][k] == v, (rel, k)
+                else:
+                    assert mine[sec][k] is not None and len(mine[sec][k]) >= 4, (rel, k)
+    demo2 = yaml.safe_load(open(os.path.join(base, "cond_demo", "demo2.yml")))
+    assert demo2["sampling"]["diff_collage"] and demo2["dc"] == {"type": "circle", "overlap_size": 64, "num_img": 1}
+    assert demo2["guidance"]["dc"] == {"base": 128} and demo2["scg"]["pitch_hist"] == 100.0
+
+
+def test_cli_skips_chord_entries_without_a_backend_and_infers_classifier_names():
+    """The reference's chord entries are accepted and skipped (warning) while no analyser is registered; demo3.yml's third
+    cond_fn (no third classifier name) and the name-less pixel-space configs resolve like the reference's loader loop."""
+    from types import SimpleNamespace
+    from guided_diffusion.midi_util import load_config
+    cli = _load_cli()
+    base = os.path.join(PKG, "scripts", "configs")
+    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0),
+                                  load_config(os.path.join(base, "cond_table", "all", "scg_classifier_all.yml")))
+    assert list(vars(cfg.target_rules)) == ["pitch_hist", "vertical_nd", "horizontal_nd"] and "chord_progression" not in vars(cfg.scg)
+    c = cfg.guidance.cond_fn
+    assert c.rule_names == ["pitch_hist", "note_density"] and c.fns == ["grad_nn_zt_mse"] * 2 and c.classifiers.names == ["DiTRotary-S/8-cls"] * 2
+    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0), load_config(os.path.join(base, "cond_demo", "demo3.yml")))
+    assert cfg.guidance.cond_fn.rule_names == ["pitch_hist", "note_density"] and len(cfg.guidance.cond_fn.classifiers.names) == 2
+    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0),
+                                  load_config(os.path.join(base, "cond_table", "single", "scg", "chord.yml")))
+    assert vars(cfg.target_rules) == {}                       # nothing left to guide: the CLI reports it
 
 
 def test_scg_partition_is_contiguous_and_order_preserving():
@@ -280,7 +324,7 @@ def test_every_shipped_config_has_the_reference_name_and_usable_targets():
     for rel in names:
         cfg = load_config(os.path.join(base, rel))
         if rel.startswith("edit/"):
-            assert cfg.edit.source in ("synthetic",) and 0 <= cfg.edit.l_start < cfg.edit.l_end <= 128
+            assert cfg.edit.source in ("synthetic", "dataset") and 0 <= cfg.edit.l_start < cfg.edit.l_end <= 128
             continue
         rules = cli.build_target_rules(vars(cfg.target_rules), 3, "cpu")
         assert rules, rel
@@ -288,7 +332,8 @@ def test_every_shipped_config_has_the_reference_name_and_usable_targets():
         for k, v in rules.items():
             assert v.shape == (3, width[k] * (1 if k == "pitch_hist" else long)), (rel, k, tuple(v.shape))
         if cfg.guidance.cond_fn is not None:
-            for name in cfg.guidance.cond_fn.rule_names:       # every guided rule has a target (pixel variants share the keys)
-                assert name.replace("_pixel", "") in rules or name in rules, (rel, name)
+            nrun = len(getattr(cfg.guidance.cond_fn.classifiers, "names", cfg.guidance.cond_fn.fns)) if cfg.guidance.nn else len(cfg.guidance.cond_fn.fns)
+            for name in cfg.guidance.cond_fn.rule_names[:nrun]:  # every guided rule that RUNS has a target (demo3 lists a third cond_fn
+                assert name.replace("_pixel", "") in rules or name in rules, (rel, name)   # without a classifier: never loaded, as in the reference)
         if getattr(cfg.sampling, "use_ddim", False) and hasattr(cfg.sampling, "timestep_respacing"):
             assert cfg.sampling.timestep_respacing.startswith("ddim")
