@@ -461,6 +461,8 @@ def main():
 
     from rgm import native as R
     R.set_gemm_precision(args.precision)
+    if os.environ.get("RGM_STREAMK") is not None:               # experiments: 0 off, 1 heuristic (default), 2 always
+        R.check(R.lib.rgm_set_streamk(int(os.environ["RGM_STREAMK"])))
     torch.manual_seed(0)
     batch = args.batch or {"c2": 16, "c3": 32, "scg": 4, "long": 1, "dps_rule": 16}[args.workload]
     work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload, "long": LongWorkload,

@@ -120,6 +120,8 @@ int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int l
  * scratch is caller memory like every other workspace.  rgm_gemm_streamk_workspace_bytes() bytes, 16-byte aligned; tile 0 lets
  * the heuristic choose, 47 forces the persistent stream-K kernel.  The entry zeroes the scratch's flag words on `stream`. */
 size_t rgm_gemm_streamk_workspace_bytes(void);
+/* process-wide: 0 never use the persistent kernel, 1 heuristic (default), 2 whenever the operands allow it */
+int rgm_set_streamk(int mode);
 int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias, int act,
                       int tile, int out_split, void* ws, size_t ws_bytes, void* stream);
 /* Same as rgm_gemm without gate/residual but with an explicit tile shape in the low 4 bits (1: 128x128,

@@ -369,15 +369,29 @@ static int g4_grid = 0;
 
 size_t gemm4_workspace_bytes() { return (size_t)G4_FLAG_BYTES + (size_t)512 * G4_SLOT_BYTES; }
 
-// stream-K pays when every workgroup's range is long enough to amortise one hand-off (measured: tools/gemm_sweep.py)
+static int g4_mode = 1;   // rgm_set_streamk: 0 never, 1 heuristic, 2 whenever the operands allow it
+void gemm4_set_mode(int mode) { g4_mode = mode; }
+int gemm4_get_mode() { return g4_mode; }
+
+// When it pays (tools/gemm_sweep.py + bench.py A/B, MI355X): the persistent whole-tile rounds run ~6 % above the tiled launch
+// (fc1 / fc2 at M = 16384: 369 / 360 vs 347 / 339 TFLOP/s); the stream-K remainder costs every workgroup a slot round trip
+// (~25 us of fabric traffic when all 512 publish at once), which eats the balance gain at M = 4096 (B = 16: C2 62.0 vs 64.7
+// steps/s with fc1 on this kernel) and leaves +1.8 % on the C3 step (B = 32).  Hence: M >= 8192 and a remainder of at most
+// 15 % of a workgroup's K-tiles (or none).
 bool gemm4_eligible(const GemmParams& p) {
+  if (g4_mode == 0) return false;
   if (!p.sk_ws || p.sk_ws_bytes < gemm4_workspace_bytes()) return false;
   if (p.aload || p.batch != 1 || p.stats || p.act > 2 || p.aux) return false;
   if (((p.N | p.ldc | p.ldres | p.gate_ld) & 3) != 0 || (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) != 0)
     return false;                                  // the epilogue moves 16 bytes per lane
   const long long tiles = (long long)cdiv(p.M, 128) * cdiv(p.N, 128);
-  const long long iters = tiles * (p.K >> 5);
-  return tiles >= 384 && iters / 512 >= 32;
+  const int KT = p.K >> 5;
+  if (tiles * KT >= (1LL << 31)) return false;
+  if (g4_mode == 2) return tiles * KT >= 512;
+  const long long F = tiles / 512, R = tiles - F * 512;
+  if (F == 0 || p.M < 8192) return false;
+  const double sk = (double)R * KT / 512.0, all = (double)F * KT + sk;
+  return R == 0 || (sk >= 8.0 && sk <= 0.15 * all);
 }
 
 int gemm4_launch(const GemmParams& p, hipStream_t s) {
@@ -424,6 +438,13 @@ int gemm4_launch(const GemmParams& p, hipStream_t s) {
 // Bytes of the stream-K workspace (flags + one raw accumulator slot per resident workgroup); zero its first 4096 bytes once
 // before the first launch that uses it (the kernels hand every flag back).
 extern "C" size_t rgm_gemm_streamk_workspace_bytes(void) { return rgm::gemm4_workspace_bytes(); }
+
+// 0: never use the persistent stream-K kernel, 1: heuristic (default), 2: whenever the operands allow it (experiments)
+extern "C" int rgm_set_streamk(int mode) {
+  RGM_REQUIRE(mode >= 0 && mode <= 2, "set_streamk: mode %d", mode);
+  rgm::gemm4_set_mode(mode);
+  return RGM_OK;
+}
 
 // rgm_gemm_split with a caller-provided stream-K workspace: tile 0 lets the heuristic pick (stream-K when it pays), 47 forces it.
 // The flag words are zeroed here on the stream (a standalone call may be the workspace's first user).
