@@ -294,26 +294,40 @@ def roofline_pass(work, steps=2):
 
 def cpu_baseline(work):
     """BASELINE config[0] (C1): unconditional DDIM-50 (eta=1), batch 2, DiTRotary_XL_8, on the host cores -- the torch-CPU
-    restatement (oracle/dit_torch.py; same ATen operator set as the reference on CPU), three steps of the chain, median."""
+    restatement (oracle/dit_torch.py; same ATen operator set as the reference on CPU), three steps of the chain, median.
+    Timed with torch's default thread count (what the reference would use) and with 16 threads (a batch-2 forward is
+    weight-streaming work that many-core hosts oversubscribe); the faster of the two is the value, both are listed."""
     from oracle import diffusion_np as odf, dit_torch as odt
-    cores = torch.get_num_threads()
     sd = odt.to_torch({k: v.detach().cpu() for k, v in work.model.state_dict().items()})
     S = odf.Schedule(1000, "linear", "ddim50")
-    g = torch.Generator().manual_seed(0)
-    x = torch.randn(2, 4, 128, 16, generator=g)
 
     def model(xx, tt):
         return odt.dit_forward(sd, xx, tt, None, depth=28, heads=16)
-    times = []
-    for i in (49, 48, 47, 46):                       # the first one also pages the 2.7 GB of weights in: not timed
-        t = torch.full((2,), i, dtype=torch.int64)
-        t0 = time.perf_counter()
-        x, _ = odt.ddim_step(S, model, x, t, torch.randn(x.shape, generator=g), eta=1.0)
-        times.append(time.perf_counter() - t0)
-    med = sorted(times[1:])[1]
+
+    def run(threads):
+        torch.set_num_threads(threads)
+        g = torch.Generator().manual_seed(0)
+        x = torch.randn(2, 4, 128, 16, generator=g)
+        times = []
+        for i in (49, 48, 47, 46):                   # the first one also pages the 2.7 GB of weights in: not timed
+            t = torch.full((2,), i, dtype=torch.int64)
+            t0 = time.perf_counter()
+            x, _ = odt.ddim_step(S, model, x, t, torch.randn(x.shape, generator=g), eta=1.0)
+            times.append(time.perf_counter() - t0)
+        return sorted(times[1:])[1], times[1:]
+    default = torch.get_num_threads()
+    tried = {}
+    try:
+        for th_ in sorted({default, min(16, default)}, reverse=True):
+            tried[th_] = run(th_)
+    finally:
+        torch.set_num_threads(default)
+    cores = min(tried, key=lambda k: tried[k][0])
+    med, steps = tried[cores]
     return {"value": round(1.0 / med, 4), "unit": "steps/s", "cores": int(cores), "kind": "port",
-            "sample": f"BASELINE C1: 3 DDIM-50 steps at batch 2 (DiTRotary_XL_8, torch CPU fp32, {cores} threads), median {med:.2f} s/step "
-                      f"(steps: {', '.join(f'{v:.2f}' for v in times[1:])} s)"}
+            "sample": f"BASELINE C1: 3 DDIM-50 steps at batch 2 (DiTRotary_XL_8, torch CPU fp32 restatement), median {med:.2f} s/step with "
+                      f"{cores} threads (steps: {', '.join(f'{v:.2f}' for v in steps)} s); "
+                      + "; ".join(f"{k} threads: {v[0]:.2f} s/step" for k, v in tried.items())}
 
 
 def uint8_flip_record(device):

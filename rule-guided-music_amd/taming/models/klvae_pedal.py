@@ -49,6 +49,42 @@ class DiagonalGaussianDistribution:
         return self.mean
 
 
+def read_lightning_state_dict(path):
+    """["state_dict"] of a torch / pytorch-lightning checkpoint without importing what else it pickles: tensors and plain
+    containers load normally (weights_only first); if the file references classes this stack does not have (Lightning
+    callbacks, omegaconf nodes), it is re-read with an unpickler that replaces every global outside torch / collections /
+    numpy by an inert stub -- only tensor storage is ever materialised."""
+    import pickle
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception:
+        class _Stub:
+            def __init__(self, *a, **k):
+                pass
+
+            def __setstate__(self, state):
+                pass
+
+            def __call__(self, *a, **k):
+                return _Stub()
+
+        class _Unpickler(pickle.Unpickler):
+            def find_class(self, module, name):
+                if module.split(".")[0] in ("torch", "collections", "numpy", "builtins", "_codecs"):
+                    return super().find_class(module, name)
+                return type(name, (_Stub,), {"__module__": module})
+
+        class _Pickle:
+            Unpickler = _Unpickler
+            load = staticmethod(lambda f, **kw: _Unpickler(f, **kw).load())
+            __name__ = "pickle"
+        obj = torch.load(path, map_location="cpu", weights_only=False, pickle_module=_Pickle)
+    sd = obj["state_dict"] if isinstance(obj, dict) and "state_dict" in obj else obj
+    if not isinstance(sd, dict) or not all(torch.is_tensor(v) for v in sd.values()):
+        raise ValueError(f"{path}: no tensor state_dict found")
+    return dict(sd)
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, ddconfig=None, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
                  colorize_nlabels=None, monitor=None):
@@ -75,10 +111,23 @@ class AutoencoderKL(nn.Module):
             self.init_from_ckpt(ckpt_path, ignore_keys=list(ignore_keys))
 
     def init_from_ckpt(self, path, ignore_keys=list()):
-        sd = torch.load(path, map_location="cpu")["state_dict"]
+        """Restore a Lightning checkpoint's ["state_dict"] (reference klvae_pedal.py:50-59).  The reference's VAE checkpoint
+        is a pytorch-lightning 1.0.8 file: besides the tensors it pickles callback classes / omegaconf containers that this
+        stack does not ship, so it is read with an unpickler that stubs every non-torch global (read_lightning_state_dict);
+        every decoder / post_quant_conv (and, when present, encoder / quant_conv) parameter must be found -- a key mismatch
+        raises instead of leaving layers at their random initialisation."""
+        sd = read_lightning_state_dict(path)
         sd = {k: v for k, v in sd.items() if not any(k.startswith(ik) for ik in ignore_keys)}
-        own = set(self.state_dict().keys())
-        self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)   # encoder./loss. keys are not ours
+        own = self.state_dict()
+        have_encoder = any(k.startswith("encoder.") for k in sd)
+        need = [k for k in own if not (k.startswith(("encoder.", "quant_conv.")) and not have_encoder)]
+        missing = [k for k in need if k not in sd]
+        if missing:
+            raise KeyError(f"{path}: {len(missing)} AutoencoderKL parameters are missing from the checkpoint, e.g. {missing[:4]}")
+        bad = [k for k in need if tuple(sd[k].shape) != tuple(own[k].shape)]
+        if bad:
+            raise ValueError(f"{path}: shape mismatch for {bad[:4]} (kl/f8-all-onset expects {tuple(own[bad[0]].shape)})")
+        self.load_state_dict({k: sd[k] for k in need}, strict=False)          # loss.* (discriminator) keys are not ours
         print(f"Restored from {path}")
 
     def _apply(self, fn, *a, **k):

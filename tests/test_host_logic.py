@@ -337,3 +337,44 @@ def test_every_shipped_config_has_the_reference_name_and_usable_targets():
                 assert name.replace("_pixel", "") in rules or name in rules, (rel, name)   # without a classifier: never loaded, as in the reference)
         if getattr(cfg.sampling, "use_ddim", False) and hasattr(cfg.sampling, "timestep_respacing"):
             assert cfg.sampling.timestep_respacing.startswith("ddim")
+
+
+class _FakeLightningCallback:
+    """stands for pytorch_lightning.callbacks.ModelCheckpoint, the class object Lightning 1.0.x pickles as a dict KEY"""
+
+
+def test_vae_checkpoint_reader_stubs_lightning_globals_and_checks_key_coverage(tmp_path):
+    """ADVICE r1: the reference's VAE checkpoint is a pytorch-lightning file whose `callbacks` dict is keyed by a class object;
+    the reader must extract ["state_dict"] without that class being importable, and a key mismatch must raise (not leave the
+    decoder at its random initialisation)."""
+    import pickle
+    import types
+    from rgm import synth
+    from taming.models import klvae_pedal
+    sd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(2, encoder=True).items()}
+    sd["loss.discriminator.main.0.weight"] = torch.zeros(4)
+    mod = types.ModuleType("pl_fake_callbacks")
+    mod.ModelCheckpoint = _FakeLightningCallback
+    _FakeLightningCallback.__module__, _FakeLightningCallback.__qualname__, _FakeLightningCallback.__name__ = "pl_fake_callbacks", "ModelCheckpoint", "ModelCheckpoint"
+    sys.modules["pl_fake_callbacks"] = mod
+    path = str(tmp_path / "epoch_14.ckpt")
+    try:
+        torch.save({"epoch": 14, "callbacks": {_FakeLightningCallback: {"best": 0.1}}, "state_dict": sd,
+                    "hyper_parameters": _FakeLightningCallback()}, path)
+    finally:
+        del sys.modules["pl_fake_callbacks"]                   # the class is NOT importable when the file is read
+    with pytest.raises(Exception):
+        torch.load(path, map_location="cpu", weights_only=True)
+    got = klvae_pedal.read_lightning_state_dict(path)
+    assert set(got) == set(sd) and torch.equal(got["decoder.conv_in.weight"], sd["decoder.conv_in.weight"])
+    vae = klvae_pedal.AutoencoderKL(ckpt_path=path)
+    assert torch.equal(vae.state_dict()["decoder.mid.attn_1.q.weight"], sd["decoder.mid.attn_1.q.weight"])
+    bad = {("dec." + k[8:] if k.startswith("decoder.") else k): v for k, v in sd.items()}
+    path2 = str(tmp_path / "renamed.ckpt")
+    torch.save({"state_dict": bad}, path2)
+    with pytest.raises(KeyError):
+        klvae_pedal.AutoencoderKL(ckpt_path=path2)
+    dec_only = {k: v for k, v in sd.items() if not k.startswith(("encoder.", "quant_conv."))}
+    path3 = str(tmp_path / "decoder_only.ckpt")
+    torch.save({"state_dict": dec_only}, path3)
+    klvae_pedal.AutoencoderKL(ckpt_path=path3)                  # a decoder-only checkpoint still restores (decode path)
