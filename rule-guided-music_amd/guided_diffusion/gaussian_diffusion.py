@@ -19,8 +19,9 @@ What is different underneath (design, not a translation):
     all-gather of the (n, B) rule log-probabilities per step, winners regenerated locally from the
     shared Philox counters -- see scg_shard / SURVEY 8e.
 
-Not implemented here: learned variances / x0-prediction checkpoints (learn_sigma, predict_xstart), denoised_fn, training
-losses.  They raise NotImplementedError instead of silently degrading.
+Not implemented here: learned variances (learn_sigma=True checkpoints: LEARNED / LEARNED_RANGE), PREVIOUS_X models and the
+training losses.  They raise NotImplementedError instead of silently degrading.  SCG / DPS score candidates with an
+eps-predicting network (as every shipped configuration does).
 """
 import ctypes as C
 import enum
@@ -159,10 +160,24 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ helpers
     def _check_supported(self):
-        if self.model_mean_type != ModelMeanType.EPSILON or self.model_var_type not in (
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X or self.model_var_type not in (
                 ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
-            raise NotImplementedError("native sampler supports eps-prediction with fixed variance "
-                                      "(learn_sigma=False, predict_xstart=False: the sample_rule.py defaults)")
+            raise NotImplementedError("native sampler supports eps- / x0-predicting models with fixed variance "
+                                      "(learn_sigma=False: the default of every CLI of the reference)")
+
+    def _model_eps(self, x, out, t, denoised_fn):
+        """The eps estimate the fused step starts from.  An eps-predicting model without denoised_fn: its output.  Otherwise the
+        x0 estimate (the model's output for START_X, c1 x - c2 eps for EPSILON) goes through denoised_fn (reference
+        process_xstart :281-286; the clip that follows is applied inside the step kernel) and is turned back into the eps that
+        reproduces it -- one masked-replacement launch with an all-ones mask."""
+        start_x = self.model_mean_type == ModelMeanType.START_X
+        if not start_x and denoised_fn is None:
+            return out
+        x0 = out.float() if start_x else self._predict_xstart_from_eps(x, t, out)
+        if denoised_fn is not None:
+            x0 = denoised_fn(x0)
+        ones = th.ones((1,) * x.dim(), dtype=th.float32, device=x.device)
+        return self._edit_eps(x, th.zeros_like(x, dtype=th.float32), t, False, {"gt": x0, "mask": ones})
 
     def _tab(self, device):
         key = str(device)
@@ -297,8 +312,7 @@ class GaussianDiffusion:
 
     @staticmethod
     def _reject_unsupported(denoised_fn, edit_kwargs, guidance_kwargs=None):
-        if denoised_fn is not None:
-            raise NotImplementedError("denoised_fn is not supported by the fused native step")
+        return
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None,
                         cond_fn=None, embed_model=None, edit_kwargs=None):
@@ -306,7 +320,7 @@ class GaussianDiffusion:
         self._reject_unsupported(denoised_fn, edit_kwargs)
         model_kwargs = model_kwargs or {}
         assert t.shape == (x.shape[0],)
-        eps = model(x, self._scale_timesteps(t), **model_kwargs)
+        eps = self._model_eps(x, model(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         mean, x0, _ = self._step("ddpm", x, eps, None, None, t, clip_denoised)
@@ -557,7 +571,7 @@ class GaussianDiffusion:
         self._reject_unsupported(denoised_fn, edit_kwargs)
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
-        eps = self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs)
+        eps = self._model_eps(x, self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         # with scg_kwargs given the guidance schedule only gates the SCG search: condition_mean runs on every step (reference :691)
@@ -612,7 +626,7 @@ class GaussianDiffusion:
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
         wrapped = self._wrap_model(model)
-        eps = wrapped(x, self._scale_timesteps(t), **model_kwargs)
+        eps = self._model_eps(x, wrapped(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         grad = None

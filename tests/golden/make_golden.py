@@ -718,6 +718,36 @@ def g_next2():
     save("next2", **out)
 
 
+def g_hooks():
+    """denoised_fn (applied to the x0 estimate before clipping, reference :281-286) and x0-predicting models
+    (predict_xstart=True -> ModelMeanType.START_X, :323-333): one DDPM and one DDIM step each, SM backbone."""
+    print("[hooks: denoised_fn, predict_xstart]")
+    m, sd = ref_dit(SM, 11)
+    mf = ref_model_fn(m, 3, True)
+    rng = np.random.RandomState(1700)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    out = {"x": x, "y": y}
+
+    def dfn(v):
+        return v.clamp(-0.5, 0.5) * 0.9
+    for tag, rs, ddim, ti, px in (("dfn_ddpm", "", False, 300, False), ("dfn_ddim", "ddim50", True, 12, False),
+                                  ("x0_ddpm", "250", False, 77, True), ("x0_ddim", "ddim50", True, 33, True)):
+        d = rsu.create_diffusion(learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs, use_kl=False,
+                                 predict_xstart=px, rescale_timesteps=False, rescale_learned_sigmas=False)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        kw = dict(clip_denoised=True, denoised_fn=None if px else dfn, model_kwargs={"y": torch.from_numpy(y)})
+        r = (d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), eta=1.0, **kw) if ddim
+             else d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), **kw))
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].numpy(), f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
+        print(f"    {tag}: sample range {r['sample'].min().item():.3f} .. {r['sample'].max().item():.3f}")
+    save("hooks", **out)
+
+
 def g_configs():
     """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
     checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
@@ -1151,7 +1181,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "configs"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "configs"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1176,6 +1206,8 @@ if __name__ == "__main__":
         g_cli2(vae)
     if "next2" in which:
         g_next2()
+    if "hooks" in which:
+        g_hooks()
     if "configs" in which:
         g_configs()
     if "collage" in which:

@@ -16,6 +16,9 @@ def dev(a, dtype=None):
 
 
 def rel(a, b):
+    """NORM-WISE relative error max|a - b| / max|b| -- the measure every "rel" tolerance of the GPU tests (and the north
+    star's "latents within 1e-3 rel") is stated in.  It bounds the error relative to the tensor's scale; entries much smaller
+    than the largest one are constrained absolutely (to tol * max|b|), not relatively."""
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))

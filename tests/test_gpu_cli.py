@@ -96,7 +96,7 @@ def test_edit_cli_reads_a_midi_source(tmp_path, monkeypatch):
     cfg_src = os.path.join(CFG, "edit", "nd_scg_given_target.yml")
     cfg = os.path.join(str(tmp_path), "configs", "edit", "nd_midi.yml")
     os.makedirs(os.path.dirname(cfg))
-    text = open(cfg_src).read().replace("noise_level: 500", "noise_level: 12").replace("source: synthetic", f"source: {src}")
+    text = open(cfg_src).read().replace("noise_level: 500", "noise_level: 12").replace("source: dataset", f"source: {src}")
     open(cfg, "w").write(text)
     res, sample = cli.main(["--config_path", cfg, "--batch_size", "1", "--num_samples", "1", "--diffusion_steps", "24"] + COMMON)
     assert len(res) == 1 and np.isfinite(res["note_density.loss"]).all()

@@ -272,3 +272,23 @@ def test_two_step_sample_rule_cli_reproduces_the_reference_roll_and_losses(tmp_p
         tol = 1e-6 if "target_rule" in col else 2e-3
         assert np.abs(a - b).max() <= tol * (np.abs(b).max() + 1e-30), (col, a, b)
     print(f"[cli2 {precision}] uint8 mismatches {bad.sum()} / {bad.size}; losses {res.filter(like='.loss').values.tolist()}")
+
+
+@pytest.mark.parametrize("tag,rs,ddim,px", [("dfn_ddpm", "", False, False), ("dfn_ddim", "ddim50", True, False),
+                                           ("x0_ddpm", "250", False, True), ("x0_ddim", "ddim50", True, True)])
+def test_denoised_fn_and_x0_predicting_models(tag, rs, ddim, px, precision):
+    """denoised_fn (applied to the x0 estimate before the clip, reference :281-286) and predict_xstart=True (ModelMeanType.START_X,
+    :323-333) through the fused step, against the reference's outputs."""
+    from gpu_util import dev, rel
+    from guided_diffusion.script_util import create_diffusion
+    g = load_golden("hooks")
+    m = _dit(SM, 11)
+    d = create_diffusion(learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs, use_kl=False,
+                         predict_xstart=px, rescale_timesteps=False, rescale_learned_sigmas=False)
+    d.t_end = 0
+    _inject(d, g[f"{tag}.noise"])
+    kw = dict(clip_denoised=True, denoised_fn=None if px else (lambda v: v.clamp(-0.5, 0.5) * 0.9), model_kwargs={"y": dev(g["y"])})
+    x, t = dev(g["x"]), dev(g[f"{tag}.t"])
+    out = d.ddim_sample(_model_fn(m), x, t, eta=1.0, **kw) if ddim else d.p_sample(_model_fn(m), x, t, **kw)
+    assert rel(out["pred_xstart"].cpu().numpy(), g[f"{tag}.pred_xstart"]) < 2e-4
+    assert rel(out["sample"].cpu().numpy(), g[f"{tag}.sample"]) < 2e-4

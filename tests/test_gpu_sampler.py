@@ -354,3 +354,38 @@ def test_chord_rule_device_preamble_and_host_plugin():
         assert list(df["chord_progression.key_str"]) == [music_rules.IND2KEY[e["key"]] for e in expect]
     finally:
         music_rules.register_chord_backend(None)
+
+
+def test_full_size_guidance_and_scg_decode_are_row_independent(precision):
+    """The shapes the bench runs but the goldens cannot hold: BASELINE config 3's classifier value-and-
+    gradient at B = 32 (DiTRotary-S/8-cls, depth 12) and config 4's SCG decode of 512 latent squares (B = 4, n = 16) at once.
+    Size-independent property: every row of the big call equals the same row computed in a batch of 2 (other tiles, grids and
+    kernels -- same per-row arithmetic), which the goldens pin."""
+    from gpu_util import dev, load_module, rel
+    from guided_diffusion.dit import DiTRotaryClassifier
+    arch = dict(depth=12, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=16)
+    clf = load_module(DiTRotaryClassifier(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=12, num_heads=6,
+                                          num_classes=16), synth.dit_state_dict(3, **arch))
+    rng = np.random.RandomState(91)
+    x = dev(rng.randn(32, 4, 128, 16).astype(F32))
+    t = dev(rng.randint(0, 1000, size=32).astype(np.int64))
+    tgt = dev((rng.rand(32, 16) * 4).astype(F32))
+    logits, grad = clf.value_and_grad(x, t, tgt, "mse", 10.0)
+    tol = 2e-6 if precision == "fp32" else 3e-5
+    for i in (0, 14, 30):
+        l2, g2 = clf.value_and_grad(x[i:i + 2].contiguous(), t[i:i + 2].contiguous(), tgt[i:i + 2].contiguous(), "mse", 10.0)
+        assert rel(logits[i:i + 2].cpu().numpy(), l2.cpu().numpy()) < tol, i
+        assert rel(grad[i:i + 2].cpu().numpy(), g2.cpu().numpy()) < 10 * tol, i
+    vae = _vae(2)
+    z = dev(rng.randn(512, 4, 16, 16).astype(F32))
+    dec = vae.decode(z)
+    assert dec.shape == (512, 3, 128, 128)
+    for i in (0, 255, 510):
+        assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < 2e-6, i
+    # and the latent-shaped path SCG uses (64 candidates x 8 squares, segment-major gather inside the kernel)
+    from guided_diffusion.gaussian_diffusion import _decode
+    lat = dev(rng.randn(64, 4, 128, 16).astype(F32))
+    roll = _decode(lat, vae, scale_factor=1.2465)
+    assert roll.shape == (64, 3, 128, 1024)
+    for i in (0, 33, 62):
+        assert rel(roll[i:i + 2].cpu().numpy(), _decode(lat[i:i + 2].contiguous(), vae, scale_factor=1.2465).cpu().numpy()) < 2e-6, i
