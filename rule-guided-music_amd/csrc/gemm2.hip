@@ -1016,7 +1016,29 @@ int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total
   return RGM_OK;
 }
 
+// raw per-launch records of the pre-split kernels, in launch order (tools/insitu_probe.py): kernel id, milliseconds, FLOPs
+int gemm2_prof_dump(int cap, int* ids, double* ms, double* flops) {
+  int n = 0;
+  for (auto& r : g2_prof) {
+    if (n >= cap) break;
+    if (hipEventSynchronize(r.b) != hipSuccess) break;
+    float e = 0.f;
+    if (hipEventElapsedTime(&e, r.a, r.b) != hipSuccess) break;
+    ids[n] = r.tile;
+    ms[n] = e;
+    flops[n] = r.flops;
+    ++n;
+  }
+  return n;
+}
+
 }  // namespace rgm
+
+// Profiling aid: the per-launch records behind rgm_prof_report for the pre-split GEMM kernels, in launch order; returns the count.
+extern "C" int rgm_prof_dump(int cap, int* ids, double* ms, double* flops) {
+  if (!ids || !ms || !flops || cap <= 0) return 0;
+  return rgm::gemm2_prof_dump(cap, ids, ms, flops);
+}
 
 // Split a (rows, K) fp32 matrix into the split-row format consumed by rgm_gemm_split (out-of-place).
 extern "C" int rgm_split_rows(const float* x, float* out, int64_t rows, int K, void* stream) {
