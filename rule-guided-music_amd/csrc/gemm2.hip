@@ -879,7 +879,31 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
                            ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
                            (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate | (uintptr_t)p.aux) & 15) == 0),
               "gemm2: GroupNorm partial sums need 128-row tiles, N%%64==0, group width 4/8/16 and 16-byte aligned rows");
-  const int S = (p.stats ? 1 : splitk_factor(p));
+  int S = (p.stats ? 1 : splitk_factor(p));
+  int sk_tile = 44;
+  if (S == 1 && p.tile == 0 && p.sk_ws && !p.stats && !p.aload && p.batch == 1 && p.act < 3 && (p.K >> 5) >= 96 &&
+      ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0) {
+    // long-K GEMM on a grid that leaves the second 128x128 workgroup slot of most CUs empty (fc2 at B = 16: 288 tiles on 512
+    // slots, 144 K-tiles each): K slices as a batch fill whole rounds.  Cost model in K-tile times, from tools/gemm_sweep.py
+    // (fc2: 157 / 162 / 138 / 156 / 158 us at S = 1 / 2 / 3 / 4 / 6): rounds(S) * KT / S plus ~10 per slice for the partial
+    // sums' round trip through the reduce kernel.
+    const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int KT = p.K >> 5;
+    if (t128 >= 192 && t128 < 512) {
+      double best = (double)KT;                    // unsplit: one (partial) round of KT K-tiles
+      for (int c = 2; c <= 6; ++c) {
+        if (KT % c || KT / c < 24) continue;
+        if ((size_t)c * p.M * p.N * sizeof(float) + GEMM_SK_FLAG_BYTES > p.sk_ws_bytes) continue;
+        const double cost = (double)((t128 * c + 511) / 512) * (KT / c) + 10.0 * c;
+        if (cost < best * 0.95) { best = cost; S = c; sk_tile = 43; }
+      }
+    }
+  }
+  if (p.tile >= 200 && p.tile < 217 && p.sk_ws && !p.stats) {   // experiments: 200 + S slices on 128x128 tiles (tools/gemm_sweep.py)
+    S = p.tile - 200;
+    sk_tile = 43;
+    RGM_REQUIRE(S >= 2 && (p.K >> 5) % S == 0, "gemm2: K-tiles %d do not divide into %d slices", p.K >> 5, S);
+  }
   if (S > 1) {
     const size_t need = (size_t)S * p.M * p.N * sizeof(float);
     RGM_REQUIRE(p.sk_ws_bytes >= GEMM_SK_FLAG_BYTES + need, "gemm2: split-K scratch %zu bytes < %zu", p.sk_ws_bytes, GEMM_SK_FLAG_BYTES + need);
@@ -891,7 +915,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     q.C = partial; q.ldc = p.N; q.sC = (long long)p.M * p.N;
     q.sk_ws = nullptr; q.sk_ws_bytes = 0;
     q.bias = nullptr; q.act = 0; q.alpha = 1.0f; q.gate = nullptr; q.res = nullptr; q.out_split = 0;
-    q.tile = 44;
+    q.tile = sk_tile;
     RGM_TRY(gemm2_launch(q, s));
     const long long total4 = (long long)p.M * (p.N >> 2);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)partial, p, S);

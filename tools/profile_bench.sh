@@ -12,8 +12,8 @@ OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$TAG
-timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o $TAG -- python $ROOT/bench.py --no-extras "$@" > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.log
-f=$(find /tmp/prof_$TAG -name "*kernel_stats.csv" | head -1)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o $TAG -- python $ROOT/bench.py --no-extras "$@" > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/${TAG}_bench_under_rocprof.log
+find /tmp/prof_$TAG -type f | head -20 >&2; f=$(find /tmp/prof_$TAG -name "*kernel_stats*.csv" | head -1)
 [ -n "$f" ] && cp "$f" $OUT/${TAG}_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE"; do
   d=/tmp/pmc_${TAG}_$(echo $c | cut -c1-10 | tr ' ' '_')
