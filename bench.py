@@ -466,11 +466,19 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     assert world == args.gpus, f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)"
+    # RGM_BENCH_ONE_DEVICE=1 (plumbing test on a 1-GPU box only): every rank uses cuda:0 and the collectives run over gloo --
+    # exercises the N > 1 control flow, never a measurement (the JSON says so)
+    one_dev = os.environ.get("RGM_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        if one_dev:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
         world = dist.get_world_size()                            # n_gpus = the RCCL world that actually runs
 
     from rgm import native as R
@@ -534,7 +542,7 @@ def main():
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
             "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else f"f32 via {args.precision} split (3 bf16 MFMA per product, fp32 accumulate)",
-            "data": "synthetic",
+            "data": "synthetic" if not one_dev else "synthetic [PLUMBING TEST: all ranks on one device over gloo -- not a measurement]",
             "config": {"workload": work.name + (f" [SIMULATED rank 0 of {args.simulate_ranks}: per-rank work only, no fabric]"
                                                 if args.simulate_ranks > 1 else ""), "batch_per_gpu": batch, "sample_steps_per_s": round(units * batch / dt, 2),
                        "weights": "synthetic random-init (rgm.synth seed 1; adaLN/final layers re-randomised)",

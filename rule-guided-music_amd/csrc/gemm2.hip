@@ -33,9 +33,11 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
+// the kernel body: output tile `bid` (raster order) of batch element `z`.  A function so that ONE launch can mix tile shapes
+// (gemm2_dual_kernel below); gemm2_kernel is the plain one-shape wrapper.
 template <int BM, int BN, int WM, int WN, int ALOAD, int NSTAGE, int DBG = 0, int PIPE = 0>
-__global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m,
-                                                            int tiles_n, int exp, long long* __restrict__ dbg = nullptr) {
+__device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __restrict__ zero_page, int tiles_m, int tiles_n, int exp,
+                                           long long* __restrict__ dbg, const int bid, const int z, const int rec_bid) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int STAGE = (BM + BN) * 128;        // bytes per ring stage: BM A rows then BN B rows, one 128-B line each
@@ -51,7 +53,6 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
 
   // ---- blockIdx -> tile (same XCD-contiguous grouped raster as gemm.hip)
   const int nb = tiles_m * tiles_n;
-  const int bid = blockIdx.x;
   const int xcd = bid & 7, loc = bid >> 3, q = nb >> 3, r = nb & 7;
   const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   constexpr int GROUP = 8;
@@ -62,7 +63,6 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
   const int in_g = sid - grp * per_group;
   const int m0 = (first_m + in_g % gsz) * BM;
   const int n0 = (in_g / gsz) * BN;
-  const int z = blockIdx.z;
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
 
   // DBG: per-wave s_memtime deltas summed over the K loop (segments: DMA wait, barrier, DMA issue, read0, mfma0, read1, mfma1)
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;
-  const bool rec = DBG && blockIdx.x == (gridDim.x >> 1);
+  const bool rec = DBG && bid == rec_bid;
 #define RGM_STAMP(i)                                               \
   if (DBG) {                                                       \
     __builtin_amdgcn_sched_barrier(0);                             \
@@ -732,6 +732,27 @@ __global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kerne
 #undef RGM_STAMP
 }
 
+template <int BM, int BN, int WM, int WN, int ALOAD, int NSTAGE, int DBG = 0, int PIPE = 0>
+__global__ __launch_bounds__(WM* WN * 64 * (PIPE == 4 ? 2 : 1)) void gemm2_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m,
+                                                            int tiles_n, int exp, long long* __restrict__ dbg = nullptr) {
+  gemm2_body<BM, BN, WM, WN, ALOAD, NSTAGE, DBG, PIPE>(p, zero_page, tiles_m, tiles_n, exp, dbg, (int)blockIdx.x, (int)blockIdx.z,
+                                                       (int)(gridDim.x >> 1));
+}
+
+// Two tile shapes in ONE launch: workgroups [0, nbig) compute 128x128 tiles of `pb` (whole CU-rounds of the big tile, the
+// efficient shape), workgroups [nbig, gridDim.x) compute SBM x SBN tiles of `ps` (the leftover columns).  Workgroups are
+// dispatched in index order, so the launch ENDS on small tiles: the last, partly filled round costs a fraction of a big
+// tile's time instead of a whole one (fc1 at B = 16: 1024 + 128 tiles of 128x128 = 2.25 rounds that cost ~3; here 2 rounds
+// + 256 tiles of 128x64).  No K split, no partial sums: every output element is still one workgroup's fixed-order sum.
+template <int SBM, int SBN>
+__global__ __launch_bounds__(256) void gemm2_dual_kernel(GemmParams pb, GemmParams ps, const char* __restrict__ zero_page, int tmb, int tnb,
+                                                         int tms, int tns, int nbig, int exp) {
+  if ((int)blockIdx.x < nbig)
+    gemm2_body<128, 128, 2, 2, 0, 2, 0, 3>(pb, zero_page, tmb, tnb, exp, nullptr, (int)blockIdx.x, 0, -1);
+  else
+    gemm2_body<SBM, SBN, 2, 2, 0, (SBM == 64 ? 3 : 2), 0, 3>(ps, zero_page, tms, tns, exp, nullptr, (int)blockIdx.x - nbig, 0, -1);
+}
+
 static char* g_zero_page = nullptr;
 static long long* g_dbg = nullptr;   // set by rgm_gemm2_dbg: stamped kernel variant (tools/gemm_stamp.py)
 // timing experiments only (wrong results): RGM_GEMM2_EXP=1 no DMA after the prologue, =2 DMA + barriers only
@@ -796,6 +817,49 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     RGM_CHECK_HIP(hipEventRecord(rec.b, s));
     g2_prof.push_back(rec);
   }
+  return RGM_OK;
+}
+
+// big + small tiles in one launch (gemm2_dual_kernel): returns the number of leading columns that fill whole rounds of 512
+// 128x128 workgroups when the columns left over are at most 0.3 round -- otherwise 0 (tools/gemm_sweep.py, tile code 48)
+static int dual_big_columns(const GemmParams& p) {
+  if (p.aload || p.batch != 1 || p.stats || p.act >= 3 || (p.M & 127) || (p.N & 127)) return 0;
+  const int tm = p.M >> 7, tn = p.N >> 7;
+  int best = 0;
+  for (int c = tn - 1; c >= 1; --c) {              // c big column-tiles: tm * c must be whole rounds
+    if (((long long)tm * c) % 512) continue;
+    const long long left = (long long)tm * (tn - c);
+    if (left <= 154) best = c * 128;               // <= 0.3 round of big tiles left
+    break;
+  }
+  return best;
+}
+
+template <int SBM, int SBN>
+static int launch_dual(const GemmParams& p, int nb_cols, hipStream_t s) {
+  if (!g_zero_page) {
+    RGM_CHECK_HIP(hipMalloc(&g_zero_page, 4096));
+    RGM_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
+  }
+  GemmParams pb = p, ps = p;
+  pb.N = nb_cols;
+  ps.N = p.N - nb_cols;
+  ps.B = p.B + (long long)nb_cols * p.ldb;
+  ps.C = p.C + nb_cols;                            // split-row output: a 128-column block is 128 floats wide as well
+  if (p.bias) ps.bias = p.bias + nb_cols;
+  if (p.res) ps.res = p.res + nb_cols;
+  if (p.gate) ps.gate = p.gate + nb_cols;
+  const int tmb = cdiv(pb.M, 128), tnb = cdiv(pb.N, 128), tms = cdiv(ps.M, SBM), tns = cdiv(ps.N, SBN);
+  auto k = gemm2_dual_kernel<SBM, SBN>;
+  static bool attr = false;
+  if (!attr) {
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    attr = true;
+  }
+  const int rec = gemm2_prof_begin(88, 2.0 * p.M * (double)p.N * p.K, s);
+  hipLaunchKernelGGL(k, dim3(tmb * tnb + tms * tns), dim3(256), 65536, s, pb, ps, (const char*)g_zero_page, tmb, tnb, tms, tns, tmb * tnb, g_exp);
+  RGM_LAUNCH_CHECK();
+  gemm2_prof_end(rec, s);
   return RGM_OK;
 }
 
@@ -923,6 +987,14 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     return RGM_OK;
   }
   int tile = p.tile;
+  if (tile == 48 || tile == 49) {   // whole rounds of 128x128 tiles + the leftover columns on 128x64 (48) / 64x64 (49) in one launch.
+    // Not the heuristic's choice: fc1 at B = 16 runs 129-135 us this way in isolation (tools/gemm_sweep.py; 145 / 152 us for the
+    // one-shape 128x128 / 128x64 launches) but 162-166 us inside the forward, where the 128x64 launch holds 149 us
+    // (tools/insitu_probe.py: operands from the Infinity Cache / HBM favour 3 workgroups per CU).
+    const int nb_cols = dual_big_columns(p);
+    RGM_REQUIRE(nb_cols > 0, "gemm2: tile %d (big + small tiles) does not apply to M=%d N=%d", tile, p.M, p.N);
+    return tile == 49 ? launch_dual<64, 64>(p, nb_cols, s) : launch_dual<128, 64>(p, nb_cols, s);
+  }
   if (tile == 0 && gemm4_eligible(p)) tile = 47;   // >= 1.5 CU-rounds of 128x128 tiles: equal K-tile ranges per workgroup (gemm4.hip)
   if (tile == 0) {
     // tools/gemm_sweep.py on MI355X: cross-iteration pipeline (PIPE 3) at 128x128 (2 workgroups per CU) once the grid

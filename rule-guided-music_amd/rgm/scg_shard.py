@@ -34,7 +34,7 @@ def gather_totals(total_local):
     """(n/R, B) float32 per rank -> (n, B) on every rank, rank-major (== candidate order)."""
     R, _ = world()
     total_local = total_local.contiguous()
-    if total_local.is_cuda:                      # RCCL: one all-gather straight into the (n, B) table
+    if total_local.is_cuda and dist.get_backend() == "nccl":   # RCCL: one all-gather straight into the (n, B) table
         out = torch.empty((R * total_local.shape[0],) + tuple(total_local.shape[1:]), dtype=total_local.dtype, device=total_local.device)
         dist.all_gather_into_tensor(out, total_local)
         return out

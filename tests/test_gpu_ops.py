@@ -236,3 +236,27 @@ def test_streamk_gemm_gate_and_residual_in_place():
     torch.cuda.synchronize()
     # no gate / residual through this entry: the plain product first ...
     assert rel(x.cpu().numpy(), _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)) < 3e-5
+
+
+@pytest.mark.parametrize("tile", [48, 49])
+@pytest.mark.parametrize("M,N,K,act,split", [(4096, 4608, 1152, 2, 1), (4096, 4608, 1152, 0, 0), (8192, 2304, 256, 1, 0)])
+def test_gemm_big_and_small_tiles_in_one_launch(tile, M, N, K, act, split):
+    """gemm2_dual_kernel (tiles 48 / 49; an explicit choice, see gemm2_launch): whole CU-rounds of 128x128 tiles plus the
+    leftover columns on 128x64 / 64x64 tiles in the same launch -- every element is still ONE workgroup's K loop, so the result
+    is bit-identical to the one-shape kernels wherever the per-element arithmetic is (same K order)."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    rng = np.random.RandomState(M + N + K + tile)
+    A = rng.randn(M, K).astype(F32)
+    B = (rng.randn(N, K) * 0.05).astype(F32)
+    bias = rng.randn(N).astype(F32)
+    As, Bs, bd = _split(A), _split(B), dev(bias)
+    st = R.current_stream()
+    c = torch.full((M, N), float("nan"), device="cuda")
+    R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(c), M, N, K, R.ptr(bd), act, tile, split, st))
+    c2 = torch.full((M, N), float("nan"), device="cuda")
+    R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(c2), M, N, K, R.ptr(bd), act, 43, split, st))
+    torch.cuda.synchronize()
+    got = _unsplit(c) if split else c.cpu().numpy()
+    assert rel(got, _ref_gemm(A, B, bias, act, 1.0, None, 1, None)) < 3e-5
+    assert np.array_equal(got, _unsplit(c2) if split else c2.cpu().numpy())       # same per-element K order as the 128x128 kernel
