@@ -422,6 +422,23 @@ def scg_record(device, world, rank, dist, steps=5, warmup=2):
             "algorithmic_tflops": round(work.flop_per_step * steps / dt / 1e12, 2)}
 
 
+def c3_sharded_record(device, world, dist, steps=5, warmup=2):
+    """BASELINE config[2] shape (classifier guidance, '250' chain, batch 32) as ONE chain whose batch is sharded over the ranks
+    (rgm/batch_shard.py: rank r computes rows [r*B/R, (r+1)*B/R), one all-gather of x_{t-1} per step): strong scaling."""
+    work = C3Workload(device, 32)
+    work.d.batch_shard = True
+    for _ in range(warmup):
+        work.step()
+    dt, _ = time_steps(work, steps, world, dist)
+    mine = work.x.contiguous()
+    allx = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(allx, mine)
+    same = all(bool(torch.equal(allx[0], m)) for m in allx)
+    return {"workload": work.name + " [one chain, batch rows sharded over the ranks]", "scaling": "strong", "ranks": world,
+            "rows_per_rank": 32 // world if 32 % world == 0 else 32, "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3),
+            "steps_per_s": round(steps / dt, 4), "same_latents_on_every_rank": bool(same)}
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torchrun: re-execute through torch.distributed.run, one rank per GPU, on 127.0.0.1."""
     import socket
@@ -495,6 +512,8 @@ def main():
         Rn = args.simulate_ranks
         scg_shard.partition = lambda n, world_size=None, rank=None: (0, n // Rn, True) if n % Rn == 0 else (0, n, False)
         scg_shard.gather_totals = lambda local: local.repeat(Rn, 1)     # same table shape and selection work as the real all-gather
+    if args.workload in ("c2", "c3", "dps_rule"):
+        work.d.batch_shard = False            # the headline runs one independent chain per GPU (weak scaling): nothing to shard
     for _ in range(args.warmup):
         work.step()
     regions = [time_steps(work, args.steps, world, dist) for _ in range(max(1, args.repeats))]
@@ -529,6 +548,8 @@ def main():
                     "ms_per_step": round(1e3 * d32 / k, 3), "roofline": r32}
         attempt("fp32_exact", fp32_exact)
         attempt("scg", lambda: scg_record(device, world, rank, dist))
+        if world > 1:
+            attempt("c3_batch_sharded", lambda: c3_sharded_record(device, world, dist))
         if rank == 0:
             attempt("uint8_flips", lambda: uint8_flip_record(device))
             if world == 1 and not args.no_cpu_baseline:
@@ -554,7 +575,7 @@ def main():
         if "uint8_flips" in extras:
             res["config"]["uint8_flips"] = extras.pop("uint8_flips")
         res["roofline"] = roof
-        for k in ("fp32_exact", "scg", "cpu_baseline"):
+        for k in ("fp32_exact", "scg", "c3_batch_sharded", "cpu_baseline"):
             if k in extras:
                 res[k] = extras[k]
         print(json.dumps(res), flush=True)

@@ -17,7 +17,9 @@ What is different underneath (design, not a translation):
   * noise is a counter-based Philox stream (rgm_randn); `noise_fn` lets tests inject the reference's draws;
   * scg_sample can shard its candidates over the ranks of torch.distributed (RCCL over xGMI): one
     all-gather of the (n, B) rule log-probabilities per step, winners regenerated locally from the
-    shared Philox counters -- see scg_shard / SURVEY 8e.
+    shared Philox counters -- see scg_shard / SURVEY 8e;
+  * every other step (unguided, classifier-guided, DPS) is batch-parallel: rank r computes rows [r*B/R, (r+1)*B/R) and ONE
+    all-gather of the new latents per step gives every rank the full batch again -- see batch_shard / SURVEY 8e.
 
 Not implemented here: learned variances (learn_sigma=True checkpoints: LEARNED / LEARNED_RANGE), PREVIOUS_X models and the
 training losses.  They raise NotImplementedError instead of silently degrading.  SCG / DPS score candidates with an
@@ -32,7 +34,7 @@ import numpy as np
 import torch as th
 
 from rgm import native as _rgm
-from rgm import scg_shard
+from rgm import batch_shard, scg_shard
 from music_rule_guidance.rule_maps import FUNC_DICT, LOSS_DICT
 
 
@@ -155,6 +157,8 @@ class GaussianDiffusion:
         self.noise_fn = None          # tests: callable(shape, device) -> tensor, called in the reference's draw order
         self.noise = None             # PhiloxNoise, created lazily (seed = torch.initial_seed())
         self.scg_shard = True         # shard SCG candidates over torch.distributed ranks when initialised
+        self.batch_shard = True       # shard the batch of every other step over the ranks (rgm/batch_shard.py)
+        self._rows = None             # (b0, nb, B) while a rank computes its rows of a batch-sharded step
         self._tables = {}
         self._t_host = None
 
@@ -186,12 +190,51 @@ class GaussianDiffusion:
         return self._tables[key]
 
     def _draw(self, shape, device):
+        shape = tuple(shape)
+        rows = self._rows
+        if rows is not None and shape[0] == rows[1]:
+            # inside a batch-sharded step: the draw is the FULL batch's draw (same stream positions on every rank), this rank
+            # materialises its rows only
+            b0, nb, B = rows
+            full = (B,) + shape[1:]
+            if self.noise_fn is not None:
+                return self.noise_fn(full, device).to(device=device, dtype=th.float32)[b0:b0 + nb].contiguous()
+            if self.noise is None:
+                self.noise = PhiloxNoise()
+            per = 1
+            for d in shape[1:]:
+                per *= int(d)
+            base = self.noise.reserve(B * per)
+            return self.noise.fill(shape, device, offset=base + b0 * per)
         if self.noise_fn is not None:
-            z = self.noise_fn(tuple(shape), device)
+            z = self.noise_fn(shape, device)
             return z.to(device=device, dtype=th.float32).contiguous()
         if self.noise is None:
             self.noise = PhiloxNoise()
         return self.noise.fill(shape, device)
+
+    def _batch_sharded(self, step, model, x, t, kw):
+        """Run `step` (p_sample / ddim_sample) on this rank's rows of the batch and all-gather the new latents; None when the step
+        is not sharded (single rank, indivisible batch, an SCG search step -- candidates are sharded instead --, record mode)."""
+        if not self.batch_shard or self._rows is not None or kw.get("record", False):
+            return None
+        B = x.shape[0]
+        b0, nb, sharded = batch_shard.partition(B)
+        if not sharded:
+            return None
+        if kw.get("scg_kwargs") is not None and self._use_guidance(kw.get("guidance_kwargs"), t) and self._t0(t) > self.t_end:
+            return None
+        kw = dict(kw)
+        for key in ("model_kwargs", "edit_kwargs"):
+            if kw.get(key) is not None:
+                kw[key] = batch_shard.slice_rows(kw[key], B, b0, nb)
+        self._rows = (b0, nb, B)
+        try:
+            out = step(model, x[b0:b0 + nb].contiguous(), t[b0:b0 + nb].contiguous(), **kw)
+        finally:
+            self._rows = None
+        sample, x0 = batch_shard.gather_rows([out["sample"].float(), out["pred_xstart"].float()])
+        return {"sample": sample, "pred_xstart": x0}
 
     def _scale_timesteps(self, t):
         return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
@@ -369,11 +412,25 @@ class GaussianDiffusion:
         if not (isinstance(inner_m, functools.partial) and inner_m.func is cf.model_fn):
             raise NotImplementedError("DPS guidance expects model = partial(model_fn, model=DiTRotary, ...)")
         mk = inner_m.keywords
-        if mk.get("cfg", False):
-            raise NotImplementedError("DPS guidance with classifier-free guidance")
         net = mk["model"]
-        y = model_kwargs.get("y") if mk.get("class_cond", True) else cf._null_labels(x, mk.get("num_classes", 3))
-        eps = net.vjp_forward(x, ts_m, y)
+        nc = mk.get("num_classes", 3)
+        w_cfg = float(mk.get("w", 0.)) if (mk.get("cfg", False) and mk.get("class_cond", True)) else None
+        if w_cfg is not None:
+            # classifier-free guidance inside DPS (reference model_fn :22-23 under autograd): eps = (1+w) m(x,y) - w m(x,y_null)
+            # as ONE 2B-row saved-activation forward; the backward runs once with the cotangents (1+w) g | -w g and the two
+            # halves' input gradients add up (both halves see the same x)
+            B_ = x.shape[0]
+            e2 = net.vjp_forward(th.cat([x, x], dim=0), th.cat([ts_m, ts_m], dim=0),
+                                 th.cat([model_kwargs["y"].to(th.int64), cf._null_labels(x, nc)], dim=0))
+            eps = th.add(e2[:B_], e2[:B_] - e2[B_:], alpha=w_cfg)
+
+            def eps_vjp(g_eps):
+                g2 = net.vjp_backward(th.cat([(1.0 + w_cfg) * g_eps, -w_cfg * g_eps], dim=0))
+                return g2[:B_] + g2[B_:]
+        else:
+            y = model_kwargs.get("y") if mk.get("class_cond", True) else cf._null_labels(x, nc)
+            eps = net.vjp_forward(x, ts_m, y)
+            eps_vjp = net.vjp_backward
         x0 = self._predict_xstart_from_eps(x, t, eps)
         rule_kwargs = {k: v for k, v in model_kwargs.items() if k in ("y", "rule")}
         if through_vae:
@@ -390,7 +447,7 @@ class GaussianDiffusion:
             log_probs, g0 = cf.composite_nn_zt_value_and_grad(x0, ts, **rule_kwargs, **inner_c.keywords)
         c1 = self._per_sample(self.sqrt_recip_alphas_cumprod, t, x)
         c2 = self._per_sample(self.sqrt_recipm1_alphas_cumprod, t, x)
-        grad = c1 * g0 + net.vjp_backward(-c2 * g0)
+        grad = c1 * g0 + eps_vjp(-c2 * g0)
         grad = grad / th.sqrt(-log_probs.view(x.shape[0], 1, 1, 1).float() + 1e-12)
         return p_mean_var["mean"].float() + float(guidance_kwargs.step_size) * grad.float()
 
@@ -569,6 +626,11 @@ class GaussianDiffusion:
                  embed_model=None, scale_factor=1., guidance_kwargs=None, scg_kwargs=None, edit_kwargs=None, record=False):
         """One ancestral DDPM step -> {'sample', 'pred_xstart'}."""
         self._reject_unsupported(denoised_fn, edit_kwargs)
+        sharded = self._batch_sharded(self.p_sample, model, x, t, dict(
+            clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, embed_model=embed_model,
+            scale_factor=scale_factor, guidance_kwargs=guidance_kwargs, scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs, record=record))
+        if sharded is not None:
+            return sharded
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
         eps = self._model_eps(x, self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
@@ -623,6 +685,12 @@ class GaussianDiffusion:
                     record=False):
         """One DDIM step (eta = 1 is the stochastic variant the CLI always uses)."""
         self._reject_unsupported(denoised_fn, edit_kwargs)
+        sharded = self._batch_sharded(self.ddim_sample, model, x, t, dict(
+            clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs, eta=eta,
+            embed_model=embed_model, scale_factor=scale_factor, guidance_kwargs=guidance_kwargs, edit_kwargs=edit_kwargs,
+            scg_kwargs=scg_kwargs, record=record))
+        if sharded is not None:
+            return sharded
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
         wrapped = self._wrap_model(model)

@@ -1,0 +1,55 @@
+"""Batch sharding of the non-SCG work over torch.distributed ranks ("classifier guidance and unguided steps are
+batch-parallel: shard B across ranks with an all-gather of x_{t-1}").
+
+A reverse step is independent per sample everywhere outside SCG's candidate search: the eps-network forward, the classifier's
+value-and-gradient, DPS, the fused step update and the noise draw (counter-based: row b of a draw is the same numbers on any
+rank).  Rank r of R therefore computes rows [r*B/R, (r+1)*B/R) of the step and ONE all-gather of the new latents (and the x0
+estimates: 2 x 32 KiB per sample) gives every rank the full batch for the next step.  SCG search steps keep their own split
+(candidates, rgm/scg_shard.py); batches that do not divide by the world size stay replicated.
+
+Pure host logic (no HIP calls): the N > 1 control flow is testable with world_size-2 gloo on CPU.
+"""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def partition(B, world_size=None, rank=None):
+    """(first row, local rows, sharded?) of this rank; replicated when B does not divide evenly."""
+    if world_size is None:
+        world_size, rank = world()
+    if world_size <= 1 or B % world_size != 0:
+        return 0, B, False
+    per = B // world_size
+    return rank * per, per, True
+
+
+def slice_rows(obj, B, b0, nb):
+    """Rows [b0, b0+nb) of every tensor with leading dimension B inside a (nested) dict / list / tuple; other values pass through
+    (per-call scalars, namespaces, tensors broadcast over the batch such as a (1,C,H,W) edit mask)."""
+    if torch.is_tensor(obj):
+        return obj[b0:b0 + nb].contiguous() if obj.dim() >= 1 and obj.shape[0] == B else obj
+    if isinstance(obj, dict):
+        return {k: slice_rows(v, B, b0, nb) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(slice_rows(v, B, b0, nb) for v in obj)
+    return obj
+
+
+def gather_rows(tensors):
+    """[(nb, ...)] per rank, all of one shape / dtype -> [(R*nb, ...)] on every rank, rank-major (= row order): ONE collective."""
+    R, _ = world()
+    local = torch.stack([t.contiguous() for t in tensors], dim=1).contiguous()        # (nb, k, ...)
+    if local.is_cuda and dist.get_backend() == "nccl":
+        out = torch.empty((R * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local)
+    else:
+        parts = [torch.empty_like(local) for _ in range(R)]
+        dist.all_gather(parts, local)
+        out = torch.cat(parts, dim=0)
+    return [out[:, i].contiguous() for i in range(len(tensors))]

@@ -44,6 +44,7 @@ def main(argv=None):
                                    learn_sigma=args.learn_sigma)
     diffusion = create_diffusion(**args_to_dict(args, ["learn_sigma", "diffusion_steps", "noise_schedule", "timestep_respacing",
                                                        "use_kl", "predict_xstart", "rescale_timesteps", "rescale_learned_sigmas"]))
+    diffusion.batch_shard = diffusion.scg_shard = False     # data-parallel sampler: every rank draws its OWN batches (no shared chain to shard)
     if args.synthetic_weights:
         from rgm import synth
         arch = dict(depth=model.depth, hidden=model.hidden_size, heads=model.num_heads, patch=model.patch_size,

@@ -748,6 +748,39 @@ def g_hooks():
     save("hooks", **out)
 
 
+def g_cfgdps():
+    """DPS with classifier-free guidance in the eps-network (model_fn cfg=True, w=4 under autograd; reference
+    condition_mean :415-465 with condition_functions.py:22-23): one dps step on the '250' chain."""
+    print("[cfgdps: dps step with a cfg eps-network]")
+    from functools import partial
+    from types import SimpleNamespace
+    rng = np.random.RandomState(1800)
+    m, sd = ref_dit(SM, 11)
+    cm, csd = ref_cls(CLS2, 4)
+    mf = partial(rcf.model_fn, model=m, num_classes=3, class_cond=True, cfg=True, w=4.)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
+    cond = partial(rcf.composite_nn_zt, fns=["nn_z0_mse_dummy"], classifier_scales=[1.], classifiers=[cm], rule_names=["note_density"])
+    torch.set_grad_enabled(True)
+    d = make_diffusion("250")
+    d.t_end = 0
+    t = np.full((B,), 140, dtype=np.int64)
+    nz = rng.randn(B, 4, 128, 16).astype(F32)
+    gk = SimpleNamespace(schedule=False, method="dps", step_size=1.5, nn=True, vae=False)
+    kw = dict(clip_denoised=False, model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in rule.items()}})
+    NQ.push(nz)
+    r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), cond_fn=cond, guidance_kwargs=gk, **kw)
+    NQ.push(nz)
+    u = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), **kw)
+    torch.set_grad_enabled(False)
+    shift = (r["sample"] - u["sample"]).detach().numpy()
+    print(f"    guidance shift |max| {np.abs(shift).max():.3e}")
+    save("cfgdps", x=x, y=y, rule=rule["note_density"], t=t, noise=nz, sample=r["sample"].detach().numpy(),
+         pred_xstart=r["pred_xstart"].detach().numpy(), shift=shift)
+
+
 def g_configs():
     """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
     checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
@@ -1181,7 +1214,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "configs"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "configs"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1208,6 +1241,8 @@ if __name__ == "__main__":
         g_next2()
     if "hooks" in which:
         g_hooks()
+    if "cfgdps" in which:
+        g_cfgdps()
     if "configs" in which:
         g_configs()
     if "collage" in which:

@@ -292,3 +292,23 @@ def test_denoised_fn_and_x0_predicting_models(tag, rs, ddim, px, precision):
     out = d.ddim_sample(_model_fn(m), x, t, eta=1.0, **kw) if ddim else d.p_sample(_model_fn(m), x, t, **kw)
     assert rel(out["pred_xstart"].cpu().numpy(), g[f"{tag}.pred_xstart"]) < 2e-4
     assert rel(out["sample"].cpu().numpy(), g[f"{tag}.sample"]) < 2e-4
+
+
+def test_dps_with_classifier_free_guidance_in_the_eps_network(precision):
+    """DPS through model_fn(cfg=True, w=4) (the reference differentiates both conditional and null-label passes with autograd):
+    one 2B-row saved-activation forward, one backward with the cotangents (1+w) g | -w g."""
+    from gpu_util import dev, rel
+    from guided_diffusion.condition_functions import model_fn
+    g = load_golden("cfgdps")
+    m, cm = _dit(SM, 11), _cls()
+    mf = partial(model_fn, model=m, num_classes=3, class_cond=True, cfg=True, w=4.)
+    d = _diffusion("250")
+    d.t_end = 0
+    _inject(d, g["noise"], g["noise"])
+    gk = SimpleNamespace(schedule=False, method="dps", step_size=1.5, nn=True, vae=False)
+    kw = dict(clip_denoised=False, model_kwargs={"y": dev(g["y"]), "rule": {"note_density": dev(g["rule"])}})
+    out = d.p_sample(mf, dev(g["x"]), dev(g["t"]), cond_fn=_cond(cm, "nn_z0_mse_dummy", 1.), guidance_kwargs=gk, **kw)
+    plain = d.p_sample(mf, dev(g["x"]), dev(g["t"]), **kw)
+    assert rel(out["pred_xstart"].cpu().numpy(), g["pred_xstart"]) < 5e-4
+    assert rel(out["sample"].cpu().numpy(), g["sample"]) < 5e-4
+    assert rel((out["sample"] - plain["sample"]).cpu().numpy(), g["shift"]) < 5e-3

@@ -389,3 +389,56 @@ def test_full_size_guidance_and_scg_decode_are_row_independent(precision):
     assert roll.shape == (64, 3, 128, 1024)
     for i in (0, 33, 62):
         assert rel(roll[i:i + 2].cpu().numpy(), _decode(lat[i:i + 2].contiguous(), vae, scale_factor=1.2465).cpu().numpy()) < 2e-6, i
+
+
+@pytest.mark.parametrize("kind", ["ddpm_cls", "ddim", "dps"])
+def test_batch_sharded_step_reproduces_the_unsharded_rows(kind, monkeypatch):
+    """SURVEY 8e for the steps outside SCG's search: the step replayed as 'rank r of 2' (this rank's rows only, the other rank's
+    rows supplied by a stand-in all-gather) gives the unsharded step's rows bit for bit -- same kernels per row, and the Philox
+    draw of a row does not depend on which rank materialises it."""
+    from functools import partial
+    from types import SimpleNamespace
+    from gpu_util import dev, load_module
+    from rgm import batch_shard
+    from guided_diffusion.condition_functions import composite_nn_zt
+    from guided_diffusion.dit import DiTRotaryClassifier
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    g = load_golden("steps")
+    m = _dit(SM, 11)
+    carch = dict(depth=2, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=16)
+    cm = load_module(DiTRotaryClassifier(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6,
+                                         num_classes=16), synth.dit_state_dict(4, **carch))
+    rng = np.random.RandomState(3)
+    x = dev(np.concatenate([g["x"], rng.randn(2, 4, 128, 16).astype(F32)]))          # B = 4
+    y = dev(np.array([1, 2, 0, 1], dtype=np.int64))
+    rule = {"note_density": dev((rng.rand(4, 16) * 4).astype(F32))}
+
+    def run(d):
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=5)
+        kw = dict(clip_denoised=False, model_kwargs={"y": y, "rule": rule})
+        if kind == "ddim":
+            return d.ddim_sample(_model_fn(m), x, dev(np.full(4, 30, dtype=np.int64)), eta=1.0, **kw)
+        fn = "grad_nn_zt_mse" if kind == "ddpm_cls" else "nn_z0_mse_dummy"
+        cond = partial(composite_nn_zt, fns=[fn], classifier_scales=[10. if kind == "ddpm_cls" else 1.], classifiers=[cm],
+                       rule_names=["note_density"])
+        gk = SimpleNamespace(schedule=False, method="classifier_guidance" if kind == "ddpm_cls" else "dps", step_size=1.5, nn=True, vae=False)
+        return d.p_sample(_model_fn(m), x, dev(np.full(4, 120, dtype=np.int64)), cond_fn=cond, guidance_kwargs=gk, **kw)
+
+    chain = "ddim50" if kind == "ddim" else "250"
+    ref = run(_diffusion(chain))
+    for rank in (0, 1):
+        monkeypatch.setattr(batch_shard, "partition", lambda B, r=rank: (r * B // 2, B // 2, True))
+
+        def fake_gather(tensors, r=rank):
+            out = []
+            for mine, full in zip(tensors, (ref["sample"], ref["pred_xstart"])):
+                assert mine.shape[0] == 2
+                parts = [full[:2].clone(), full[2:].clone()]
+                parts[r] = mine
+                out.append(torch.cat(parts, dim=0))
+            return out
+        monkeypatch.setattr(batch_shard, "gather_rows", fake_gather)
+        got = run(_diffusion(chain))
+        assert torch.equal(got["sample"], ref["sample"]), f"rank {rank}: rows differ from the unsharded step"
+        assert torch.equal(got["pred_xstart"], ref["pred_xstart"])

@@ -378,3 +378,42 @@ def test_vae_checkpoint_reader_stubs_lightning_globals_and_checks_key_coverage(t
     path3 = str(tmp_path / "decoder_only.ckpt")
     torch.save({"state_dict": dec_only}, path3)
     klvae_pedal.AutoencoderKL(ckpt_path=path3)                  # a decoder-only checkpoint still restores (decode path)
+
+
+def _batch_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    from rgm import batch_shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 6
+    gen = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 4, 8, 2, generator=gen)
+    kw = {"y": torch.arange(B), "rule": {"note_density": torch.randn(B, 16, generator=gen)}, "scale": 3.0,
+          "mask": torch.ones(1, 4, 8, 2)}
+    b0, nb, sharded = batch_shard.partition(B)
+    mine = batch_shard.slice_rows(kw, B, b0, nb)
+    ok = (mine["y"].tolist() == list(range(b0, b0 + nb)) and torch.equal(mine["rule"]["note_density"], kw["rule"]["note_density"][b0:b0 + nb])
+          and mine["scale"] == 3.0 and mine["mask"].shape == (1, 4, 8, 2))
+    new = x[b0:b0 + nb] * 2 + 1                                   # this rank's rows of "the step"
+    full, full2 = batch_shard.gather_rows([new, -new])
+    q.put((rank, b0, nb, sharded, ok, torch.equal(full, x * 2 + 1) and torch.equal(full2, -(x * 2 + 1)), batch_shard.partition(7)))
+    dist.destroy_process_group()
+
+
+def test_batch_sharding_two_ranks_gloo():
+    """SURVEY 8e, the non-SCG steps: contiguous row blocks per rank, per-sample model_kwargs sliced (broadcast tensors and scalars
+    pass through), one all-gather rebuilds the full batch in row order on every rank; an indivisible batch stays replicated."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2], r[3]) for r in res] == [(0, 3, True), (3, 3, True)]
+    assert all(r[4] and r[5] for r in res) and all(r[6] == (0, 7, False) for r in res)
