@@ -344,6 +344,7 @@ def uint8_flip_record(device):
     vae.load_state_dict(synth.vae_state_dict(2, device=device), strict=False)
     vae = vae.to(device).eval()
     d = make_diffusion("ddim50")
+    d.batch_shard = d.scg_shard = False          # rank 0 runs this chain alone: no collectives
     rng = np.random.RandomState(701)
     q = [rng.randn(2, 4, 128, 16).astype(np.float32) for _ in range(51)]
     d.noise_fn = lambda shape, dev: torch.from_numpy(q.pop(0)).to(dev)
