@@ -147,6 +147,13 @@ int rgm_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, void* strea
 int rgm_ddpm_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
                   const float* const* tables_host, int clip_denoised, int t_end, float* sample, float* pred_xstart,
                   float* g_out, int N, int E, void* stream);
+/* The same step with LEARNED variances (learn_sigma=True checkpoints; p_mean_variance :299-313): var_values (N,E) is the second
+ * half of the network's output; min_log_tab / max_log_tab (device float32 tables: posterior_log_variance_clipped, log(betas))
+ * give log var = frac max + (1 - frac) min, frac = (v + 1) / 2 (LEARNED_RANGE); both NULL: var_values is the log-variance (LEARNED). */
+int rgm_ddpm_step_learned(const float* x, const float* eps, const float* var_values, const float* min_log_tab,
+                          const float* max_log_tab, const float* grad, const float* noise, const int64_t* t,
+                          const float* const* tables_host, int clip_denoised, int t_end, float* sample, float* pred_xstart, int N,
+                          int E, void* stream);
 /* ddim_sample (:881-952) incl. condition_score (:467-489) when grad != NULL; g_out receives sigma. */
 int rgm_ddim_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
                   const float* const* tables_host, int clip_denoised, int t_end, float eta, float* sample,

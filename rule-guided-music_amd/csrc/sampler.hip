@@ -84,10 +84,14 @@ struct StepTables {          // device float32 copies of the float64 schedule ta
 // DDPM ancestral step.  One thread per element; E = elements per sample.
 //   x0 = c1*x - c2*eps (clip) ; mean = pc1*x0 + pc2*x (+ var*grad) ; sample = mean + [t>t_end]*exp(.5 logvar)*noise
 // noise == nullptr -> sample = mean (SCG: candidates are drawn by scg_candidates instead).
+// Learned variances (ModelVarType.LEARNED_RANGE / LEARNED, :299-313): `vv` holds the network's second output half per
+// element; with min_log / max_log tables log var = frac * max_log + (1 - frac) * min_log, frac = (vv + 1) / 2 (LEARNED_RANGE);
+// with the tables NULL vv IS the log-variance (LEARNED).  vv == NULL: the fixed tables.
 __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ grad,
                                  const float* __restrict__ noise, const int64_t* __restrict__ t, StepTables tb, int clip,
                                  int t_end, float* __restrict__ sample, float* __restrict__ pred_xstart,
-                                 float* __restrict__ g_out, long long total, int E) {
+                                 float* __restrict__ g_out, long long total, int E, const float* __restrict__ vv = nullptr,
+                                 const float* __restrict__ min_log = nullptr, const float* __restrict__ max_log = nullptr) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / E);
@@ -96,8 +100,18 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
   float x0 = tb.sqrt_recip_ac[ti] * xv - tb.sqrt_recipm1_ac[ti] * eps[i];
   if (clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
   float mean = tb.post_c1[ti] * x0 + tb.post_c2[ti] * xv;
-  if (grad) mean = mean + tb.var[ti] * grad[i];
-  const float g = expf(0.5f * tb.logvar[ti]);
+  float logvar = tb.logvar[ti], var = tb.var[ti];
+  if (vv) {
+    if (min_log) {
+      const float frac = (vv[i] + 1.f) / 2.f;
+      logvar = frac * max_log[ti] + (1.f - frac) * min_log[ti];
+    } else {
+      logvar = vv[i];
+    }
+    var = expf(logvar);
+  }
+  if (grad) mean = mean + var * grad[i];
+  const float g = expf(0.5f * logvar);
   float s = mean;
   if (noise) s = mean + (ti > t_end ? 1.f : 0.f) * g * noise[i];
   sample[i] = s;
@@ -253,7 +267,22 @@ extern "C" int rgm_ddpm_step(const float* x, const float* eps, const float* grad
   RGM_REQUIRE(x && eps && t && tables && sample && pred_xstart && N > 0 && E > 0, "ddpm_step: bad arguments");
   const long long total = (long long)N * E;
   hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, grad,
-                     noise, t, make_tables(tables), clip_denoised, t_end, sample, pred_xstart, g_out, total, E);
+                     noise, t, make_tables(tables), clip_denoised, t_end, sample, pred_xstart, g_out, total, E, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+extern "C" int rgm_ddpm_step_learned(const float* x, const float* eps, const float* var_values, const float* min_log_tab,
+                                     const float* max_log_tab, const float* grad, const float* noise, const int64_t* t,
+                                     const float* const* tables, int clip_denoised, int t_end, float* sample, float* pred_xstart, int N,
+                                     int E, void* stream) {
+  RGM_REQUIRE(x && eps && var_values && t && tables && sample && pred_xstart && N > 0 && E > 0, "ddpm_step_learned: bad arguments");
+  RGM_REQUIRE((min_log_tab == nullptr) == (max_log_tab == nullptr), "ddpm_step_learned: min / max log-variance tables come together");
+  const long long total = (long long)N * E;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, grad, noise, t,
+                     make_tables(tables), clip_denoised, t_end, sample, pred_xstart, (float*)nullptr, total, E, var_values, min_log_tab,
+                     max_log_tab);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -21,9 +21,9 @@ What is different underneath (design, not a translation):
   * every other step (unguided, classifier-guided, DPS) is batch-parallel: rank r computes rows [r*B/R, (r+1)*B/R) and ONE
     all-gather of the new latents per step gives every rank the full batch again -- see batch_shard / SURVEY 8e.
 
-Not implemented here: learned variances (learn_sigma=True checkpoints: LEARNED / LEARNED_RANGE), PREVIOUS_X models and the
-training losses.  They raise NotImplementedError instead of silently degrading.  SCG / DPS score candidates with an
-eps-predicting network (as every shipped configuration does).
+Not implemented here: PREVIOUS_X models, SCG / DPS steps with LEARNED variances (learn_sigma=True; plain, classifier-guided
+and DDIM steps with them are provided) and the training losses.  They raise NotImplementedError instead of silently degrading.
+SCG / DPS score candidates with an eps-predicting network (as every shipped configuration does).
 """
 import ctypes as C
 import enum
@@ -164,16 +164,23 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ helpers
     def _check_supported(self):
-        if self.model_mean_type == ModelMeanType.PREVIOUS_X or self.model_var_type not in (
-                ModelVarType.FIXED_LARGE, ModelVarType.FIXED_SMALL):
-            raise NotImplementedError("native sampler supports eps- / x0-predicting models with fixed variance "
-                                      "(learn_sigma=False: the default of every CLI of the reference)")
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            raise NotImplementedError("native sampler supports eps- / x0-predicting models (ModelMeanType.PREVIOUS_X is unused by the reference's CLIs)")
+
+    def _learned(self):
+        return self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE)
 
     def _model_eps(self, x, out, t, denoised_fn):
         """The eps estimate the fused step starts from.  An eps-predicting model without denoised_fn: its output.  Otherwise the
         x0 estimate (the model's output for START_X, c1 x - c2 eps for EPSILON) goes through denoised_fn (reference
         process_xstart :281-286; the clip that follows is applied inside the step kernel) and is turned back into the eps that
         reproduces it -- one masked-replacement launch with an all-ones mask."""
+        self._var_values = None
+        if self._learned():
+            # learn_sigma=True networks emit 2C channels: the mean-type output and the variance values (reference :299-301)
+            C_ = x.shape[1]
+            assert out.shape[1] == 2 * C_, f"learned variances need a 2C-channel model output, got {tuple(out.shape)}"
+            out, self._var_values = out[:, :C_].contiguous(), out[:, C_:].float().contiguous()
         start_x = self.model_mean_type == ModelMeanType.START_X
         if not start_x and denoised_fn is None:
             return out
@@ -182,6 +189,14 @@ class GaussianDiffusion:
             x0 = denoised_fn(x0)
         ones = th.ones((1,) * x.dim(), dtype=th.float32, device=x.device)
         return self._edit_eps(x, th.zeros_like(x, dtype=th.float32), t, False, {"gt": x0, "mask": ones})
+
+    def _learned_tabs(self, device):
+        """float32 device copies of posterior_log_variance_clipped and log(betas) (the LEARNED_RANGE interpolation ends)"""
+        key = "lv" + str(device)
+        if key not in self._tables:
+            self._tables[key] = (th.from_numpy(self.posterior_log_variance_clipped).to(device=device, dtype=th.float32).contiguous(),
+                                 th.from_numpy(np.log(self.betas)).to(device=device, dtype=th.float32).contiguous())
+        return self._tables[key]
 
     def _tab(self, device):
         key = str(device)
@@ -342,6 +357,22 @@ class GaussianDiffusion:
         sample, x0 = th.empty_like(x), th.empty_like(x)
         g = th.empty(N, dtype=th.float32, device=x.device) if want_g else None
         tab = self._tab(x.device)
+        vv = getattr(self, "_var_values", None) if self._learned() else None
+        if vv is not None and kind == "ddpm":
+            # learned (per-element) variances: the noise scale is a tensor, so SCG's per-sample scale does not apply
+            if want_g:
+                raise NotImplementedError("SCG / DPS steps with learned variances (learn_sigma=True) are not provided")
+            assert vv.shape == x.shape
+            if self.model_var_type == ModelVarType.LEARNED_RANGE:
+                lt = self._learned_tabs(x.device)
+                lo, hi = _rgm.ptr(lt[0]), _rgm.ptr(lt[1])
+            else:
+                lo = hi = None
+            with th.cuda.device(x.device):
+                _rgm.check(_rgm.lib.rgm_ddpm_step_learned(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(vv), lo, hi, _rgm.ptr(grad), _rgm.ptr(noise),
+                                                          _rgm.ptr(tt), tab.ptrs, int(bool(clip_denoised)), int(self.t_end),
+                                                          _rgm.ptr(sample), _rgm.ptr(x0), N, E, _rgm.current_stream()))
+            return sample, x0, None
         with th.cuda.device(x.device):
             if kind == "ddpm":
                 _rgm.check(_rgm.lib.rgm_ddpm_step(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(grad), _rgm.ptr(noise), _rgm.ptr(tt),
@@ -367,6 +398,14 @@ class GaussianDiffusion:
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         mean, x0, _ = self._step("ddpm", x, eps, None, None, t, clip_denoised)
+        if self._learned():        # the dict's variance entries (API surface; the sampling steps compute them inside the fused kernel)
+            vv = self._var_values
+            if self.model_var_type == ModelVarType.LEARNED_RANGE:
+                frac = (vv + 1) / 2
+                logvar = frac * self._per_sample(np.log(self.betas), t, x) + (1 - frac) * self._per_sample(self.posterior_log_variance_clipped, t, x)
+            else:
+                logvar = vv
+            return {"mean": mean, "variance": th.exp(logvar), "log_variance": logvar, "pred_xstart": x0, "eps": eps}
         return {"mean": mean, "variance": self._per_sample(self._model_variance, t, x),
                 "log_variance": self._per_sample(self._model_log_variance, t, x), "pred_xstart": x0, "eps": eps}
 

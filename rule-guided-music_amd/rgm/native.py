@@ -37,6 +37,7 @@ def _load():
         "rgm_rotary_attention": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_randn": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_uint64, vp]),
         "rgm_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp]),
+        "rgm_ddpm_step_learned": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp]),
         "rgm_ddim_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, i32, vp]),
         "rgm_scg_candidates": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_xstart_from_eps": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, i32, vp]),

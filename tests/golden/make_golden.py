@@ -781,6 +781,44 @@ def g_cfgdps():
          pred_xstart=r["pred_xstart"].detach().numpy(), shift=shift)
 
 
+def g_learned():
+    """learn_sigma=True checkpoints (ModelVarType.LEARNED_RANGE, reference :299-313): the network emits 2C channels, the step's
+    variance is interpolated per element between the clipped posterior variance and beta.  A DDPM step, a classifier-guided DDPM
+    step ('250' chain) and a DDIM step (which ignores the learned variance), SM backbone with 8 output channels."""
+    print("[learned: learn_sigma=True steps]")
+    from functools import partial
+    from types import SimpleNamespace
+    arch = dict(SM, out_ch=8)
+    sd = synth.dit_state_dict(21, **arch)
+    m = rdit.DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6, num_classes=3, learn_sigma=True)
+    m.load_state_dict(tsd(sd), strict=True)
+    m.eval()
+    cm, csd = ref_cls(CLS2, 4)
+    mf = ref_model_fn(m, 3, True)
+    rng = np.random.RandomState(1900)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
+    out = {"x": x, "y": y, "rule": rule["note_density"], "seed": np.array(21)}
+    cond = partial(rcf.composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[cm], rule_names=["note_density"])
+    for tag, rs, ddim, ti, guided in (("ddpm", "", False, 400, False), ("cg250", "250", False, 60, True), ("ddim", "ddim50", True, 21, False)):
+        d = rsu.create_diffusion(learn_sigma=True, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs, use_kl=False,
+                                 predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        kw = dict(clip_denoised=False, model_kwargs={"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in rule.items()}})
+        if guided:
+            kw.update(cond_fn=cond, guidance_kwargs=SimpleNamespace(schedule=False, method="classifier_guidance"))
+        r = (d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), eta=1.0, **kw) if ddim
+             else d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), **kw))
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].numpy(), f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
+        print(f"    {tag}: sample range {r['sample'].min().item():.3f} .. {r['sample'].max().item():.3f}")
+    save("learned", **out)
+
+
 def g_configs():
     """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
     checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
@@ -1214,7 +1252,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "configs"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1243,6 +1281,8 @@ if __name__ == "__main__":
         g_hooks()
     if "cfgdps" in which:
         g_cfgdps()
+    if "learned" in which:
+        g_learned()
     if "configs" in which:
         g_configs()
     if "collage" in which:

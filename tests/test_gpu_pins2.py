@@ -312,3 +312,28 @@ def test_dps_with_classifier_free_guidance_in_the_eps_network(precision):
     assert rel(out["pred_xstart"].cpu().numpy(), g["pred_xstart"]) < 5e-4
     assert rel(out["sample"].cpu().numpy(), g["sample"]) < 5e-4
     assert rel((out["sample"] - plain["sample"]).cpu().numpy(), g["shift"]) < 5e-3
+
+
+@pytest.mark.parametrize("tag,rs,ddim,guided", [("ddpm", "", False, False), ("cg250", "250", False, True), ("ddim", "ddim50", True, False)])
+def test_learned_variance_checkpoints(tag, rs, ddim, guided, precision):
+    """learn_sigma=True (ModelVarType.LEARNED_RANGE, reference :299-313): the 2C-channel network output is split, the per-element
+    log-variance is interpolated inside the fused DDPM step (rgm_ddpm_step_learned), classifier guidance scales its gradient by
+    that variance, DDIM ignores it."""
+    from gpu_util import dev, load_module, rel
+    from guided_diffusion.dit import DiTRotary
+    from guided_diffusion.script_util import create_diffusion
+    g = load_golden("learned")
+    arch = dict(SM, out_ch=8)
+    m = load_module(DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6, num_classes=3,
+                              learn_sigma=True), synth.dit_state_dict(int(g["seed"]), **arch))
+    d = create_diffusion(learn_sigma=True, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs, use_kl=False,
+                         predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+    d.t_end = 0
+    _inject(d, g[f"{tag}.noise"])
+    kw = dict(clip_denoised=False, model_kwargs={"y": dev(g["y"]), "rule": {"note_density": dev(g["rule"])}})
+    if guided:
+        kw.update(cond_fn=_cond(_cls()), guidance_kwargs=SimpleNamespace(schedule=False, method="classifier_guidance"))
+    x, t = dev(g["x"]), dev(g[f"{tag}.t"])
+    out = d.ddim_sample(_model_fn(m), x, t, eta=1.0, **kw) if ddim else d.p_sample(_model_fn(m), x, t, **kw)
+    assert rel(out["pred_xstart"].cpu().numpy(), g[f"{tag}.pred_xstart"]) < 2e-4
+    assert rel(out["sample"].cpu().numpy(), g[f"{tag}.sample"]) < 2e-4
