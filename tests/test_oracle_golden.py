@@ -288,8 +288,8 @@ def test_segmentwise_selection_index_arithmetic():
         assert np.allclose(lp, totals[:, i]) and np.array_equal(lp.argmax(0), inds[i])
         for b in range(B):
             assert np.array_equal(sample[b, :, i * 128:(i + 1) * 128], cand.reshape(n, B, 4, 256, 16)[inds[i, b], b, :, i * 128:(i + 1) * 128])
-    g = load_golden("steps2")
-    assert g["seg.max_ind"].shape == (2, 2) and g["seg.total_log_prob"].shape == (3, 2, 2)
+    g = load_golden("seg")
+    assert g["max_ind"].shape == (2, 2) and g["total_log_prob"].shape == (3, 2, 2)
 
 
 def test_torch_cpu_restatement_for_the_cpu_baseline_leg():
