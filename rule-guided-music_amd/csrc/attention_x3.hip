@@ -27,6 +27,21 @@ __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
   }
 }
 
+#ifdef RGM_ATTN_STAMPS   // phase timing experiment (tools/attn_stamps.py; make EXTRA="-DRGM_EXPERIMENTS -DRGM_ATTN_STAMPS")
+__device__ long long g_attn_stamps[16 * 8];
+__device__ long long g_attn_real[2 * 1024];   // s_memrealtime (100 MHz) at entry / exit of wave 0 of every workgroup
+#define ATTN_STAMP(i)                                                                       \
+  if (blockIdx.x == 7) {                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime();                         \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                      \
+    if ((threadIdx.x & 63) == 0) g_attn_stamps[(threadIdx.x >> 6) * 16 + (i)] = now_;       \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+#else
+#define ATTN_STAMP(i)
+#endif
+
 template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                   const float* __restrict__ cos_tab,
@@ -50,6 +65,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   const int R = 2 * rot_half;
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+#ifdef RGM_ATTN_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_real[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+  ATTN_STAMP(0)
   // ---- stage K (rotated, split) and V (split, transposed, keys permuted); padded keys / channels are zeros
   constexpr int CPR = KP / 4;               // float4 chunks per padded K row
   for (int c = tid; c < TP * CPR; c += 512) {
@@ -93,7 +112,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       }
     }
   }
+  ATTN_STAMP(1)
   __syncthreads();
+  ATTN_STAMP(2)
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   // scores are kept in the log2 domain (log2(e) folded into the query scale): p = 2^(s - max) is ONE v_exp_f32 per element
@@ -132,6 +153,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
         split8(v8, qh[j], ql[j]);
       }
     }
+    ATTN_STAMP(3)
     // ---- S^T[key][query] = K . Q^T
     f32x16 sacc[NKT];
 #pragma unroll
@@ -148,6 +170,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
         sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[j], sacc[kt], 0, 0, 0);
       }
     }
+    ATTN_STAMP(4)
     // ---- softmax over keys: register e of tile kt is key kt*32 + (e&3) + 8*(e>>2) + 4*hh
     float mx = -INFINITY;
     const int ktr = T >> 5, tr = T & 31;   // ragged tile index / valid keys in it (wave-uniform)
@@ -178,6 +201,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
     const float inv = 1.0f / sum;
     // natural-log sum-exp of the scaled scores, saved for the backward (scores here are in the log2 domain)
     if (lse && hh == 0 && q < T) lse[((long long)n * heads + head) * T + q] = (mx + log2f(sum)) * 0.693147180559945309417f;
+    ATTN_STAMP(5)
     // ---- O^T[d][query] = V^T . P^T ; A operand = V^T rows (d = lane&31), B operand = the probability registers, split
     f32x16 oacc[DT];
 #pragma unroll
@@ -208,6 +232,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the V^T reads of later key tiles from being hoisted (spills)
     }
+    ATTN_STAMP(6)
     // ---- store: lane = query (row), registers 4g..4g+3 = 4 consecutive channels
     if (q < T) {
       float* op = o + ((long long)n * T + q) * D + head * HD;
@@ -233,7 +258,11 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           }
         }
     }
+    ATTN_STAMP(7)
   }
+#ifdef RGM_ATTN_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_real[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 template <int HD, int NKT>
@@ -280,4 +309,16 @@ int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const
   return rotary_attention_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, lse, out_split);
 }
 
+#ifdef RGM_ATTN_STAMPS
+int attn_stamps_copy(long long* out) {
+  RGM_CHECK_HIP(hipDeviceSynchronize());
+  RGM_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_stamps), sizeof(long long) * 128));
+  RGM_CHECK_HIP(hipMemcpyFromSymbol(out + 128, HIP_SYMBOL(g_attn_real), sizeof(long long) * 2048));
+  return RGM_OK;
+}
+#endif
+
 }  // namespace rgm
+#ifdef RGM_ATTN_STAMPS
+extern "C" int rgm_attn_stamps(long long* out128)  /* 128 phase stamps + 2048 entry/exit real-time stamps */ { return rgm::attn_stamps_copy(out128); }
+#endif
