@@ -87,11 +87,13 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // Loader waves (waves NW..2NW-1): all the DMA of the workgroup and nothing else.  One wave issues an LDS-DMA piece
     // only every ~70-80 cycles whatever the TA load (tools/gemm_stamp.py; the guide's "ldsdma-fill": 25 GB/s per
     // loader wave), which is what sat between the MFMAs of the other kernels; NW loaders beside NW MFMA waves give the
-    // 40 B/clk/CU a 128x128 tile needs without touching the MFMA waves' streams.  3-stage ring: after barrier kt-1
-    // (consumers are done with tile kt-1) a loader issues its share of tile kt+2 into that stage, waits until its
-    // share of tile kt+1 has landed (vmcnt(LSEG): only the pieces just issued may still fly) and joins barrier kt.
+    // 40 B/clk/CU a 128x128 tile needs without touching the MFMA waves' streams.  NSTAGE-deep ring: after barrier kt-1
+    // (consumers are done with tile kt-1) a loader issues its share of tile kt+NSTAGE-1 into that stage, waits until its
+    // share of tile kt+1 has landed (vmcnt((NSTAGE-2)*LSEG): only the tiles behind it may still fly) and joins barrier
+    // kt.  3 stages cover a K-tile's worth of MFMA time; grids of at most one workgroup per CU (B <= 4) have nothing
+    // else to hide the HBM latency of their weights behind and take 4-6 stages (tiles 53-56).
     constexpr int LSEG = SEGS / NW;                         // pieces per loader wave and tile
-    static_assert(NSTAGE == 3 && ALOAD == 0 && SEGS % NW == 0, "PIPE 4: dense operands, 3-stage ring");
+    static_assert(NSTAGE >= 3 && ALOAD == 0 && SEGS % NW == 0 && (NSTAGE - 2) * LSEG < 64, "PIPE 4: dense operands, ring of 3+ stages");
     if (wave >= NW) {
       const int lw = wave - NW;
       const int r8l = lane >> 3;
@@ -116,24 +118,22 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
           lsrc[i] += linc[i];
         });
       };
-      issue_tile(ring);
-      if (KT > 1) {
-        issue_tile(ring + STAGE);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSEG) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      auto wait_flying = [&](int tiles) {                // wave-uniform: at most `tiles` of the newest tiles may still fly
+        static_for<0, NSTAGE - 1>([&](auto c) {
+          if (tiles == decltype(c)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(c)::value * LSEG) : "memory");
+        });
+      };
+      static_for<0, NSTAGE - 1>([&](auto c) {
+        if (decltype(c)::value < KT) issue_tile(ring + decltype(c)::value * STAGE);
+      });
+      wait_flying(min(NSTAGE - 2, KT - 1));
       __builtin_amdgcn_s_barrier();                     // barrier P: tile 0 is in LDS
-      int s2 = 2;
+      int s2 = NSTAGE - 1;
       for (int kt = 0; kt + 1 < KT; ++kt) {
-        if (kt + 2 < KT && exp != 1) {
-          issue_tile(ring + s2 * STAGE);
-          asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LSEG) : "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (kt + NSTAGE - 1 < KT && exp != 1) issue_tile(ring + s2 * STAGE);
+        wait_flying(min(NSTAGE - 2, KT - 2 - kt));
         __builtin_amdgcn_s_barrier();                   // barrier kt: tile kt+1 is in LDS
-        s2 = s2 == 2 ? 0 : s2 + 1;
+        s2 = s2 == NSTAGE - 1 ? 0 : s2 + 1;
       }
       if (vec) __syncthreads();                         // the consumers' epilogue barrier
       return;
@@ -289,7 +289,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(cur, std::integral_constant<int, 1>{}, more1, nxt, ring + s1 * STAGE);
       RGM_STAMP(6)
-      s1 = s1 == 2 ? 0 : s1 + 1;
+      s1 = s1 == NSTAGE - 1 ? 0 : s1 + 1;
     };
     for (int kt = 0; kt < KT; kt += 2) {
       iter(f0, f1, kt);
@@ -604,53 +604,133 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
 #pragma unroll
         for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
       });
+      // Three bodies, chosen by uniform branches.  The general one carries every epilogue variant (activations and their
+      // derivatives, gate, residual, statistics, split output): ~2.5 KB of code, so its row loop is ROLLED -- unrolled 4-16
+      // times it was 20-40 KB of straight-line code fetched once per tile, and a workgroup that runs one tile (small grids)
+      // spent 11-25k cycles of instruction fetch in it (tools/gemm_stamp.py).  A rolled loop with global loads in it waits
+      // vmcnt(0) every iteration = for its own previous store, so the two cases the DiT forward runs get their own bodies:
+      //   plain   (bias / SiLU / GELU / split output, nothing read per row): rolled, no global load in the loop, the bias
+      //           load is retired before it -> stores are fire-and-forget;
+      //   linear  (act 0 + gate and/or residual, no statistics: attention proj, fc2): the slab's gate / residual reads are
+      //           all issued before the first row is finished, small unrolled body.
+      constexpr int NJ = 32 / RPI;
+      const int row_b = m0 + arow0 + im * 32 + lr;
+      auto store_row = [&](int row, const float (&v)[4]) {
+        if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          bf16x4 hi, lo;
 #pragma unroll
-      for (int j = 0; j < 32 / RPI; ++j) {
-        const int r = j * RPI + lr;
-        const int row = m0 + arow0 + im * 32 + r;
-        const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
-        if (row < p.M && col_ok) {
-          float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
-          if (p.act == 1) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] = silu_f(v[q4]);
-          } else if (p.act == 2) {
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] = gelu_tanh_fast_f(v[q4]);
-          } else if (p.act == 3 || p.act == 4) {   // backward through an activation: times gelu'(aux) / silu'(aux)
-            const float4 x4 = *reinterpret_cast<const float4*>(auxb + (long long)row * p.ldaux + col);
-            const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] *= (p.act == 3 ? gelu_tanh_grad_f(xs[q4]) : silu_grad_f(xs[q4]));
+          for (int q4 = 0; q4 < 4; ++q4) {
+            hi[q4] = (__bf16)v[q4];
+            lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
           }
-          if (p.gate) {
-            const float4 g4 = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
-            v[0] *= g4.x; v[1] *= g4.y; v[2] *= g4.z; v[3] *= g4.w;
-          }
-          if (resb) {
-            const float4 r4 = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-          }
-          if (p.stats) {
+          __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+          *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+          *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+        } else if (exp != 4) {
+          *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      };
+      const bool reads_rows = p.gate || resb || p.act >= 3;
+      if (!reads_rows && !p.stats) {
+        asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));   // the bias has landed: no VMEM wait inside the loop
+        auto plain_rows = [&](auto act_c, auto split_c) {      // branch-free body per (activation, output format)
+          constexpr int ACT = decltype(act_c)::value;
+          constexpr bool SPLIT = decltype(split_c)::value != 0;
+#pragma unroll 1
+          for (int j = 0; j < NJ; ++j) {
+            const int r = j * RPI + lr, row = row_b + j * RPI;
+            const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
+            if (row < p.M && col_ok) {
+              float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              gs[q4] += (double)v[q4];
-              gs[4 + q4] += (double)v[q4] * (double)v[q4];
+              for (int q4 = 0; q4 < 4; ++q4) v[q4] = ACT == 1 ? silu_f(v[q4]) : (ACT == 2 ? gelu_tanh_fast_f(v[q4]) : v[q4]);
+              if constexpr (SPLIT) {
+                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                bf16x4 hi, lo;
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                  hi[q4] = (__bf16)v[q4];
+                  lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+                }
+                __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+                *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+                *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+              } else {
+                if (exp != 4) *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+              }
             }
           }
-          if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
-            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-            bf16x4 hi, lo;
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (p.out_split) {
+          if (p.act == 0) plain_rows(I0{}, I1{});
+          else if (p.act == 1) plain_rows(I1{}, I1{});
+          else plain_rows(I2{}, I1{});
+        } else {
+          if (p.act == 0) plain_rows(I0{}, I0{});
+          else if (p.act == 1) plain_rows(I1{}, I0{});
+          else plain_rows(I2{}, I0{});
+        }
+      } else if (p.act == 0 && !p.stats) {
+        float4 g4[NJ], r4[NJ];
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-              hi[q4] = (__bf16)v[q4];
-              lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+        for (int j = 0; j < NJ; ++j) {
+          const int row = row_b + j * RPI;
+          g4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+          r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row < p.M && col_ok) {
+            if (p.gate) g4[j] = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+            if (resb) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int r = j * RPI + lr, row = row_b + j * RPI;
+          const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);
+          if (row < p.M && col_ok) {
+            const float v[4] = {(a4.x * p.alpha + bv.x) * g4[j].x + r4[j].x, (a4.y * p.alpha + bv.y) * g4[j].y + r4[j].y,
+                                (a4.z * p.alpha + bv.z) * g4[j].z + r4[j].z, (a4.w * p.alpha + bv.w) * g4[j].w + r4[j].w};
+            store_row(row, v);
+          }
+        }
+      } else {
+#pragma unroll 1
+        for (int j = 0; j < NJ; ++j) {
+          const int r = j * RPI + lr, row = row_b + j * RPI;
+          const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);
+          if (row < p.M && col_ok) {
+            float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
+            if (p.act == 1) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) v[q4] = silu_f(v[q4]);
+            } else if (p.act == 2) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) v[q4] = gelu_tanh_fast_f(v[q4]);
+            } else if (p.act == 3 || p.act == 4) {   // backward through an activation: times gelu'(aux) / silu'(aux)
+              const float4 x4 = *reinterpret_cast<const float4*>(auxb + (long long)row * p.ldaux + col);
+              const float xs[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) v[q4] *= (p.act == 3 ? gelu_tanh_grad_f(xs[q4]) : silu_grad_f(xs[q4]));
             }
-            __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-            *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
-            *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
-          } else if (exp != 4) {
-            *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            if (p.gate) {
+              const float4 g = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+              v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
+            }
+            if (resb) {
+              const float4 rr = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+              v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+            }
+            if (p.stats) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                gs[q4] += (double)v[q4];
+                gs[4 + q4] += (double)v[q4] * (double)v[q4];
+              }
+            }
+            store_row(row, v);
           }
         }
       }
@@ -1006,7 +1086,13 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     // 1152 / 2304 tiles = 2.25 (75 %) / 3.0 (100 %) rounds, qkv 864 / 1728 = 1.69 (84 %) / 2.25 (75 %)
     auto fill = [](long long tiles, long long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     if (t128 >= 512 && fill(t128, 512) * 1.15 >= fill(t64, 768)) tile = 43;   // 128x128 is ~15 % ahead per tile (B = 32 sweep)
-    else tile = (t64 >= 384 || p.aload) ? 44 : (t64 >= 256 ? 46 : 52);   // small grids: SWEEP_SHAPES=small sweep
+    else if (p.aload || t128 > 512) tile = 44;
+    else if (t128 > 256) tile = 43;     // one round at two workgroups per CU (qkv at B = 8: 432 tiles, 51 us; 864 128x64 tiles are two rounds, 77 us)
+    // at most one 128x128 workgroup per CU (B <= 4): nothing else on the CU hides the HBM latency of the weights -> loader/consumer
+    // kernels with 4-6 stage rings, the largest tile that still gives every CU one (SWEEP_SHAPES=small SWEEP_COLD=1 sweep)
+    else if (t64 > 256) tile = 54;
+    else if (t64 > 128) tile = 56;
+    else tile = 57;
     // implicit-conv loader: the per-piece pixel bookkeeping pushes the cross-iteration pipeline at 128x128 over 256
     // registers (one wave per SIMD) -> the single-set pipeline (PIPE 1) there
     if (p.aload && tile == 43) tile = 21;
@@ -1028,6 +1114,13 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 47: return gemm4_launch(p, s);                        // persistent stream-K 128x128 (gemm4.hip)
     case 51: return launch2<128, 128, 2, 2, 3, 4>(p, s, 51);   // 96 KB: 1 per CU
     case 52: return launch2<128, 64, 2, 2, 3, 4>(p, s, 52);    // 72 KB: 2 per CU
+    // deep rings for grids of at most one workgroup per CU
+    case 53: return launch2<128, 64, 2, 2, 6, 4>(p, s, 53);    // 144 KB
+    case 54: return launch2<128, 128, 2, 2, 4, 4>(p, s, 54);   // 128 KB
+    case 55: return launch2<128, 128, 2, 2, 5, 4>(p, s, 55);   // 160 KB
+    case 56: return launch2<128, 64, 2, 2, 4, 4>(p, s, 56);    // 96 KB
+    case 57: return launch2<64, 64, 2, 2, 6, 4>(p, s, 57);     // 96 KB
+    case 58: return launch2<64, 64, 2, 2, 3, 4>(p, s, 58);     // 48 KB: 3 per CU
     // persistent loader/consumer kernel (gemm3.hip)
     case 61:
     case 62:

@@ -55,3 +55,6 @@ for t in tiles:
         else:
             extra = ""
         print(f"  {w:4d} " + " ".join(f"{x:9.0f}" for x in v) + f" {sum(v):9.0f}" + extra)
+    if any(out[32 + i] for i in range(32)):          # experiment builds: epilogue sub-stamps of waves 0-3 (cycles after the K loop)
+        for w in range(4):
+            print(f"  epilogue wave {w}: " + " ".join(f"{out[32 + w * 8 + i]:7d}" for i in range(8)))
