@@ -74,13 +74,15 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   // the 8 lanes of a row still cover one whole 128-B cache line.
   const char* Ab = reinterpret_cast<const char*>(p.A + (long long)z * p.sA);
   const char* Bb = reinterpret_cast<const char*>(p.B + (long long)z * p.sB);
-  float* __restrict__ Cb = p.C + (long long)z * p.sC;
-  const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
-  const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
-  const float* auxb = p.aux ? p.aux + (long long)z * p.sAux : nullptr;   // act 3 / 4: pre-activation whose derivative multiplies the result
+  // The instruction cache is cold at every launch and the code up to the first DMA is fetched line by line while the whole
+  // chip waits (tools/gemm_stamp.py: 4-6k cycles of prologue): everything only the epilogue needs is computed after the K loop.
   // vector epilogue (below) needs 16-B aligned rows; uniform over the workgroup
-  const bool vec = ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
-                   (((uintptr_t)Cb | (uintptr_t)resb | (uintptr_t)biasb | (uintptr_t)p.gate | (uintptr_t)auxb) & 15) == 0 && exp != 5;
+  auto vector_epilogue = [&]() {
+    const uintptr_t zb = (uintptr_t)(p.C + (long long)z * p.sC) | (p.res ? (uintptr_t)(p.res + (long long)z * p.sRes) : 0) |
+                         (p.bias ? (uintptr_t)(p.bias + (long long)z * p.sBias) : 0) | (uintptr_t)p.gate |
+                         (p.aux ? (uintptr_t)(p.aux + (long long)z * p.sAux) : 0);
+    return ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 && (zb & 15) == 0 && exp != 5;
+  };
   const int KT = p.K >> 5;
 
   if constexpr (PIPE == 4) {
@@ -99,10 +101,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       const int r8l = lane >> 3;
       const char* lsrc[LSEG];
       int linc[LSEG];
+      static_assert((BM / 8) % NW == 0, "piece i of every wave is an A piece or a B piece");
 #pragma unroll
       for (int i = 0; i < LSEG; ++i) {
         const int sgm = lw + i * NW;
-        const bool isA = sgm < BM / 8;
+        const bool isA = i < BM / 8 / NW;                     // == sgm < BM / 8, known per piece
         const int row_l = sgm * 8 + r8l;
         const int row_t = isA ? row_l : row_l - BM;
         const int cs = ((lane & 7) ^ ((row_l >> 1) & 7)) << 4;
@@ -135,7 +138,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         __builtin_amdgcn_s_barrier();                   // barrier kt: tile kt+1 is in LDS
         s2 = s2 == NSTAGE - 1 ? 0 : s2 + 1;
       }
-      if (vec) __syncthreads();                         // the consumers' epilogue barrier
+      if (vector_epilogue()) __syncthreads();           // the consumers' epilogue barrier
       return;
     }
   }
@@ -147,10 +150,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   int a_y[SPW], a_x[SPW];
   long long a_img[SPW];
   bool a_row_ok[SPW], is_a[SPW];
+  static_assert((BM / 8) % NW == 0, "piece i of every wave is an A piece or a B piece");
 #pragma unroll
   for (int i = 0; i < SPW; ++i) {
     const int s = wave + i * NW;
-    const bool isA = s < BM / 8;
+    const bool isA = i < BM / 8 / NW;                         // == s < BM / 8, known per piece (no branch on the wave id)
     const int row_l = s * 8 + r8;                             // LDS row within the stage
     const int row_t = isA ? row_l : row_l - BM;               // row within the A / B tile
     csrc[i] = ((lane & 7) ^ ((row_l >> 1) & 7)) << 4;
@@ -581,6 +585,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
 
   }   // !PIPE
   const unsigned long long t_loop_end = tp;
+  float* __restrict__ Cb = p.C + (long long)z * p.sC;
+  const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
+  const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  const float* auxb = p.aux ? p.aux + (long long)z * p.sAux : nullptr;   // act 3 / 4: pre-activation whose derivative multiplies the result
+  const bool vec = vector_epilogue();
   // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); optional split output
   // Vector path: the accumulators of one 32-row slab go through the (now idle) LDS ring so that every lane owns 4
   // consecutive columns of a row -> bias / gate / residual are read and C is written 16 B per lane, a full 128-B line
@@ -590,57 +599,64 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     constexpr int WCOLS = TN * 32, LPR = WCOLS / 4, RPI = 64 / LPR;   // lanes per row, rows per wave-instruction
     static_assert(NW * 32 * WCOLS * 4 <= NSTAGE * STAGE, "epilogue slab must fit in the ring");
     __syncthreads();                                                  // every wave is done reading the last stage
-    float* stg = reinterpret_cast<float*>(ring) + wave * (32 * WCOLS);
+    // all TM slabs of a wave staged at once when the ring has the room (every tile but 256x128): ONE row loop per tile
+    constexpr bool ALL_IM = (size_t)TM * NW * 32 * WCOLS * 4 <= (size_t)NSTAGE * STAGE;
+    float* stg = reinterpret_cast<float*>(ring) + wave * ((ALL_IM ? TM : 1) * 32 * WCOLS);
     const int lr = lane / LPR, lc = (lane % LPR) * 4;
     const int col = n0 + bcol0 + lc;
     const bool col_ok = col < p.N;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (biasb && col_ok) bv = *reinterpret_cast<const float4*>(biasb + col);
     double gs[8] = {0., 0., 0., 0., 0., 0., 0., 0.};   // p.stats: this lane's column sums / sums of squares (fp64: see common.h)
-    static_for<0, TM>([&](auto im_c) {
+    constexpr int NJ = 32 / RPI;
+    auto write_slab = [&](auto im_c, float* slab) {
       constexpr int im = decltype(im_c)::value;
       static_for<0, TN>([&](auto in_c) {
         constexpr int in = decltype(in_c)::value;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
+        for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
       });
-      // Three bodies, chosen by uniform branches.  The general one carries every epilogue variant (activations and their
-      // derivatives, gate, residual, statistics, split output): ~2.5 KB of code, so its row loop is ROLLED -- unrolled 4-16
-      // times it was 20-40 KB of straight-line code fetched once per tile, and a workgroup that runs one tile (small grids)
-      // spent 11-25k cycles of instruction fetch in it (tools/gemm_stamp.py).  A rolled loop with global loads in it waits
-      // vmcnt(0) every iteration = for its own previous store, so the two cases the DiT forward runs get their own bodies:
-      //   plain   (bias / SiLU / GELU / split output, nothing read per row): rolled, no global load in the loop, the bias
-      //           load is retired before it -> stores are fire-and-forget;
-      //   linear  (act 0 + gate and/or residual, no statistics: attention proj, fc2): the slab's gate / residual reads are
-      //           all issued before the first row is finished, small unrolled body.
-      constexpr int NJ = 32 / RPI;
-      const int row_b = m0 + arow0 + im * 32 + lr;
-      auto store_row = [&](int row, const float (&v)[4]) {
-        if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
-          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-          bf16x4 hi, lo;
+    };
+    auto store_row = [&](int row, const float (&v)[4]) {
+      if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        bf16x4 hi, lo;
 #pragma unroll
-          for (int q4 = 0; q4 < 4; ++q4) {
-            hi[q4] = (__bf16)v[q4];
-            lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
-          }
-          __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-          *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
-          *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
-        } else if (exp != 4) {
-          *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        for (int q4 = 0; q4 < 4; ++q4) {
+          hi[q4] = (__bf16)v[q4];
+          lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
         }
-      };
-      const bool reads_rows = p.gate || resb || p.act >= 3;
-      if (!reads_rows && !p.stats) {
+        __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+        *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+        *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+      } else if (exp != 4) {
+        *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    };
+    // Three row bodies, chosen by uniform branches.  The general one carries every epilogue variant (activations and their
+    // derivatives, gate, residual, statistics, split output): ~2.5 KB of code, so its row loop is ROLLED -- unrolled 4-16
+    // times it was 20-40 KB of straight-line code, and the instruction cache is cold at every launch: a workgroup of the
+    // first round (all of them on small grids) spent 11-25k cycles fetching it (tools/gemm_stamp.py; a second pass over the
+    // same code in the same kernel runs in a third of the time).  A rolled loop with global loads in it waits vmcnt(0) every
+    // iteration = for its own previous store, so the two cases the DiT forward runs get their own bodies:
+    //   plain   (bias / SiLU / GELU / split output, nothing read per row): rolled and branch-free, the bias load is retired
+    //           before the loop -> stores are fire-and-forget;
+    //   linear  (act 0 + gate and/or residual, no statistics: attention proj, fc2): a slab's gate / residual reads are all
+    //           issued before its first row is finished, small unrolled body.
+    const bool reads_rows = p.gate || resb || p.act >= 3;
+    const bool plain = !reads_rows && !p.stats;
+    const bool linear = !plain && p.act == 0 && !p.stats;
+    // rows [0, nj * RPI) of `slab`; slab row 0 is global row row0 - lr
+    auto rolled_rows = [&](const float* slab, int row0, int nj) {
+      if (plain) {
         asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));   // the bias has landed: no VMEM wait inside the loop
         auto plain_rows = [&](auto act_c, auto split_c) {      // branch-free body per (activation, output format)
           constexpr int ACT = decltype(act_c)::value;
           constexpr bool SPLIT = decltype(split_c)::value != 0;
 #pragma unroll 1
-          for (int j = 0; j < NJ; ++j) {
-            const int r = j * RPI + lr, row = row_b + j * RPI;
-            const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
+          for (int j = 0; j < nj; ++j) {
+            const int r = j * RPI + lr, row = row0 + j * RPI;
+            const float4 a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
             if (row < p.M && col_ok) {
               float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
 #pragma unroll
@@ -674,33 +690,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
           else if (p.act == 1) plain_rows(I1{}, I0{});
           else plain_rows(I2{}, I0{});
         }
-      } else if (p.act == 0 && !p.stats) {
-        float4 g4[NJ], r4[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int row = row_b + j * RPI;
-          g4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
-          r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row < p.M && col_ok) {
-            if (p.gate) g4[j] = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
-            if (resb) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int r = j * RPI + lr, row = row_b + j * RPI;
-          const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);
-          if (row < p.M && col_ok) {
-            const float v[4] = {(a4.x * p.alpha + bv.x) * g4[j].x + r4[j].x, (a4.y * p.alpha + bv.y) * g4[j].y + r4[j].y,
-                                (a4.z * p.alpha + bv.z) * g4[j].z + r4[j].z, (a4.w * p.alpha + bv.w) * g4[j].w + r4[j].w};
-            store_row(row, v);
-          }
-        }
       } else {
 #pragma unroll 1
-        for (int j = 0; j < NJ; ++j) {
-          const int r = j * RPI + lr, row = row_b + j * RPI;
-          const float4 a4 = *reinterpret_cast<const float4*>(stg + r * WCOLS + lc);
+        for (int j = 0; j < nj; ++j) {
+          const int r = j * RPI + lr, row = row0 + j * RPI;
+          const float4 a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);
           if (row < p.M && col_ok) {
             float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
             if (p.act == 1) {
@@ -734,7 +728,45 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
           }
         }
       }
-    });
+    };
+    auto linear_rows = [&](const float* slab, int row0) {      // one 32-row slab
+      float4 g4[NJ], r4[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int row = row0 + j * RPI;
+        g4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+        r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < p.M && col_ok) {
+          if (p.gate) g4[j] = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+          if (resb) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int r = j * RPI + lr, row = row0 + j * RPI;
+        const float4 a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);
+        if (row < p.M && col_ok) {
+          const float v[4] = {(a4.x * p.alpha + bv.x) * g4[j].x + r4[j].x, (a4.y * p.alpha + bv.y) * g4[j].y + r4[j].y,
+                              (a4.z * p.alpha + bv.z) * g4[j].z + r4[j].z, (a4.w * p.alpha + bv.w) * g4[j].w + r4[j].w};
+          store_row(row, v);
+        }
+      }
+    };
+    const int row_w = m0 + arow0 + lr;                          // this lane's row in slab row lr of the wave's first slab
+    if constexpr (ALL_IM) {
+      static_for<0, TM>([&](auto im_c) { write_slab(im_c, stg + decltype(im_c)::value * 32 * WCOLS); });
+      if (linear) {
+        static_for<0, TM>([&](auto im_c) { linear_rows(stg + decltype(im_c)::value * 32 * WCOLS, row_w + decltype(im_c)::value * 32); });
+      } else {
+        rolled_rows(stg, row_w, TM * NJ);
+      }
+    } else {
+      static_for<0, TM>([&](auto im_c) {
+        write_slab(im_c, stg);
+        if (linear) linear_rows(stg, row_w + decltype(im_c)::value * 32);
+        else rolled_rows(stg, row_w + decltype(im_c)::value * 32, NJ);
+      });
+    }
     if (p.stats) {   // GroupNorm partial sums of this tile (uniform branch): lanes -> waves -> groups, all in a fixed order
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) {
@@ -1087,7 +1119,9 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     auto fill = [](long long tiles, long long slots) { return (double)tiles / (double)(((tiles + slots - 1) / slots) * slots); };
     if (t128 >= 512 && fill(t128, 512) * 1.15 >= fill(t64, 768)) tile = 43;   // 128x128 is ~15 % ahead per tile (B = 32 sweep)
     else if (p.aload || t128 > 512) tile = 44;
-    else if (t128 > 256) tile = 43;     // one round at two workgroups per CU (qkv at B = 8: 432 tiles, 51 us; 864 128x64 tiles are two rounds, 77 us)
+    // one round of 128x128 at two workgroups per CU where 128x64 tiles would need two (qkv at B = 8: 432 tiles, 51 us against 77 us)
+    // (in situ, 288 / 576 tiles both ways: fc1 at B = 4, wide and short, 51.6 us on 128x128 against 58.8; proj at B = 16, tall, 54.1 against 52.2)
+    else if (t128 > 256) tile = (t64 > 768 || p.N >= 4 * p.M) ? 43 : 44;
     // at most one 128x128 workgroup per CU (B <= 4): nothing else on the CU hides the HBM latency of the weights -> loader/consumer
     // kernels with 4-6 stage rings, the largest tile that still gives every CU one (SWEEP_SHAPES=small SWEEP_COLD=1 sweep)
     else if (t64 > 256) tile = 54;
