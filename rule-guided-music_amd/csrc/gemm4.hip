@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
       if constexpr (st == 1 && m < SPW) {
         if (issue) {
           dma16_g4(src[m], dst + (wave + m * NW) * 1024);
-          src[m] += EDGE ? inc[m] : 128;
+          if constexpr (EDGE) src[m] += inc[m]; else src[m] += 128;
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
   static_for<0, SPW>([&](auto ic) {
     constexpr int i = decltype(ic)::value;
     dma16_g4(src[i], ring + (wave + i * NW) * 1024);
-    src[i] += EDGE ? inc[i] : 128;
+    if constexpr (EDGE) src[i] += inc[i]; else src[i] += 128;
   });
   advance();
   if (Gw > 1) {
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
     static_for<0, SPW>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       dma16_g4(src[i], ring + STAGE + (wave + i * NW) * 1024);
-      src[i] += EDGE ? inc[i] : 128;
+      if constexpr (EDGE) src[i] += inc[i]; else src[i] += 128;
     });
     advance();
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
