@@ -641,11 +641,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // iteration = for its own previous store, so the two cases the DiT forward runs get their own bodies:
     //   plain   (bias / SiLU / GELU / split output, nothing read per row): rolled and branch-free, the bias load is retired
     //           before the loop -> stores are fire-and-forget;
-    //   linear  (act 0 + gate and/or residual, no statistics: attention proj, fc2): a slab's gate / residual reads are all
-    //           issued before its first row is finished, small unrolled body.
+    //   linear  (act 0 + gate and/or residual: attention proj, fc2, the residual convs of the VAE with their statistics): a slab's
+    //           gate / residual reads are all issued before its first row is finished, small unrolled body.
     const bool reads_rows = p.gate || resb || p.act >= 3;
     const bool plain = !reads_rows && !p.stats;
-    const bool linear = !plain && p.act == 0 && !p.stats;
+    const bool linear = !plain && p.act == 0 && reads_rows;
     // rows [0, nj * RPI) of `slab`; slab row 0 is global row row0 - lr
     auto rolled_rows = [&](const float* slab, int row0, int nj) {
       if (plain) {
@@ -691,6 +691,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
           else plain_rows(I2{}, I0{});
         }
       } else {
+        asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));   // as above: without per-row reads (conv + statistics) no VMEM wait is left in the loop
 #pragma unroll 1
         for (int j = 0; j < nj; ++j) {
           const int r = j * RPI + lr, row = row0 + j * RPI;
@@ -748,6 +749,13 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         if (row < p.M && col_ok) {
           const float v[4] = {(a4.x * p.alpha + bv.x) * g4[j].x + r4[j].x, (a4.y * p.alpha + bv.y) * g4[j].y + r4[j].y,
                               (a4.z * p.alpha + bv.z) * g4[j].z + r4[j].z, (a4.w * p.alpha + bv.w) * g4[j].w + r4[j].w};
+          if (p.stats) {
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+              gs[q4] += (double)v[q4];
+              gs[4 + q4] += (double)v[q4] * (double)v[q4];
+            }
+          }
           store_row(row, v);
         }
       }
