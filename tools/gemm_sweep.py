@@ -19,6 +19,8 @@ elif os.environ.get("SWEEP_SHAPES") == "small":      # B = 2 / 4 / 8 latents
 elif os.environ.get("SWEEP_SHAPES") == "cls":        # DiTRotary-S/8 classifier (D = 384) at B = 32: forward and dgrad shapes
     SHAPES_OVERRIDE = [("qkv", 8224, 1152, 384), ("proj", 8224, 384, 384), ("fc1", 8224, 1536, 384), ("fc2", 8224, 384, 1536),
                        ("d_qkv", 8224, 384, 1152), ("d_fc2", 8224, 1536, 384), ("d_fc1", 8224, 384, 1536)]
+elif os.environ.get("SWEEP_SHAPES") == "conv":       # dense stand-ins for the VAE's 3x3 convs (K = 9 Cin): huge M, N = Cout
+    SHAPES_OVERRIDE = [("c128", 1 << 20, 128, 1152), ("c256", 1 << 19, 256, 2304), ("c512", 1 << 17, 512, 4608)]
 elif os.environ.get("SWEEP_SHAPES") == "b32":        # XL backbone at B = 32 (C3)
     SHAPES_OVERRIDE = [("qkv", 8192, 3456, 1152), ("proj", 8192, 1152, 1152), ("fc1", 8192, 4608, 1152), ("fc2", 8192, 1152, 4608)]
 else:
