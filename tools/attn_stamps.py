@@ -25,10 +25,16 @@ for _ in range(5):
 torch.cuda.synchronize()
 buf = (C.c_longlong * (128 + 2048))()
 assert lib.rgm_attn_stamps(buf) == 0
-names = ["stage K/V", "barrier", "Q frags", "S^T MFMA", "softmax", "PV MFMA", "store"]
-for w in range(8):
-    t = [buf[w * 16 + i] for i in range(8)]
-    print(f"wave {w}: " + "  ".join(f"{names[i]} {t[i + 1] - t[i]:6d}" for i in range(7)) + f"   total {t[7] - t[0]} shader clocks")
+if os.environ.get("RGM_ATTN_BLOCKED", "1") != "0":   # key-blocked kernel: request+Q | deposit 0 | request 1 + barrier | per block: S^T | softmax + PV | deposit + request + barrier
+    names = ["req0+Q", "dep0", "req1+bar"] + [f"b{b} {x}" for b in range(4) for x in ("S^T", "sm+PV", "dep+bar")]
+    for w in range(8):
+        t = [buf[w * 16 + i] for i in range(16)]
+        print(f"wave {w}: " + " ".join(f"{names[i]} {t[i + 1] - t[i]:5d}" for i in range(14)) + f"  store {t[15] - t[14]}  total {t[15] - t[0]}")
+else:
+    names = ["stage K/V", "barrier", "Q frags", "S^T MFMA", "softmax", "PV MFMA", "store"]
+    for w in range(8):
+        t = [buf[w * 16 + i] for i in range(8)]
+        print(f"wave {w}: " + "  ".join(f"{names[i]} {t[i + 1] - t[i]:6d}" for i in range(7)) + f"   total {t[7] - t[0]} shader clocks")
 
 import numpy as np  # noqa: E402
 rt = np.array(buf[128:128 + 2 * N * heads], dtype=np.int64).reshape(-1, 2)
@@ -36,4 +42,5 @@ t0 = rt[:, 0].min()
 print("workgroup entry  (us after the first): min %.2f median %.2f max %.2f" % tuple(np.percentile((rt[:, 0] - t0) / 100.0, [0, 50, 100])))
 print("workgroup exit   (us after the first entry): min %.2f median %.2f max %.2f" % tuple(np.percentile((rt[:, 1] - t0) / 100.0, [0, 50, 100])))
 print("workgroup span us: min %.2f median %.2f max %.2f" % tuple(np.percentile((rt[:, 1] - rt[:, 0]) / 100.0, [0, 50, 100])))
-print("block 7 span %.2f us -> shader clock ~ %.2f GHz" % ((rt[7, 1] - rt[7, 0]) / 100.0, (buf[7] - buf[0]) / ((rt[7, 1] - rt[7, 0]) * 10.0)))
+last = 15 if os.environ.get("RGM_ATTN_BLOCKED", "1") != "0" else 7
+print("block 7 span %.2f us -> shader clock ~ %.2f GHz" % ((rt[7, 1] - rt[7, 0]) / 100.0, (buf[last] - buf[0]) / ((rt[7, 1] - rt[7, 0]) * 10.0)))
