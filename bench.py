@@ -513,6 +513,9 @@ def main():
         Rn = args.simulate_ranks
         scg_shard.partition = lambda n, world_size=None, rank=None: (0, n // Rn, True) if n % Rn == 0 else (0, n, False)
         scg_shard.gather_totals = lambda local: local.repeat(Rn, 1)     # same table shape and selection work as the real all-gather
+        from rgm import batch_shard                                     # the x_t forward of a search step: this rank's rows only
+        batch_shard.partition_rows = lambda B, ws=None, r=None: ((0, B // Rn) if B % Rn == 0 else ((0, 1) if Rn % B == 0 else None))
+        batch_shard.gather_rows = lambda ts: [t.repeat((Rn,) + (1,) * (t.dim() - 1)) for t in ts]   # stand-in: shapes, not values
     if args.workload in ("c2", "c3", "dps_rule"):
         work.d.batch_shard = False            # the headline runs one independent chain per GPU (weak scaling): nothing to shard
     for _ in range(args.warmup):

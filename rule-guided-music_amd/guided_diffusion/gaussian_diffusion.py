@@ -251,6 +251,37 @@ class GaussianDiffusion:
         sample, x0 = batch_shard.gather_rows([out["sample"].float(), out["pred_xstart"].float()])
         return {"sample": sample, "pred_xstart": x0}
 
+    def _search_step_inputs(self, model, cond_fn, x, t, model_kwargs, denoised_fn, edit_kwargs, clip_denoised, record=False,
+                            grad_on_edit_rows=True):
+        """(eps after the edit replacement, guidance gradient or None) of an SCG search step.  These two forwards are per-sample work
+        that comes before the candidate search; under torch.distributed their batch rows are shared out over the ranks
+        (batch_shard.partition_rows) and ONE all-gather gives every rank the same full-batch eps and gradient -- the search that
+        follows needs them identical everywhere ("or shard that forward over batch and all-gather 32 KiB/sample")."""
+        B = x.shape[0]
+
+        def run(xr, tr, kw, ekw):
+            eps = self._model_eps(xr, self._wrap_model(model)(xr, self._scale_timesteps(tr), **kw), tr, denoised_fn)
+            if ekw is not None:
+                eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw)
+            grad = None
+            if cond_fn is not None:
+                if ekw is None or not grad_on_edit_rows:      # (ddim_sample differentiates the whole latent, like the reference)
+                    grad = self._wrap_model(cond_fn)(xr, self._scale_timesteps(tr), **kw)
+                else:
+                    grad = self._edit_grad(self._wrap_model(cond_fn), xr, self._scale_timesteps(tr), kw, ekw)
+            return eps, grad
+
+        part = None
+        if self.scg_shard and self.batch_shard and self._rows is None and not record and not self._learned():
+            part = batch_shard.partition_rows(B)
+        if part is None:
+            return run(x, t, model_kwargs, edit_kwargs)
+        b0, nb = part
+        eps, grad = run(x[b0:b0 + nb].contiguous(), t[b0:b0 + nb].contiguous(), batch_shard.slice_rows(model_kwargs, B, b0, nb),
+                        batch_shard.slice_rows(edit_kwargs, B, b0, nb) if edit_kwargs is not None else None)
+        full = batch_shard.gather_rows([eps.float()] + ([grad.float()] if grad is not None else []))
+        return full[0][:B].contiguous(), (full[1][:B].contiguous() if grad is not None else None)
+
     def _scale_timesteps(self, t):
         return t.float() * (1000.0 / self.num_timesteps) if self.rescale_timesteps else t
 
@@ -672,12 +703,24 @@ class GaussianDiffusion:
             return sharded
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
+        # with scg_kwargs given the guidance schedule only gates the SCG search: condition_mean runs on every step (reference :691)
+        guided = cond_fn is not None and (use_guidance or scg_kwargs is not None)
+        dps = guided and getattr(guidance_kwargs, "method", None) == "dps"
+        search = scg_kwargs is not None and use_guidance and not dps and self._t0(t) > self.t_end
+        if search:      # the two per-sample forwards before the candidate search: rows shared out over the ranks when there are any
+            eps, grad = self._search_step_inputs(model, cond_fn if guided else None, x, t, model_kwargs, denoised_fn, edit_kwargs,
+                                                 clip_denoised, record)
+            mean, x0, g = self._step("ddpm", x, eps, grad, None, t, clip_denoised, want_g=True)
+            # the reference hands the UNWRAPPED model to scg_sample here (gaussian_diffusion.py:711):
+            # with a re-spaced chain the candidates are evaluated at the un-mapped t.  Reproduced, not fixed.
+            sample = self.scg_sample(model, t, mean, g, embed_model, scale_factor, model_kwargs=model_kwargs,
+                                     scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
+                                     dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record)
+            return {"sample": sample, "pred_xstart": x0}
         eps = self._model_eps(x, self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
-        # with scg_kwargs given the guidance schedule only gates the SCG search: condition_mean runs on every step (reference :691)
-        guided = cond_fn is not None and (use_guidance or scg_kwargs is not None)
-        if guided and getattr(guidance_kwargs, "method", None) == "dps":
+        if dps:
             mean, x0, g = self._step("ddpm", x, eps, None, None, t, clip_denoised, want_g=True)
             # the reference hands the UNWRAPPED model to condition_mean (:692-697): on a re-spaced chain the DPS forward
             # runs at the un-mapped t, like scg_sample's.  Reproduced, not fixed.
@@ -703,18 +746,8 @@ class GaussianDiffusion:
                 grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
             else:
                 grad = self._edit_grad(self._wrap_model(cond_fn), x, self._scale_timesteps(t), model_kwargs, edit_kwargs)
-        if scg_kwargs is None:
+        if scg_kwargs is None or self._t0(t) > self.t_end:       # (the search steps of an SCG chain returned above)
             sample, x0, _ = self._step("ddpm", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised)
-        elif self._t0(t) > self.t_end:
-            if use_guidance:
-                mean, x0, g = self._step("ddpm", x, eps, grad, None, t, clip_denoised, want_g=True)
-                # the reference hands the UNWRAPPED model to scg_sample here (gaussian_diffusion.py:711):
-                # with a re-spaced chain the candidates are evaluated at the un-mapped t.  Reproduced, not fixed.
-                sample = self.scg_sample(model, t, mean, g, embed_model, scale_factor, model_kwargs=model_kwargs,
-                                         scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
-                                         dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record)
-            else:
-                sample, x0, _ = self._step("ddpm", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised)
         else:
             sample, x0, _ = self._step("ddpm", x, eps, grad, None, t, clip_denoised)
         return {"sample": sample, "pred_xstart": x0}
@@ -733,28 +766,29 @@ class GaussianDiffusion:
         model_kwargs = model_kwargs or {}
         use_guidance = self._use_guidance(guidance_kwargs, t)
         wrapped = self._wrap_model(model)
+        if cond_fn is not None and use_guidance and getattr(guidance_kwargs, "method", None) == "dps":
+            # the reference feeds the (B,) log-probabilities of a DPS cond_fn to condition_score as if they were a gradient
+            # (:467-482), which does not broadcast against the latent either
+            raise NotImplementedError("DPS guidance is defined for the DDPM step (p_sample) only; ddim_sample applies "
+                                      "condition_score, which needs a gradient cond_fn")
+        if scg_kwargs is not None and use_guidance and self._t0(t) > self.t_end:
+            # a search step: the per-sample forwards that precede the candidate search are shared out over the ranks (p_sample)
+            eps, grad = self._search_step_inputs(model, cond_fn, x, t, model_kwargs, denoised_fn, edit_kwargs, clip_denoised, record,
+                                                 grad_on_edit_rows=False)
+            mean, x0, sigma = self._step("ddim", x, eps, grad, None, t, clip_denoised, eta=eta, want_g=True)
+            sample = self.scg_sample(wrapped, t, mean, sigma, embed_model, scale_factor, model_kwargs=model_kwargs,
+                                     scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
+                                     dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record, record_freq=10)
+            return {"sample": sample, "pred_xstart": x0}
         eps = self._model_eps(x, wrapped(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
         grad = None
         if cond_fn is not None and use_guidance:
-            if getattr(guidance_kwargs, "method", None) == "dps":
-                # the reference feeds the (B,) log-probabilities of a DPS cond_fn to condition_score as if they were a gradient
-                # (:467-482), which does not broadcast against the latent either
-                raise NotImplementedError("DPS guidance is defined for the DDPM step (p_sample) only; ddim_sample applies "
-                                          "condition_score, which needs a gradient cond_fn")
             grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
-        if scg_kwargs is None:
+        if scg_kwargs is None or self._t0(t) > self.t_end:
+            # (with scg_kwargs: t0 > t_end here, so the kernel's [t != t_end] mask is 1, as in the reference's unmasked draw)
             sample, x0, _ = self._step("ddim", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised, eta=eta)
-        elif self._t0(t) > self.t_end:
-            if use_guidance:
-                mean, x0, sigma = self._step("ddim", x, eps, grad, None, t, clip_denoised, eta=eta, want_g=True)
-                sample = self.scg_sample(wrapped, t, mean, sigma, embed_model, scale_factor, model_kwargs=model_kwargs,
-                                         scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
-                                         dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record, record_freq=10)
-            else:
-                # t0 > t_end here, so the kernel's [t != t_end] mask is 1, as in the reference's unmasked draw
-                sample, x0, _ = self._step("ddim", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised, eta=eta)
         else:
             sample, x0, _ = self._step("ddim", x, eps, grad, None, t, clip_denoised, eta=eta)
         return {"sample": sample, "pred_xstart": x0}

@@ -5,7 +5,9 @@ A reverse step is independent per sample everywhere outside SCG's candidate sear
 value-and-gradient, DPS, the fused step update and the noise draw (counter-based: row b of a draw is the same numbers on any
 rank).  Rank r of R therefore computes rows [r*B/R, (r+1)*B/R) of the step and ONE all-gather of the new latents (and the x0
 estimates: 2 x 32 KiB per sample) gives every rank the full batch for the next step.  SCG search steps keep their own split
-(candidates, rgm/scg_shard.py); batches that do not divide by the world size stay replicated.
+(candidates, rgm/scg_shard.py) for the search itself; the x_t forward and the classifier gradient that come BEFORE the search are
+shared out by rows too (partition_rows: one all-gather of eps (+ gradient), 32 KiB per sample each), instead of every rank
+repeating them.  Batches that do not divide by the world size stay replicated.
 
 Pure host logic (no HIP calls): the N > 1 control flow is testable with world_size-2 gloo on CPU.
 """
@@ -27,6 +29,25 @@ def partition(B, world_size=None, rank=None):
         return 0, B, False
     per = B // world_size
     return rank * per, per, True
+
+
+def partition_rows(B, world_size=None, rank=None):
+    """Rows of the x_t forward (and classifier gradient) of an SCG search step this rank computes: (first row, rows) or None =
+    replicated.  B % R == 0: B / R rows each, in rank order.  R % B == 0 (more ranks than samples, e.g. B = 4 on 8 GPUs): one row
+    each, rank r takes row r % B -- the all-gather then holds rows 0..B-1 in its first B entries (ranks 0..B-1) and copies after."""
+    if world_size is None:
+        world_size, rank = world()
+    if world_size <= 1 or B <= 0:
+        return None
+    if B % world_size == 0:
+        per = B // world_size
+        return rank * per, per
+    if world_size % B == 0:
+        return rank % B, 1
+    return None
+
+
+_orig_partition_rows = partition_rows        # (tests replace partition_rows with one rank's view and still need the rule itself)
 
 
 def slice_rows(obj, B, b0, nb):

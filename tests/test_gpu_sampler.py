@@ -253,6 +253,63 @@ def test_sharded_scg_rank_sees_same_winner_and_rebuilds_it(monkeypatch):
     assert len(set(ref_idx.tolist())) >= 1
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_search_step_forward_rows_are_shared_out_over_the_ranks(monkeypatch, world):
+    """SURVEY 8e, the x_t forward of an SCG search step: replayed as 'rank r of R' on one GPU the step runs the eps-network on this
+    rank's rows only (R = 2: one row of the batch of 2; R = 4 > B: one row each, ranks 2 and 3 repeat rows 0 and 1), the stand-in
+    all-gather supplies the other rows as the owning rank computes them, and the step ends on the unsharded winners and a latent
+    equal to the unsharded one up to the batch-size dependence of the GEMM tiles (rows computed in a batch of 1 instead of 2)."""
+    from types import SimpleNamespace
+    from gpu_util import dev, rel
+    from rgm import batch_shard
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    g = load_golden("steps")
+    m, vae = _dit(SM, 11), _vae(2)
+    tgt = {"pitch_hist": dev(g["scg.target.pitch_hist"]), "note_density": dev(g["scg.target.note_density"])}
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    scg = {"num_samples": 16, "pitch_hist": 40., "note_density": 1.}
+    x, t, y = dev(g["x"]), dev(g["scg.t"]), dev(g["y"])
+    B = x.shape[0]
+    mf = _model_fn(m)
+
+    def run(d):
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=99)
+        out = d.p_sample(mf, x, t, clip_denoised=False, model_kwargs={"y": y, "rule": tgt}, embed_model=vae, scale_factor=1.2465,
+                         guidance_kwargs=guid, scg_kwargs=scg)
+        return out["sample"], d.last_scg["max_ind"].clone()
+
+    ref_sample, ref_idx = run(_diffusion(""))
+    dd = _diffusion("")
+    calls = []
+    for rank in range(world):
+        part = batch_shard._orig_partition_rows(B, world, rank)
+        assert part == ((rank * B // world, B // world) if B % world == 0 else (rank % B, 1))
+        monkeypatch.setattr(batch_shard, "partition_rows", lambda b, ws=None, r=None, part=part: part)
+
+        def fake_gather(tensors, rank=rank):                       # every rank's rows, each computed in that rank's own small batch
+            out = []
+            for tns in tensors:
+                rows = []
+                for r in range(world):
+                    b0, nb = batch_shard._orig_partition_rows(B, world, r)
+                    if r == rank:
+                        rows.append(tns)
+                    else:
+                        with torch.no_grad():
+                            tr = t[b0:b0 + nb].contiguous()
+                            rows.append(dd._wrap_model(mf)(x[b0:b0 + nb].contiguous(), dd._scale_timesteps(tr), y=y[b0:b0 + nb],
+                                                           rule={k: v[b0:b0 + nb] for k, v in tgt.items()}).float())
+                out.append(torch.cat(rows, dim=0))
+            calls.append((rank, tensors[0].shape[0]))
+            return out
+        monkeypatch.setattr(batch_shard, "gather_rows", fake_gather)
+        s, idx = run(_diffusion(""))
+        assert torch.equal(idx, ref_idx), f"rank {rank} of {world}: other winners"
+        assert rel(s.cpu().numpy(), ref_sample.cpu().numpy()) < 2e-5, rank
+    assert calls == [(r, max(1, B // world)) for r in range(world)]
+
+
 def test_sharded_segmentwise_scg_matches_unsharded(monkeypatch):
     """dc.base > 0 (per-segment winners, reference :562-592) under candidate sharding: rank r scores its half of the
     candidates on every segment, the stand-in all-gather completes the (n, S, B) table, every rank picks the same

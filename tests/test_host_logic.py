@@ -395,9 +395,15 @@ def _batch_worker(rank, world, port, q):
     mine = batch_shard.slice_rows(kw, B, b0, nb)
     ok = (mine["y"].tolist() == list(range(b0, b0 + nb)) and torch.equal(mine["rule"]["note_density"], kw["rule"]["note_density"][b0:b0 + nb])
           and mine["scale"] == 3.0 and mine["mask"].shape == (1, 4, 8, 2))
+    # rows of an SCG search step's forwards: B % R == 0 -> blocks; more ranks than samples -> one row each, row = rank % B
+    rows_ok = (batch_shard.partition_rows(6) == (rank * 3, 3) and batch_shard.partition_rows(1) == (0, 1)
+               and batch_shard.partition_rows(4, 8, 5) == (1, 1) and batch_shard.partition_rows(3) is None
+               and batch_shard.partition_rows(4, 1, 0) is None)
+    one = batch_shard.gather_rows([x[:1] + rank])[0]               # the B = 1 case: both ranks hold "row 0"; the first entry is rank 0's
+    rows_ok = rows_ok and one.shape[0] == 2 and torch.equal(one[:1], x[:1])
     new = x[b0:b0 + nb] * 2 + 1                                   # this rank's rows of "the step"
     full, full2 = batch_shard.gather_rows([new, -new])
-    q.put((rank, b0, nb, sharded, ok, torch.equal(full, x * 2 + 1) and torch.equal(full2, -(x * 2 + 1)), batch_shard.partition(7)))
+    q.put((rank, b0, nb, sharded, ok and rows_ok, torch.equal(full, x * 2 + 1) and torch.equal(full2, -(x * 2 + 1)), batch_shard.partition(7)))
     dist.destroy_process_group()
 
 
