@@ -124,6 +124,13 @@ size_t rgm_gemm_streamk_workspace_bytes(void);
 int rgm_set_streamk(int mode);
 int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias, int act,
                       int tile, int out_split, void* ws, size_t ws_bytes, void* stream);
+/* The general pre-split entry: C = (act(alpha * A . B^T + bias)) * gate + res with explicit row strides (elements), the per-sample
+ * adaLN gate gate[(row / rows_per_gate) * gate_ld + col] and a residual that may alias C (the proj / fc2 epilogue of a DiT block,
+ * guided_diffusion/dit.py:332-336), explicit tile as in rgm_gemm_split (47 = persistent stream-K, 71.. = 256x256 tiles) and the
+ * caller's scratch (NULL: no workspace-backed decomposition). */
+int rgm_gemm_split_epi(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
+                       const float* bias, int act, float alpha, const float* gate, int gate_ld, int rows_per_gate,
+                       const float* res, int ldres, int tile, int out_split, void* ws, size_t ws_bytes, void* stream);
 /* Same as rgm_gemm without gate/residual but with an explicit tile shape in the low 4 bits (1: 128x128,
  * 2: 128x64, 3: 64x64, 4: 32x128, 0: auto) and an explicit precision in bits 4.. (0: library default,
  * 1: fp32, 2: bf16x3) -- used by the parity tests and tile-selection experiments. */

@@ -300,6 +300,118 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       if (kt + 1 < KT) iter(f1, f0, kt + 1);
     }
   } else
+  if constexpr (PIPE == 5) {
+    // ONE wave per SIMD, 128x128 accumulators per wave (256x256 per workgroup, 256 AGPRs), everything else hidden behind the wave's
+    // own MFMA stream.  Why: at 128x128 per workgroup (64x64 per wave) a K-tile is 24 MFMAs against 16 fragment reads + 8 DMA
+    // pieces per wave and 42 B/clk/CU of LDS-DMA (70 % of what the texture addresser delivers: DESIGN 4/4b, the operand stream
+    // alone takes longer than the MFMAs); a 128x128 wave tile makes it 96 MFMAs against 32 reads + 16 pieces and 21 B/clk/CU.
+    // There is no second wave on the SIMD to fill a stall, so a K-tile is two phases of 48 MFMAs, each carrying the LDS reads
+    // of the NEXT k16 step (register double buffer, 2 x 64 VGPRs) and, in the second phase, the DMA of the next-but-one K-tile:
+    //   phase A(kt): MFMAs of (kt, step 0) | reads of (kt, step 1)
+    //   wait own DMA of tile kt+1, own reads of tile kt; s_barrier   (tile kt+1 complete in LDS, tile kt's stage is free)
+    //   phase B(kt): MFMAs of (kt, step 1) | reads of (kt+1, step 0) | DMA of tile kt+2 into tile kt's stage
+    // so every DMA has 1.5-3 k cycles to land and every fragment 1.5 k.  The last two K-tiles run peeled bodies without the
+    // reads / DMA they do not need: no branch sits between the MFMAs of the steady state.
+    static_assert(NSTAGE == 2, "PIPE 5: 2-stage ring");
+    constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
+    constexpr int NRD = 2 * (TM + TN);                    // ds_read_b128 per k16 step
+    auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
+      if (ALOAD == 1 && kt % cpt == 0) {
+        const int tap = kt / cpt;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int Win = p.W >> p.ups;
+#pragma unroll
+        for (int i = 0; i < SPW; ++i) {
+          if (!is_a[i]) continue;
+          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+          const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
+                      : zero_page + csrc[i];
+          inc[i] = ok ? 128 : 0;
+        }
+      }
+    };
+    static_assert(NRD * 3 <= NM && SPW * 3 <= NM, "one read / one DMA piece per three MFMA slots");
+    struct FragsK {
+      bf16x8 a[TM][2], b[TN][2];                          // [frag][hi, lo] of one k16 step
+    };
+    auto read_one = [&](FragsK& f, const char* As, auto stc, auto jc) {
+      constexpr int st = decltype(stc)::value, j = decltype(jc)::value;
+      constexpr int fi = j / 2, lo = j % 2;
+      const int chunk = ((4 * lo + 2 * st + hh) ^ rq) << 4;
+      if constexpr (fi < TM) {
+        f.a[fi][lo] = *reinterpret_cast<const bf16x8*>(As + (arow0 + fi * 32 + l31) * 128 + chunk);
+      } else {
+        f.b[fi - TM][lo] = *reinterpret_cast<const bf16x8*>(As + BM * 128 + (bcol0 + (fi - TM) * 32 + l31) * 128 + chunk);
+      }
+    };
+    // one k16 step: NM MFMAs from `cur`; READ: the NRD reads of step `stn` of the tile at `rd` into `nxt`; DMA: this wave's SPW
+    // pieces of the next-but-one tile into `dst`
+    auto phase = [&](const FragsK& cur, FragsK& nxt, auto readc, auto dmac, auto stnc, const char* rd, char* dst) {
+      constexpr bool READ = decltype(readc)::value != 0, DMA = decltype(dmac)::value != 0;
+      static_for<0, NM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value;
+        constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
+        // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
+        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
+        if constexpr (READ && m % 3 == 0 && m / 3 < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / 3>{});
+        if constexpr (DMA && m % 3 == 1 && m / 3 < SPW) {
+          constexpr int i = m / 3;
+          dma16(src[i], dst + (wave + i * NW) * 1024);
+          src[i] += inc[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    using Y = std::integral_constant<int, 1>;
+    using Nn = std::integral_constant<int, 0>;
+    FragsK f0, f1;
+    retarget(0);
+    static_for<0, SPW>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      dma16(src[i], ring + (wave + i * NW) * 1024);
+      src[i] += inc[i];
+    });
+    if (KT > 1) {
+      retarget(1);
+      static_for<0, SPW>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        dma16(src[i], ring + STAGE + (wave + i * NW) * 1024);
+        src[i] += inc[i];
+      });
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SPW) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    static_for<0, NRD>([&](auto jc) { read_one(f0, ring, Nn{}, jc); });
+    auto handover = [&]() {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of the next tile landed, own reads of this tile done
+      __builtin_amdgcn_s_barrier();
+    };
+    int kt = 0;
+    for (; kt + 2 < KT; ++kt) {                           // steady state: tiles kt+1 and kt+2 exist
+      char* cs = ring + (kt & 1) * STAGE;
+      char* ns = ring + ((kt + 1) & 1) * STAGE;
+      phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
+      retarget(kt + 2);
+      handover();
+      phase(f1, f0, Y{}, Y{}, Nn{}, ns, cs);
+    }
+    if (kt + 1 < KT) {                                    // last but one: nothing left to fetch
+      char* cs = ring + (kt & 1) * STAGE;
+      char* ns = ring + ((kt + 1) & 1) * STAGE;
+      phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
+      handover();
+      phase(f1, f0, Y{}, Nn{}, Nn{}, ns, nullptr);
+      ++kt;
+    }
+    {                                                     // last tile
+      char* cs = ring + (kt & 1) * STAGE;
+      phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
+      phase(f1, f0, Nn{}, Nn{}, Nn{}, nullptr, nullptr);
+    }
+  } else
   if constexpr (PIPE == 3) {
     // Cross-iteration register pipeline: the fragments of K-tile kt+1 are requested (behind the barrier that says the
     // tile has landed) BEFORE the second k16 step of tile kt is multiplied, into a second register set, so neither the
@@ -874,6 +986,7 @@ __global__ __launch_bounds__(256) void gemm2_dual_kernel(GemmParams pb, GemmPara
 }
 
 static char* g_zero_page = nullptr;
+static int g_big_tiles = getenv("RGM_BIG_TILES") ? atoi(getenv("RGM_BIG_TILES")) : 1;   // 0: heuristic never picks the 256x256 kernel (A/B runs)
 static long long* g_dbg = nullptr;   // set by rgm_gemm2_dbg: stamped kernel variant (tools/gemm_stamp.py)
 // timing experiments only (wrong results): RGM_GEMM2_EXP=1 no DMA after the prologue, =2 DMA + barriers only
 static int g_exp = RGM_EXP_ENV("RGM_GEMM2_EXP");
@@ -1063,8 +1176,59 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
                            ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
                            (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate | (uintptr_t)p.aux) & 15) == 0),
               "gemm2: GroupNorm partial sums need 128-row tiles, N%%64==0, group width 4/8/16 and 16-byte aligned rows");
-  int S = (p.stats ? 1 : splitk_factor(p));
+  // ---- 256x256 tiles, one wave per SIMD (tile 71, PIPE 5): 380-420 TFLOP/s per full round of 256 workgroups against 300-360 for
+  // the 128x128 kernels (tools/gemm_sweep.py: qkv at B = 16 86 us against 101, fc1 at n.B = 64 417 against 464), but ONE workgroup
+  // per CU: a launch costs ceil(tiles / 256) rounds of ~(33 + 1.44 KT) us whatever the last round's fill.  Three ways to keep the
+  // rounds full: the whole GEMM when its last round is at least 84 % full; K slices (as a batch, reduced by splitk_reduce_kernel)
+  // when the tiles fill less than one round and K is long (fc2 at B = 16: 80 tiles x 3 slices); whole rounds of column tiles on
+  // this kernel and the leftover columns through the heuristic again (fc1 at B = 16: 16 x 16 tiles + 512 columns on 128x64 tiles).
+  int S = 1;
   int sk_tile = 44;
+  const bool big_ok = p.tile == 0 && g_big_tiles && !p.aload && p.batch == 1 && !p.stats && p.act < 3 && !p.aux && p.M >= 2048 &&
+                      ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 &&
+                      (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0;
+  if (big_ok) {
+    const int tm = cdiv(p.M, 256), tn = cdiv(p.N, 256), KT = p.K >> 5;
+    const long long total = (long long)tm * tn;
+    const long long rounds = (total + 255) / 256;
+    const double waste = (double)((long long)tn * 256 - p.N) / ((double)tn * 256);      // columns of the edge tiles beyond N
+    if (total >= 200 && (double)total / (double)(rounds * 256) >= 0.84 && waste <= 0.08) {
+      GemmParams q = p;
+      q.tile = 71;
+      return gemm2_launch(q, s);
+    }
+    if (total < 200 && KT >= 72 && p.sk_ws && waste <= 0.12) {
+      int best = 1;
+      for (int c = 2; c <= 8; ++c) {
+        if (KT % c || KT / c < 24 || total * c > 256) continue;
+        if ((size_t)c * p.M * p.N * sizeof(float) + GEMM_SK_FLAG_BYTES > p.sk_ws_bytes) continue;
+        best = c;
+      }
+      if (best > 1 && total * best >= 200) {
+        S = best;
+        sk_tile = 71;
+      }
+    }
+    if (S == 1 && total > 256 && tm <= 256) {
+      const int tn_main = (int)((total / 256) * 256 / tm);      // column tiles that fill whole rounds
+      const long long main_tiles = (long long)tm * tn_main;
+      const int n_main = tn_main * 256;
+      if (tn_main >= 1 && n_main < p.N && (double)main_tiles / (double)(((main_tiles + 255) / 256) * 256) >= 0.9) {
+        GemmParams pm = p, pr = p;
+        pm.N = n_main;
+        pm.tile = 71;
+        pr.N = p.N - n_main;
+        pr.B = p.B + (long long)n_main * p.ldb;
+        pr.C = p.C + n_main;                       // split-row output: a 256-column block is 256 floats wide as well
+        if (p.bias) pr.bias = p.bias + n_main;
+        if (p.res) pr.res = p.res + n_main;
+        if (p.gate) pr.gate = p.gate + n_main;
+        RGM_TRY(gemm2_launch(pm, s));
+        return gemm2_launch(pr, s);
+      }
+    }
+  }
+  if (S == 1 && !p.stats) S = splitk_factor(p);
   if (S == 1 && p.tile == 0 && p.sk_ws && !p.stats && !p.aload && p.batch == 1 && p.act < 3 && (p.K >> 5) >= 96 &&
       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0) {
     // long-K GEMM on a grid that leaves the second 128x128 workgroup slot of most CUs empty (fc2 at B = 16: 288 tiles on 512
@@ -1163,6 +1327,8 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 56: return launch2<128, 64, 2, 2, 4, 4>(p, s, 56);    // 96 KB
     case 57: return launch2<64, 64, 2, 2, 6, 4>(p, s, 57);     // 96 KB
     case 58: return launch2<64, 64, 2, 2, 3, 4>(p, s, 58);     // 48 KB: 3 per CU
+    // one wave per SIMD, 128x128 per wave (PIPE == 5)
+    case 71: return launch2<256, 256, 2, 2, 2, 5>(p, s, 71);   // 128 KB: 1 per CU, 512 registers
     // persistent loader/consumer kernel (gemm3.hip)
     case 61:
     case 62:

@@ -458,3 +458,21 @@ extern "C" int rgm_gemm_split_ws(const float* A_split, const float* B_split, flo
   RGM_CHECK_HIP(hipMemsetAsync(ws, 0, rgm::G4_FLAG_BYTES, (hipStream_t)stream));
   return rgm::gemm2_launch(g, (hipStream_t)stream);
 }
+
+// The general entry of the pre-split GEMM family: every fused epilogue the DiT block uses (alpha, bias, activation, per-sample
+// adaLN gate, residual that may alias C, split-row output), explicit row strides, explicit tile (0 = heuristic, 47 = stream-K,
+// 7x = the 256x256 kernels of gemm5.hip) and the caller's stream-K / split-K scratch (may be NULL: decompositions that need it
+// are then not chosen; forced ones fail).  What guided_diffusion/dit.py:332-336 computes per block, in one launch.
+extern "C" int rgm_gemm_split_epi(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
+                                  const float* bias, int act, float alpha, const float* gate, int gate_ld, int rows_per_gate,
+                                  const float* res, int ldres, int tile, int out_split, void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(A_split && B_split && C, "gemm_split_epi: null operand");
+  rgm::GemmParams g;
+  g.A = A_split; g.lda = lda; g.B = B_split; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.alpha = alpha; g.tile = tile; g.out_split = out_split;
+  g.gate = gate; g.gate_ld = gate_ld; g.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
+  g.res = res; g.ldres = ldres;
+  g.sk_ws = ws; g.sk_ws_bytes = ws ? ws_bytes : 0;
+  if (ws) RGM_CHECK_HIP(hipMemsetAsync(ws, 0, rgm::G4_FLAG_BYTES, (hipStream_t)stream));
+  return rgm::gemm2_launch(g, (hipStream_t)stream);
+}

@@ -77,6 +77,7 @@ def _load():
         "rgm_gemm_streamk_workspace_bytes": (sz, []),
         "rgm_set_streamk": (C.c_int, [i32]),
         "rgm_gemm_split_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
+        "rgm_gemm_split_epi": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_split_rows_ld": (C.c_int, [vp, i32, vp, i32, C.c_int64, i32, vp]),
         "rgm_gemm_split_ld": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, i32, vp]),
         "rgm_set_gemm_precision": (C.c_int, [i32]),

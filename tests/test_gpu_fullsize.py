@@ -1,0 +1,300 @@
+"""-m gpu: parity at the sizes BASELINE configs 3-5 really run (round-2 review, "what's weak" 1 and 2).
+
+The goldens pin batches of 2; the kernels that carry C3 (B = 32), C4 (n.B = 64) and C5 (14-window batches at XL width) are chosen by
+M: the persistent stream-K kernel (gemm4.hip, profiler id 47) and the 256x256 one-wave-per-SIMD kernel (gemm5.hip, ids 71..) only
+run at M >= 4096 / 8192.  Covered here: their fused gate / residual epilogues against an fp64 product, the XL model at B = 32 / 64
+against batches of 2 (with proof, from the library's own launch records, that those kernels ran), one SCG search step at
+n.B = 64 against its 'rank r of 2' replay, and one guided DiffCollage step of config 5 at XL width."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from rgm import synth
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+XL2 = dict(depth=2, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4, num_classes=3)
+
+
+def _ref(A, B, bias, act, alpha, gate, rpg, res):
+    y = alpha * (A.astype(np.float64) @ B.astype(np.float64).T) + bias
+    if act == 1:
+        y = y / (1 + np.exp(-y))
+    elif act == 2:
+        y = 0.5 * y * (1 + np.tanh(np.sqrt(2 / np.pi) * (y + 0.044715 * y ** 3)))
+    if gate is not None:
+        y = y * gate[np.arange(A.shape[0]) // rpg]
+    if res is not None:
+        y = y + res
+    return y
+
+
+def _split(x):
+    from gpu_util import dev
+    from rgm import native as R
+    xd = dev(x)
+    out = torch.empty_like(xd)
+    R.check(R.lib.rgm_split_rows(R.ptr(xd), R.ptr(out), x.shape[0], x.shape[1], R.current_stream()))
+    return out
+
+
+def _launches(ids):
+    """{kernel id: launches} from the library's per-launch records (rgm_prof_*)."""
+    from rgm import native as R
+    out = {}
+    for k in ids:
+        n, ms, fl = C.c_int(0), C.c_double(0), C.c_double(0)
+        R.check(R.lib.rgm_prof_report(k, C.byref(n), C.byref(ms), C.byref(fl)))
+        out[k] = n.value
+    return out
+
+
+class _Recorded:
+    def __enter__(self):
+        from rgm import native as R
+        R.check(R.lib.rgm_prof_reset())
+        R.check(R.lib.rgm_prof_enable(1))
+        return self
+
+    def __exit__(self, *a):
+        from rgm import native as R
+        torch.cuda.synchronize()
+        R.check(R.lib.rgm_prof_enable(0))
+        self.n = _launches([83, 84, 47, 111, 112, 113])
+        self.big = self.n[47] + self.n[111] + self.n[112] + self.n[113]
+        R.check(R.lib.rgm_prof_reset())
+
+
+BIG_TILES = [47, 71]
+
+
+@pytest.mark.parametrize("tile", BIG_TILES)
+@pytest.mark.parametrize("M,N,K,T", [(8192, 1152, 4608, 256), (16384, 1152, 1152, 256), (8192 + 200, 1152, 1152, 128), (4096, 1152, 4608, 256)])
+def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
+    """proj / fc2 of a DiT block (dit.py:332-336: x = x + gate_b * (h W^T + bias), per-sample adaLN gate, residual read from and
+    written to C) through the persistent stream-K kernel (47) and the 256x256 kernel (71) on C3 / C4's shapes and one ragged M,
+    against the fp64 product; run twice on the same scratch (flags handed back), bit-identical, no spin timed out."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    rng = np.random.RandomState(M + N + K + tile)
+    A, B = rng.randn(M, K).astype(F32), (rng.randn(N, K) * 0.03).astype(F32)
+    bias, res = rng.randn(N).astype(F32), rng.randn(M, N).astype(F32)
+    gate = rng.randn((M + T - 1) // T, N + 64).astype(F32)          # gate rows are strided like the modulation buffer's
+    As, Bs, bd, gd = _split(A), _split(B), dev(bias), dev(gate)
+    need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 4 * M * N * 4)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    ws.fill_(0xAB)
+    st = R.current_stream()
+    outs = []
+    for rep in range(2):
+        x = dev(res)
+        R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 0.7, R.ptr(gd), N + 64, T,
+                                         R.ptr(x), N, tile, 0, R.ptr(ws), need, st))
+        torch.cuda.synchronize()
+        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "a flag was left raised or a spin timed out"
+        outs.append(x.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert rel(outs[0], _ref(A, B, bias, 0, 0.7, gate[:, :N], T, res)) < 3e-5
+    # the GELU + split-row output epilogue of fc1 through the same kernels
+    if K == 1152 and M % 128 == 0:
+        W = (rng.randn(2304, K) * 0.03).astype(F32)
+        b2 = rng.randn(2304).astype(F32)
+        h = torch.zeros(M, 2304, device="cuda")
+        R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(_split(W)), K, R.ptr(h), 2304, M, 2304, K, R.ptr(dev(b2)), 2, 1.0, None, 0, 1,
+                                         None, 0, tile, 1, R.ptr(ws), need, st))
+        torch.cuda.synchronize()
+        raw = h.view(torch.bfloat16).view(M, 2304 // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+        assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, 2304), _ref(A, W, b2, 2, 1.0, None, 1, None)) < 3e-5
+
+
+def _dit(arch, seed):
+    from gpu_util import load_module
+    from guided_diffusion.dit import DiTRotary
+    m = DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=arch["hidden"], depth=arch["depth"],
+                  num_heads=arch["heads"], num_classes=arch["num_classes"], learn_sigma=False)
+    return load_module(m, synth.dit_state_dict(seed, final_std=0.3 / arch["hidden"] ** 0.5, device="cuda", **arch))
+
+
+@pytest.mark.parametrize("B,depth", [(32, 2), (64, 2), (32, 28)])
+def test_xl_model_at_c3_and_c4_batch_sizes_is_row_independent(B, depth, precision):
+    """C3 runs the XL eps-network at B = 32 (M = 8192 rows), C4 at n.B = 64 (M = 16384): the sizes at which the heuristic hands the
+    backbone GEMMs to the big-tile kernels.  Every sample of the big batch must equal the same sample in a batch of 2 (what the
+    reference-generated goldens pin); in pre-split mode the launch records must show that the big-tile kernels really ran."""
+    from gpu_util import dev, rel
+    m = _dit(dict(XL2, depth=depth), 1)
+    rng = np.random.RandomState(B + depth)
+    x = dev(rng.randn(B, 4, 128, 16).astype(F32))
+    t = dev(rng.randint(0, 1000, size=B).astype(np.int64))
+    y = dev(rng.randint(0, 3, size=B).astype(np.int64))
+    with _Recorded() as rec:
+        big = m(x, t, y)
+    if precision == "bf16x3_presplit":
+        assert rec.big >= 2 * depth, rec.n
+    assert bool(torch.isfinite(big).all())
+    tol = 3e-5 if precision == "bf16x3_presplit" else 2e-6
+    for i in (0, B // 2 - 1, B - 2):
+        small = m(x[i:i + 2].contiguous(), t[i:i + 2].contiguous(), y[i:i + 2].contiguous())
+        assert rel(big[i:i + 2].cpu().numpy(), small.cpu().numpy()) < tol * (4 if depth == 28 else 1), (i, rec.n)
+
+
+def _vae(seed=2):
+    from gpu_util import load_module
+    from taming.models.klvae_pedal import AutoencoderKL
+    return load_module(AutoencoderKL(), synth.vae_state_dict(seed, encoder=True))
+
+
+def _diffusion(rs=""):
+    from guided_diffusion.script_util import create_diffusion
+    return create_diffusion(learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs,
+                            use_kl=False, predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+
+
+def _targets(B, nw):
+    ph = torch.tensor([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], device="cuda").repeat(B, 1)
+    nd = torch.tensor([3.] * (2 * nw), device="cuda").repeat(B, 1)
+    return {"pitch_hist": ph, "note_density": nd}
+
+
+def test_scg_search_step_at_c4_size_matches_its_two_rank_replay(monkeypatch, precision):
+    """BASELINE config 4 at its real candidate batch: B = 4, n = 16 -> the eps-network scores 64 rows (M = 16384), the decoder 512
+    squares.  The step is run unsharded and replayed as 'rank r of 2' (32 candidates each, other half of the log-prob table from a
+    stand-in all-gather): same per-sample winners, log-probs equal up to the batch-size dependence of the GEMM tiles, and the
+    rebuilt winner bit-identical."""
+    from functools import partial
+    from types import SimpleNamespace
+    from gpu_util import rel
+    from rgm import scg_shard
+    from guided_diffusion.condition_functions import model_fn
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    B, n = 4, 16
+    m, vae = _dit(XL2, 1), _vae(2)
+    fn = partial(model_fn, model=m, num_classes=3, class_cond=True, cfg=False, w=0.)
+    kw = {"y": torch.ones(B, dtype=torch.int64, device="cuda"), "rule": _targets(B, 8)}
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
+    x = torch.randn(B, 4, 128, 16, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    t = torch.full((B,), 600, dtype=torch.int64, device="cuda")
+
+    def run():
+        d = _diffusion("")
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=99)
+        out = d.p_sample(fn, x, t, clip_denoised=False, model_kwargs=kw, embed_model=vae, scale_factor=1.2465,
+                         guidance_kwargs=guid, scg_kwargs=scg)
+        return out["sample"], d.last_scg["total_log_prob"].clone(), d.last_scg["max_ind"].clone()
+
+    with _Recorded() as rec:
+        ref_sample, ref_total, ref_idx = run()
+    if precision == "bf16x3_presplit":
+        assert rec.big >= 4, rec.n
+    assert ref_total.shape == (n, B) and bool(torch.isfinite(ref_total).all())
+    spread = float((ref_total.max(0).values - ref_total.min(0).values).min())
+    assert spread > 1e-3 * float(ref_total.abs().max()), "degenerate search: every candidate scores the same"
+    h = n // 2
+    for rank in (0, 1):
+        monkeypatch.setattr(scg_shard, "partition", lambda n_, r=rank: (r * n_ // 2, n_ // 2, True))
+
+        def fake_gather(local, r=rank):
+            assert rel(local.cpu().numpy(), ref_total[r * h:(r + 1) * h].cpu().numpy()) < 1e-4
+            parts = [ref_total[:h], ref_total[h:]]
+            parts[r] = local
+            return torch.cat(parts, dim=0)
+        monkeypatch.setattr(scg_shard, "gather_totals", fake_gather)
+        s, total, idx = run()
+        assert torch.equal(idx, ref_idx), f"rank {rank}: other winners"
+        assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt winner differs"
+
+
+@pytest.mark.parametrize("depth", [2, 28])
+def test_long_sequence_guided_step_at_xl_width(monkeypatch, depth, precision):
+    """BASELINE config 5 (diff_collage/condind_long.py:24-51 + gaussian_diffusion.py:562-592): a 4 x 512 x 16 latent = 7 windows + 6
+    overlap halves through the XL eps-network per evaluation, 32 squares per candidate through the decoder, segment-wise SCG
+    (dc.base 128), B = 1, n = 4.  (a) the collage eps of the 13-window batch equals the same windows evaluated one pair at a time
+    (row independence at M = 13 x 256 .. 4 x 13 x 256 rows); (b) the guided step equals its 'rank r of 2' replay."""
+    if depth == 28 and precision != "bf16x3_presplit":
+        pytest.skip("depth 28 once, in the arithmetic the bench runs")
+    from functools import partial
+    from types import SimpleNamespace
+    from gpu_util import rel
+    import diff_collage as dc
+    from rgm import scg_shard
+    from guided_diffusion.condition_functions import dc_model_fn
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    B, n = 1, 4
+    m, vae = _dit(dict(XL2, depth=depth), 1), _vae(2)
+    calls = []
+
+    def eps_fn(x, t, y=None):
+        calls.append(tuple(x.shape))
+        return m(x.permute(0, 1, 3, 2).contiguous(), t, y=y).permute(0, 1, 3, 2)
+
+    def eps_pairs(x, t, y=None):                        # the same windows, two at a time
+        outs = []
+        for i in range(0, x.shape[0], 2):
+            outs.append(m(x[i:i + 2].permute(0, 1, 3, 2).contiguous(), t[i:i + 2].contiguous(),
+                          y=None if y is None else y[i:i + 2].contiguous()).permute(0, 1, 3, 2))
+        return torch.cat(outs, 0)
+    worker = dc.CondIndSimple((4, 16, 128), eps_fn, 7, overlap_size=64)
+    small = dc.CondIndSimple((4, 16, 128), eps_pairs, 7, overlap_size=64)
+    assert worker.shape == (4, 16, 512)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    w = torch.randn(4 * B, 4, 16, 512, device="cuda", generator=g)
+    tt = torch.full((4 * B,), 500, dtype=torch.int64, device="cuda")
+    yy = torch.ones(4 * B, dtype=torch.int64, device="cuda")
+    e_big = worker.eps_scalar_t_fn(w, tt, y=yy)
+    e_small = small.eps_scalar_t_fn(w, tt, y=yy)
+    assert max(c[0] for c in calls) >= 4 * 7, calls                    # the windows of all samples really went through as one batch
+    tol = (3e-5 if precision == "bf16x3_presplit" else 2e-6) * (4 if depth == 28 else 1)
+    assert rel(e_big.cpu().numpy(), e_small.cpu().numpy()) < tol
+
+    fn = partial(dc_model_fn, model=worker.eps_scalar_t_fn, num_classes=3, class_cond=True, cfg=False, w=0.)
+    x = torch.randn(B, 4, 512, 16, device="cuda", generator=g)
+    t = torch.full((B,), 600, dtype=torch.int64, device="cuda")
+    kw = {"y": torch.ones(B, dtype=torch.int64, device="cuda"), "rule": _targets(B, 32)}
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance", dc=SimpleNamespace(base=128))
+    scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
+
+    def run():
+        d = _diffusion("")
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=17)
+        out = d.p_sample(fn, x, t, clip_denoised=False, model_kwargs=kw, embed_model=vae, scale_factor=1.2465,
+                         guidance_kwargs=guid, scg_kwargs=scg)
+        return out["sample"], d.last_scg["total_log_prob"].clone(), d.last_scg["max_ind"].clone()
+
+    ref_sample, ref_total, ref_idx = run()
+    S = 512 // 128
+    assert ref_sample.shape == (B, 4, 512, 16) and ref_total.shape == (n, S, B) and ref_idx.shape == (S, B)
+    assert bool(torch.isfinite(ref_sample).all())
+    h = n // 2
+    for rank in (0, 1):
+        monkeypatch.setattr(scg_shard, "partition", lambda n_, r=rank: (r * n_ // 2, n_ // 2, True))
+
+        def fake_gather(local, r=rank):
+            mine = ref_total[r * h:(r + 1) * h].reshape(h, -1)
+            assert rel(local.cpu().numpy(), mine.cpu().numpy()) < 1e-4
+            parts = [ref_total[:h].reshape(h, -1), ref_total[h:].reshape(h, -1)]
+            parts[r] = local
+            return torch.cat(parts, dim=0)
+        monkeypatch.setattr(scg_shard, "gather_totals", fake_gather)
+        s, total, idx = run()
+        assert torch.equal(idx, ref_idx), f"rank {rank}: other per-segment winners"
+        assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
+
+
+def test_two_gpu_scg_bench_runs_over_rccl_when_the_box_has_two_gpus():
+    """Multi-GPU readiness: on a box with >= 2 GPUs this runs the sharded SCG bench over RCCL (bench.py spawns its own ranks) and
+    requires the same winners on every rank; on the 1-GPU boxes of this round it is skipped -- the only test that may skip."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (RCCL); the gloo two-rank tests in test_host_logic.py cover the protocol on CPU")
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-extras", "--workload", "scg", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=1500, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2
+    rec = line.get("scg", line)
+    assert rec.get("same_winners_on_every_rank", line.get("config", {}).get("same_winners_on_every_rank")) is True, line

@@ -34,15 +34,16 @@ ids, ms, fl = (C.c_int * cap)(), (C.c_double * cap)(), (C.c_double * cap)()
 n = R.lib.rgm_prof_dump(cap, ids, ms, fl)
 rec = [(ids[i], ms[i] * 1e3, fl[i]) for i in range(n)]
 per_step = n // STEPS
-assert per_step % 4 == 0, (n, per_step)
-names = ["qkv", "proj", "fc1", "fc2"]
-print(f"{n} pre-split GEMM launches over {STEPS} steps ({per_step} per step)")
+DEPTH = 28
+assert per_step % DEPTH == 0, (n, per_step)
+per_block = per_step // DEPTH                    # launches per block: 4 GEMMs, more when one is split over two kernels
+print(f"{n} pre-split GEMM launches over {STEPS} steps ({per_step} per step, {per_block} per block)")
 tot = 0.0
-for j, nm in enumerate(names):
-    sel = [r for i, r in enumerate(rec) if (i % per_step) % 4 == j]
+for j in range(per_block):
+    sel = [r for i, r in enumerate(rec) if (i % per_step) % per_block == j]
     us = np.array([r[1] for r in sel])
     tf = sel[0][2] / (np.median(us) * 1e-6) / 1e12
     tot += us.sum() / STEPS
-    print(f"{nm:5s} kernel id {sel[0][0]:3d}  median {np.median(us):7.1f} us  min {us.min():7.1f}  max {us.max():7.1f}  {tf:6.1f} TFLOP/s  "
-          f"first block {sel[0][1]:7.1f}  last block {sel[per_step // 4 - 1][1]:7.1f}")
-print(f"GEMM total per step {tot / 1e3:.2f} ms")
+    print(f"launch {j} of a block: kernel id {sel[0][0]:3d}  {sel[0][2] / 1e9:7.2f} GFLOP  median {np.median(us):7.1f} us  min {us.min():7.1f}  "
+          f"max {us.max():7.1f}  {tf:6.1f} TFLOP/s  first block {sel[0][1]:7.1f}  last block {sel[DEPTH - 1][1]:7.1f}")
+print(f"GEMM total per step {tot / 1e3:.2f} ms (split-K reduce kernels not included)")
