@@ -385,26 +385,33 @@ def time_steps(work, steps, world, dist):
 
 def scg_record(device, world, rank, dist, steps=5, warmup=2):
     """The sharded SCG step (north star): B = 4, n = 16, candidates partitioned over the ranks, one all-gather per step."""
-    from rgm import scg_shard
+    from rgm import scg_shard, batch_shard
     work = SCGWorkload(device, 4)
-    ag = {"events": []}
-    real_gather = scg_shard.gather_totals
+    ag = {"events": [], "row_events": []}
+    real_gather, real_rows = scg_shard.gather_totals, batch_shard.gather_rows
 
-    def timed_gather(local):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        out = real_gather(local)
-        b.record()
-        ag["events"].append((a, b))
-        return out
-    scg_shard.gather_totals = timed_gather
+    def timed(fn, key):
+        def wrapper(arg):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            out = fn(arg)
+            b.record()
+            ag[key].append((a, b))
+            return out
+        return wrapper
+    # the two collectives of a sharded search step: the eps (+ guidance gradient) rows of the x_t forward (batch_shard.gather_rows,
+    # 32 KiB per sample) and the (n/R, B) table of rule log-probs (scg_shard.gather_totals, 64 B per sample)
+    scg_shard.gather_totals = timed(real_gather, "events")
+    batch_shard.gather_rows = timed(real_rows, "row_events")
     try:
         for _ in range(warmup):
             work.step()
         ag["events"].clear()
+        ag["row_events"].clear()
         dt, _ = time_steps(work, steps, world, dist)
         torch.cuda.synchronize()
         ag_us = [1e3 * a.elapsed_time(b) for a, b in ag["events"]]
+        row_us = [1e3 * a.elapsed_time(b) for a, b in ag["row_events"]]
         same = True
         if world > 1:
             mine = work.d.last_scg["max_ind"].to(torch.int64).contiguous()
@@ -416,10 +423,12 @@ def scg_record(device, world, rank, dist, steps=5, warmup=2):
             dist.all_gather(allt, tot)
             same = same and all(bool(torch.equal(allt[0], m)) for m in allt)
     finally:
-        scg_shard.gather_totals = real_gather
+        scg_shard.gather_totals, batch_shard.gather_rows = real_gather, real_rows
     return {"workload": work.name, "scaling": "strong", "ranks": world, "candidates_per_rank": 16 // world if 16 % world == 0 else 16,
             "steps": steps, "ms_per_step": round(1e3 * dt / steps, 3), "steps_per_s": round(steps / dt, 4),
             "allgather_us_per_step": round(float(np.median(ag_us)), 1) if ag_us else None,
+            "allgather_logprob_table_us": round(float(np.median(ag_us)), 1) if ag_us else None,
+            "allgather_eps_rows_us": round(float(np.median(row_us)), 1) if row_us else None,
             "same_winners_on_every_rank": bool(same),
             "algorithmic_tflops": round(work.flop_per_step * steps / dt / 1e12, 2)}
 

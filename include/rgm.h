@@ -69,6 +69,9 @@ int rgm_dit_forward(rgm_dit* h, const float* x, const int64_t* t, const int32_t*
                     int N, int H, void* ws, size_t ws_bytes, void* stream);
 /* DiTRotaryClassifier.forward dit.py:803-831.  logits (N,n_out) [kind 1]  or  key (N,25) + chord
  * (N,H/width,n_out) [kind 2; key_out may be NULL]. */
+/* RGM_ERR_STATE once if a persistent stream-K GEMM of an earlier forward of this handle ran out of its bounded spin (its output
+ * is invalid); no device synchronisation -- call after one.  Every forward also checks its predecessor. */
+int rgm_dit_status(rgm_dit* h);
 int rgm_dit_classify(rgm_dit* h, const float* x, const int64_t* t, float* logits, float* key_out,
                      int N, int H, void* ws, size_t ws_bytes, void* stream);
 
@@ -122,6 +125,8 @@ int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int l
 size_t rgm_gemm_streamk_workspace_bytes(void);
 /* process-wide: 0 never use the persistent kernel, 1 heuristic (default), 2 whenever the operands allow it */
 int rgm_set_streamk(int mode);
+/* reads the scratch's error word back (synchronises `stream`): RGM_ERR_STATE if a stream-K spin ran out since the flags were zeroed */
+int rgm_gemm_streamk_status(void* ws, void* stream);
 int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias, int act,
                       int tile, int out_split, void* ws, size_t ws_bytes, void* stream);
 /* The general pre-split entry: C = (act(alpha * A . B^T + bias)) * gate + res with explicit row strides (elements), the per-sample
@@ -161,6 +166,12 @@ int rgm_ddpm_step_learned(const float* x, const float* eps, const float* var_val
                           const float* max_log_tab, const float* grad, const float* noise, const int64_t* t,
                           const float* const* tables_host, int clip_denoised, int t_end, float* sample, float* pred_xstart, int N,
                           int E, void* stream);
+/* ... also writing the per-element noise scale g_elem (N,E) = exp(0.5 log_variance): the tensor g_coeff p_sample hands scg_sample at
+ * a learned-variance step (:706-711).  Per-element candidates: rgm_scg_candidates(mean, g_elem, noise, cand, n, N*E, 1). */
+int rgm_ddpm_step_learned_g(const float* x, const float* eps, const float* var_values, const float* min_log_tab,
+                            const float* max_log_tab, const float* grad, const float* noise, const int64_t* t,
+                            const float* const* tables_host, int clip_denoised, int t_end, float* sample, float* pred_xstart,
+                            float* g_elem, int N, int E, void* stream);
 /* ddim_sample (:881-952) incl. condition_score (:467-489) when grad != NULL; g_out receives sigma. */
 int rgm_ddim_step(const float* x, const float* eps, const float* grad, const float* noise, const int64_t* t,
                   const float* const* tables_host, int clip_denoised, int t_end, float eta, float* sample,
@@ -185,6 +196,9 @@ int rgm_scg_select(const float* cand, const float* total_logp, float* out, int64
  * (max_ind is (S,B), S = ceil(H / seg_rows); seg_rows >= H: one winner per sample).  No host read of max_ind. */
 int rgm_scg_rebuild(const float* mean, const float* g, const int64_t* max_ind, uint64_t seed, uint64_t base, float* out,
                     int B, int E, int H, int W, int seg_rows, void* stream);
+/* the same with a per-element noise scale g_elem (B,E) (learned variances) */
+int rgm_scg_rebuild_g(const float* mean, const float* g_elem, const int64_t* max_ind, uint64_t seed, uint64_t base, float* out,
+                      int B, int E, int H, int W, int seg_rows, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * taming KL-VAE decoder (f8-all-onset config)            taming/models/klvae_pedal.py:80-85,

@@ -162,6 +162,7 @@ int gemm4_launch(const GemmParams& p, hipStream_t stream);
 bool gemm4_eligible(const GemmParams& p);
 size_t gemm4_workspace_bytes();
 constexpr size_t GEMM_SK_FLAG_BYTES = 4096;
+constexpr size_t GEMM_SK_ERR_OFFSET = GEMM_SK_FLAG_BYTES - 4;   // error word of the flag block (a stream-K spin ran out: gemm4.hip)
 // scratch a caller must provide for GEMMs of up to M rows and N columns to use stream-K / split-K
 size_t gemm2_scratch_bytes(int M, int N);
 int gemm2_prof_begin(int id, double flops, hipStream_t s);

@@ -389,14 +389,28 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own pieces of the next tile landed, own reads of this tile done
       __builtin_amdgcn_s_barrier();
     };
+    if (DBG) {
+      tp = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      tacc[2] = tp - t_entry;                             // prologue: entry -> K loop
+    }
     int kt = 0;
     for (; kt + 2 < KT; ++kt) {                           // steady state: tiles kt+1 and kt+2 exist
       char* cs = ring + (kt & 1) * STAGE;
       char* ns = ring + ((kt + 1) & 1) * STAGE;
       phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
+      RGM_STAMP(4)
       retarget(kt + 2);
-      handover();
+      if (DBG) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        RGM_STAMP(0)
+        __builtin_amdgcn_s_barrier();
+        RGM_STAMP(1)
+      } else {
+        handover();
+      }
       phase(f1, f0, Y{}, Y{}, Nn{}, ns, cs);
+      RGM_STAMP(6)
     }
     if (kt + 1 < KT) {                                    // last but one: nothing left to fetch
       char* cs = ring + (kt & 1) * STAGE;
@@ -411,6 +425,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
       phase(f1, f0, Nn{}, Nn{}, Nn{}, nullptr, nullptr);
     }
+    RGM_STAMP(6)
   } else
   if constexpr (PIPE == 3) {
     // Cross-iteration register pipeline: the fragments of K-tile kt+1 are requested (behind the barrier that says the
@@ -765,27 +780,36 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         auto plain_rows = [&](auto act_c, auto split_c) {      // branch-free body per (activation, output format)
           constexpr int ACT = decltype(act_c)::value;
           constexpr bool SPLIT = decltype(split_c)::value != 0;
+          // one wave per SIMD (PIPE 5) has nobody to hide an iteration's LDS round trip + activation chain behind: U rows per
+          // iteration, all slab reads first (the other kernels keep the rolled body: their cost is the cold instruction cache)
+          constexpr int U = PIPE == 5 ? 4 : 1;
 #pragma unroll 1
-          for (int j = 0; j < nj; ++j) {
-            const int r = j * RPI + lr, row = row0 + j * RPI;
-            const float4 a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);   // same wave wrote it: LDS ops are in order
-            if (row < p.M && col_ok) {
-              float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
+          for (int j0 = 0; j0 < nj; j0 += U) {
+            float4 a4s[U];
 #pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) v[q4] = ACT == 1 ? silu_f(v[q4]) : (ACT == 2 ? gelu_tanh_fast_f(v[q4]) : v[q4]);
-              if constexpr (SPLIT) {
-                typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-                bf16x4 hi, lo;
+            for (int u = 0; u < U; ++u) a4s[u] = *reinterpret_cast<const float4*>(slab + ((j0 + u) * RPI + lr) * WCOLS + lc);   // same wave wrote it: LDS ops are in order
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) {
-                  hi[q4] = (__bf16)v[q4];
-                  lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+            for (int u = 0; u < U; ++u) {
+              const int row = row0 + (j0 + u) * RPI;
+              const float4 a4 = a4s[u];
+              if (row < p.M && col_ok) {
+                float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = ACT == 1 ? silu_f(v[q4]) : (ACT == 2 ? gelu_tanh_fast_f(v[q4]) : v[q4]);
+                if constexpr (SPLIT) {
+                  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                  bf16x4 hi, lo;
+#pragma unroll
+                  for (int q4 = 0; q4 < 4; ++q4) {
+                    hi[q4] = (__bf16)v[q4];
+                    lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+                  }
+                  __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+                  *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+                  *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+                } else {
+                  if (exp != 4) *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
                 }
-                __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-                *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
-                *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
-              } else {
-                if (exp != 4) *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
               }
             }
           }
@@ -881,11 +905,32 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         rolled_rows(stg, row_w, TM * NJ);
       }
     } else {
+      auto estamp = [&](int i) {                                 // DBG: cycles since the end of the K loop (tools/gemm_stamp.py)
+        if (DBG && rec && lane == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          const unsigned long long now_ = __builtin_amdgcn_s_memtime();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          dbg[32 + wave * 8 + i] = (long long)(now_ - t_loop_end);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      estamp(0);
       static_for<0, TM>([&](auto im_c) {
         write_slab(im_c, stg);
+        if (decltype(im_c)::value == 0) {
+          if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          estamp(1);
+        }
         if (linear) linear_rows(stg, row_w + decltype(im_c)::value * 32);
         else rolled_rows(stg, row_w + decltype(im_c)::value * 32, NJ);
+        if (decltype(im_c)::value == 0) estamp(2);
+        if (decltype(im_c)::value == 1) estamp(3);
       });
+      estamp(4);
+      if (DBG) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        estamp(5);
+      }
     }
     if (p.stats) {   // GroupNorm partial sums of this tile (uniform branch): lanes -> waves -> groups, all in a fixed order
 #pragma unroll
@@ -1158,6 +1203,7 @@ static int splitk_factor(const GemmParams& p) {
   int best = 1;
   for (int S = 2; S <= 8; ++S) {
     if (KT % S != 0 || KT / S < 9) continue;
+    if ((size_t)S * p.M * p.N * sizeof(float) + GEMM_SK_FLAG_BYTES > p.sk_ws_bytes) break;   // the partial sums must fit the caller's scratch: fall back to fewer slices
     best = S;
     if (t64 * S >= 512) break;
   }

@@ -38,6 +38,7 @@ __device__ __forceinline__ void dma16_g4(const void* gsrc, void* lds_dst) {
 constexpr int G4_SLOT_BYTES = 128 * 128 * 4;     // one raw accumulator tile
 constexpr int G4_FLAG_BYTES = 4096;              // flags[gridDim.x] + error word, ahead of the slots
 constexpr unsigned G4_SPIN_LIMIT = 1u << 22;
+constexpr int G4_ERR_WORD = G4_FLAG_BYTES / 4 - 1;   // last word of the flag block: set when a finisher's bounded spin ran out (rgm_gemm_streamk_status)
 
 // EDGE: M or N is not a multiple of 128 (rows beyond the edge read a zero page; per-piece validity is carried per lane)
 template <bool EDGE>
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, const char*
         while (__hip_atomic_load(flags + w + 1 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) {
           __builtin_amdgcn_s_sleep(2);
           if (++spins > G4_SPIN_LIMIT) {                          // never hang: flag the launch instead
-            if (lane == 0) __hip_atomic_store(flags + G, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(flags + G4_ERR_WORD, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
           }
         }
@@ -438,6 +439,21 @@ int gemm4_launch(const GemmParams& p, hipStream_t s) {
 // Bytes of the stream-K workspace (flags + one raw accumulator slot per resident workgroup); zero its first 4096 bytes once
 // before the first launch that uses it (the kernels hand every flag back).
 extern "C" size_t rgm_gemm_streamk_workspace_bytes(void) { return rgm::gemm4_workspace_bytes(); }
+
+// The stream-K finisher spins a bounded number of times for its contributors' slots; if a spin ever runs out (co-residency broken by
+// a co-running kernel) it raises the workspace's error word and the launch completes with wrong data.  This reads that word back
+// (synchronises `stream`): RGM_OK, or RGM_ERR_STATE after re-zeroing the whole flag block so that the workspace is usable again.
+// rgm_dit_forward checks the same word asynchronously (dit.hip); call this at a sync point when driving the GEMM entries directly.
+extern "C" int rgm_gemm_streamk_status(void* ws, void* stream) {
+  RGM_REQUIRE(ws, "gemm_streamk_status: null workspace");
+  unsigned err = 0;
+  RGM_CHECK_HIP(hipMemcpyAsync(&err, static_cast<char*>(ws) + rgm::G4_ERR_WORD * 4, 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  RGM_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (err == 0) return RGM_OK;
+  RGM_CHECK_HIP(hipMemsetAsync(ws, 0, rgm::G4_FLAG_BYTES, (hipStream_t)stream));
+  rgm::set_error("stream-K GEMM: a finisher timed out waiting for a partial tile (results of that launch are invalid); flags re-zeroed");
+  return RGM_ERR_STATE;
+}
 
 // 0: never use the persistent stream-K kernel, 1: heuristic (default), 2: whenever the operands allow it (experiments)
 extern "C" int rgm_set_streamk(int mode) {

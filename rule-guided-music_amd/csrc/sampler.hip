@@ -91,7 +91,8 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
                                  const float* __restrict__ noise, const int64_t* __restrict__ t, StepTables tb, int clip,
                                  int t_end, float* __restrict__ sample, float* __restrict__ pred_xstart,
                                  float* __restrict__ g_out, long long total, int E, const float* __restrict__ vv = nullptr,
-                                 const float* __restrict__ min_log = nullptr, const float* __restrict__ max_log = nullptr) {
+                                 const float* __restrict__ min_log = nullptr, const float* __restrict__ max_log = nullptr,
+                                 float* __restrict__ g_elem = nullptr) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int b = (int)(i / E);
@@ -117,6 +118,7 @@ __global__ void ddpm_step_kernel(const float* __restrict__ x, const float* __res
   sample[i] = s;
   pred_xstart[i] = x0;
   if (g_out && (i % E) == 0) g_out[b] = g;
+  if (g_elem) g_elem[i] = g;          // learned variances: the noise scale is a tensor (SCG candidates: exp(0.5 log_variance), :708)
 }
 
 // DDIM step (eta general; the CLI always runs eta = 1).  grad != nullptr applies condition_score first.
@@ -213,7 +215,8 @@ __global__ void scg_select_kernel(const float* __restrict__ cand, const float* _
 // gaussian_diffusion.py:562-592): row h of the (C, H, W) latent belongs to segment h / seg_rows and takes that segment's
 // winner, max_ind is (S, B); seg_rows >= H is the plain case (S = 1).
 __global__ void scg_rebuild_kernel(const float* __restrict__ mean, const float* __restrict__ g, const int64_t* __restrict__ max_ind,
-                                   uint64_t seed, uint64_t base, float* __restrict__ out, int B, int E, int H, int W, int seg_rows) {
+                                   uint64_t seed, uint64_t base, float* __restrict__ out, int B, int E, int H, int W, int seg_rows,
+                                   int g_per_elem) {
   const long long q = blockIdx.x * (long long)blockDim.x + threadIdx.x;   // 4 consecutive elements (E % 4 == 0, W % 4 == 0)
   const long long total4 = (long long)B * E / 4;
   if (q >= total4) return;
@@ -226,12 +229,12 @@ __global__ void scg_rebuild_kernel(const float* __restrict__ mean, const float* 
   philox_normals(pos >> 2, seed, z0);
   const int lane = (int)(pos & 3);
   if (lane) philox_normals((pos >> 2) + 1, seed, z1);
-  const float gb = g[b];
+  const float gb = g_per_elem ? 0.f : g[b];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int l = lane + j;
     const float z = l < 4 ? z0[l & 3] : z1[l & 3];
-    out[i + j] = mean[i + j] + gb * z;
+    out[i + j] = mean[i + j] + (g_per_elem ? g[i + j] : gb) * z;
   }
 }
 
@@ -282,7 +285,23 @@ extern "C" int rgm_ddpm_step_learned(const float* x, const float* eps, const flo
   const long long total = (long long)N * E;
   hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, grad, noise, t,
                      make_tables(tables), clip_denoised, t_end, sample, pred_xstart, (float*)nullptr, total, E, var_values, min_log_tab,
-                     max_log_tab);
+                     max_log_tab, (float*)nullptr);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// The same step, also writing the per-element noise scale g = exp(0.5 log_variance) (N, E): what p_sample hands scg_sample as
+// g_coeff at a learned-variance step (gaussian_diffusion.py:706-711).
+extern "C" int rgm_ddpm_step_learned_g(const float* x, const float* eps, const float* var_values, const float* min_log_tab,
+                                       const float* max_log_tab, const float* grad, const float* noise, const int64_t* t,
+                                       const float* const* tables, int clip_denoised, int t_end, float* sample, float* pred_xstart,
+                                       float* g_elem, int N, int E, void* stream) {
+  RGM_REQUIRE(x && eps && var_values && t && tables && sample && pred_xstart && g_elem && N > 0 && E > 0, "ddpm_step_learned_g: bad arguments");
+  RGM_REQUIRE((min_log_tab == nullptr) == (max_log_tab == nullptr), "ddpm_step_learned_g: min / max log-variance tables come together");
+  const long long total = (long long)N * E;
+  hipLaunchKernelGGL(ddpm_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, eps, grad, noise, t,
+                     make_tables(tables), clip_denoised, t_end, sample, pred_xstart, (float*)nullptr, total, E, var_values, min_log_tab,
+                     max_log_tab, g_elem);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
@@ -342,7 +361,19 @@ extern "C" int rgm_scg_rebuild(const float* mean, const float* g, const int64_t*
   RGM_REQUIRE(E % (H * W) == 0 && W % 4 == 0, "scg_rebuild: E = %d is not C x H x W with H = %d, W = %d (W %% 4 == 0)", E, H, W);
   const long long total4 = (long long)B * E / 4;
   hipLaunchKernelGGL(scg_rebuild_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, g, max_ind,
-                     seed, base, out, B, E, H, W, seg_rows);
+                     seed, base, out, B, E, H, W, seg_rows, 0);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
+// rgm_scg_rebuild with a per-element noise scale g (B, E) -- learned variances.
+extern "C" int rgm_scg_rebuild_g(const float* mean, const float* g_elem, const int64_t* max_ind, uint64_t seed, uint64_t base, float* out,
+                                 int B, int E, int H, int W, int seg_rows, void* stream) {
+  RGM_REQUIRE(mean && g_elem && max_ind && out && B > 0 && E > 0 && H > 0 && W > 0 && seg_rows > 0, "scg_rebuild_g: bad arguments");
+  RGM_REQUIRE(E % (H * W) == 0 && W % 4 == 0, "scg_rebuild_g: E = %d is not C x H x W with H = %d, W = %d (W %% 4 == 0)", E, H, W);
+  const long long total4 = (long long)B * E / 4;
+  hipLaunchKernelGGL(scg_rebuild_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, mean, g_elem, max_ind,
+                     seed, base, out, B, E, H, W, seg_rows, 1);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -164,8 +164,7 @@ class GaussianDiffusion:
 
     # ------------------------------------------------------------------ helpers
     def _check_supported(self):
-        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
-            raise NotImplementedError("native sampler supports eps- / x0-predicting models (ModelMeanType.PREVIOUS_X is unused by the reference's CLIs)")
+        return      # EPSILON, START_X and PREVIOUS_X all reach the fused step through an eps estimate (_model_eps)
 
     def _learned(self):
         return self.model_var_type in (ModelVarType.LEARNED, ModelVarType.LEARNED_RANGE)
@@ -181,6 +180,18 @@ class GaussianDiffusion:
             C_ = x.shape[1]
             assert out.shape[1] == 2 * C_, f"learned variances need a 2C-channel model output, got {tuple(out.shape)}"
             out, self._var_values = out[:, :C_].contiguous(), out[:, C_:].float().contiguous()
+        self._prevx = None
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            # the network predicts x_{t-1} (reference :331-338): pred_xstart = process_xstart(_predict_xstart_from_xprev) (:374-384) while
+            # the MEAN stays the raw output whatever denoised_fn / clip_denoised do to x0 -- _step restores it after the fused kernel
+            self._prevx = out.float().contiguous()
+            x0 = (self._per_sample(1.0 / self.posterior_mean_coef1, t, x) * self._prevx
+                  - self._per_sample(self.posterior_mean_coef2 / self.posterior_mean_coef1, t, x) * x.float())
+            if denoised_fn is not None:
+                x0 = denoised_fn(x0)
+            self._prevx_x0 = x0.float()
+            ones = th.ones((1,) * x.dim(), dtype=th.float32, device=x.device)
+            return self._edit_eps(x, th.zeros_like(x, dtype=th.float32), t, False, {"gt": x0, "mask": ones})
         start_x = self.model_mean_type == ModelMeanType.START_X
         if not start_x and denoised_fn is None:
             return out
@@ -262,7 +273,7 @@ class GaussianDiffusion:
         def run(xr, tr, kw, ekw):
             eps = self._model_eps(xr, self._wrap_model(model)(xr, self._scale_timesteps(tr), **kw), tr, denoised_fn)
             if ekw is not None:
-                eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw)
+                eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw, denoised_fn)
             grad = None
             if cond_fn is not None:
                 if ekw is None or not grad_on_edit_rows:      # (ddim_sample differentiates the whole latent, like the reference)
@@ -331,9 +342,17 @@ class GaussianDiffusion:
         return ((self._per_sample(self.sqrt_recip_alphas_cumprod, t, x_t) * x_t - pred_xstart)
                 / self._per_sample(self.sqrt_recipm1_alphas_cumprod, t, x_t))
 
-    def _edit_eps(self, x, eps, t, clip_denoised, edit_kwargs):
+    def _edit_eps(self, x, eps, t, clip_denoised, edit_kwargs, denoised_fn=None):
         """Replacement-based conditioning of scripts/edit.py (reference p_mean_variance :293-298): where mask == 1 the
-        x0 estimate is the ground-truth latent; returns the eps estimate consistent with that x0."""
+        x0 estimate is the ground-truth latent; returns the eps estimate consistent with that x0.  The reference runs
+        process_xstart twice on an edit step -- on the model's x0 before the replacement (:294-296, done by _model_eps) and again
+        on the replaced x0 (:336-342): with a denoised_fn the second application is reproduced here (the clip is idempotent and
+        lives in the step kernel)."""
+        if denoised_fn is not None:
+            replaced = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
+            x0 = denoised_fn(self._predict_xstart_from_eps(x, t, replaced))
+            ones = th.ones((1,) * x.dim(), dtype=th.float32, device=x.device)
+            return self._edit_eps(x, th.zeros_like(x, dtype=th.float32), t, False, {"gt": x0, "mask": ones})
         _rgm.require_cuda(x, eps, t)
         x, eps = x.float().contiguous(), eps.float().contiguous()
         gt = edit_kwargs["gt"].to(x.device, th.float32).expand_as(x).contiguous()
@@ -390,20 +409,25 @@ class GaussianDiffusion:
         tab = self._tab(x.device)
         vv = getattr(self, "_var_values", None) if self._learned() else None
         if vv is not None and kind == "ddpm":
-            # learned (per-element) variances: the noise scale is a tensor, so SCG's per-sample scale does not apply
-            if want_g:
-                raise NotImplementedError("SCG / DPS steps with learned variances (learn_sigma=True) are not provided")
+            # learned (per-element) variances: the noise scale is a TENSOR -- want_g returns exp(0.5 log_variance) per element, what
+            # the reference's p_sample hands scg_sample as g_coeff (:706-711)
             assert vv.shape == x.shape
             if self.model_var_type == ModelVarType.LEARNED_RANGE:
                 lt = self._learned_tabs(x.device)
                 lo, hi = _rgm.ptr(lt[0]), _rgm.ptr(lt[1])
             else:
                 lo = hi = None
+            g_elem = th.empty_like(x) if want_g else None
             with th.cuda.device(x.device):
-                _rgm.check(_rgm.lib.rgm_ddpm_step_learned(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(vv), lo, hi, _rgm.ptr(grad), _rgm.ptr(noise),
-                                                          _rgm.ptr(tt), tab.ptrs, int(bool(clip_denoised)), int(self.t_end),
-                                                          _rgm.ptr(sample), _rgm.ptr(x0), N, E, _rgm.current_stream()))
-            return sample, x0, None
+                if want_g:
+                    _rgm.check(_rgm.lib.rgm_ddpm_step_learned_g(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(vv), lo, hi, _rgm.ptr(grad), _rgm.ptr(noise),
+                                                                _rgm.ptr(tt), tab.ptrs, int(bool(clip_denoised)), int(self.t_end),
+                                                                _rgm.ptr(sample), _rgm.ptr(x0), _rgm.ptr(g_elem), N, E, _rgm.current_stream()))
+                else:
+                    _rgm.check(_rgm.lib.rgm_ddpm_step_learned(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(vv), lo, hi, _rgm.ptr(grad), _rgm.ptr(noise),
+                                                              _rgm.ptr(tt), tab.ptrs, int(bool(clip_denoised)), int(self.t_end),
+                                                              _rgm.ptr(sample), _rgm.ptr(x0), N, E, _rgm.current_stream()))
+            return sample, x0, g_elem
         with th.cuda.device(x.device):
             if kind == "ddpm":
                 _rgm.check(_rgm.lib.rgm_ddpm_step(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(grad), _rgm.ptr(noise), _rgm.ptr(tt),
@@ -413,6 +437,13 @@ class GaussianDiffusion:
                 _rgm.check(_rgm.lib.rgm_ddim_step(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(grad), _rgm.ptr(noise), _rgm.ptr(tt),
                                                   tab.ptrs, int(bool(clip_denoised)), int(self.t_end), float(eta),
                                                   _rgm.ptr(sample), _rgm.ptr(x0), _rgm.ptr(g), N, E, _rgm.current_stream()))
+        prevx = getattr(self, "_prevx", None)
+        if kind == "ddpm" and prevx is not None and prevx.shape == x.shape:
+            # ModelMeanType.PREVIOUS_X: model_mean = model_output (:338), not the posterior mean of the processed x0 the kernel formed
+            sample = sample + (prevx - (self._per_sample(self.posterior_mean_coef1, t, x) * x0
+                                        + self._per_sample(self.posterior_mean_coef2, t, x) * x))
+            # pred_xstart straight from _predict_xstart_from_xprev (1 / coef1 is large: the eps round trip of the kernel would cost digits)
+            x0 = self._prevx_x0.clamp(-1, 1) if clip_denoised else self._prevx_x0
         return sample, x0, g
 
     @staticmethod
@@ -427,7 +458,7 @@ class GaussianDiffusion:
         assert t.shape == (x.shape[0],)
         eps = self._model_eps(x, model(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
-            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
+            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
         mean, x0, _ = self._step("ddpm", x, eps, None, None, t, clip_denoised)
         if self._learned():        # the dict's variance entries (API surface; the sampling steps compute them inside the fused kernel)
             vv = self._var_values
@@ -546,10 +577,13 @@ class GaussianDiffusion:
         E = mean_pred.numel() // B
         dev = mean_pred.device
         mean_pred = mean_pred.float().contiguous()
+        per_elem = False
         if not th.is_tensor(g_coeff):
             g = th.full((B,), float(g_coeff), device=dev)
         elif g_coeff.dim() == 1 and g_coeff.numel() == B:                    # per-sample scale from the fused step
             g = g_coeff.float().contiguous()
+        elif self._learned() and g_coeff.numel() == mean_pred.numel():       # learned variances: one scale per element (:708)
+            g, per_elem = g_coeff.float().reshape(mean_pred.shape).contiguous(), True
         else:                                                                # (B,1,1,1) / (B,C,H,W) as in the reference
             g = g_coeff.float().expand(mean_pred.shape).reshape(B, -1)[:, 0].contiguous()
         k0, nl, sharded = scg_shard.partition(n) if self.scg_shard else (0, n, False)
@@ -565,10 +599,19 @@ class GaussianDiffusion:
             noise = self.noise.fill((nl,) + tuple(mean_pred.shape), dev, offset=base + k0 * B * E)
         cand = th.empty((nl * B,) + tuple(mean_pred.shape[1:]), dtype=th.float32, device=dev)
         with th.cuda.device(dev):
-            _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(noise), _rgm.ptr(cand),
-                                                   nl, B, E, _rgm.current_stream()))
+            if per_elem:      # the same kernel over B*E "samples" of one element each: g is then indexed per element
+                _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(noise), _rgm.ptr(cand),
+                                                       nl, B * E, 1, _rgm.current_stream()))
+            else:
+                _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(noise), _rgm.ptr(cand),
+                                                       nl, B, E, _rgm.current_stream()))
         t_rep = t.repeat(nl)
         eps = model(cand, self._scale_timesteps(t_rep), y=model_kwargs["y"].repeat(nl))
+        if self._learned() and eps.shape[1] == 2 * cand.shape[1]:
+            # learn_sigma=True network: the eps half of its 2C channels, split like p_mean_variance does (:299-301).  The reference's
+            # scg_sample does not split and dies in _predict_xstart_from_eps' shape assert (tests/golden round3 'reference_raises');
+            # this is the completion its own p_mean_variance implies, pinned to the reference's selection code fed that half.
+            eps = eps[:, :cand.shape[1]].contiguous()
         x0 = self._predict_xstart_from_eps(cand, t_rep, eps)
         if edit_kwargs is not None:                                          # only the editable rows are decoded and scored
             x0 = x0[:, :, int(edit_kwargs["l_start"]):int(edit_kwargs["l_end"]), :].contiguous()
@@ -582,13 +625,15 @@ class GaussianDiffusion:
             mi = max_ind.reshape(-1, B).contiguous()
             if full_noise is not None:                       # injected noise (tests): a device gather per segment
                 ar = th.arange(B, device=dev)
-                parts = [mean_pred[:, :, r0:r0 + seg_rows] + g.view(B, 1, 1, 1) * full_noise[mi[i], ar][:, :, r0:r0 + seg_rows]
+                gv = g if per_elem else g.view(B, 1, 1, 1).expand(mean_pred.shape)
+                parts = [mean_pred[:, :, r0:r0 + seg_rows] + gv[:, :, r0:r0 + seg_rows] * full_noise[mi[i], ar][:, :, r0:r0 + seg_rows]
                          for i, r0 in enumerate(range(0, H, seg_rows))]
                 return th.cat(parts, dim=-2).contiguous()
             res = th.empty_like(mean_pred)
+            fn = _rgm.lib.rgm_scg_rebuild_g if per_elem else _rgm.lib.rgm_scg_rebuild
             with th.cuda.device(dev):
-                _rgm.check(_rgm.lib.rgm_scg_rebuild(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(mi), C.c_uint64(self.noise.seed),
-                                                    C.c_uint64(base), _rgm.ptr(res), B, E, H, W, seg_rows, _rgm.current_stream()))
+                _rgm.check(fn(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(mi), C.c_uint64(self.noise.seed),
+                              C.c_uint64(base), _rgm.ptr(res), B, E, H, W, seg_rows, _rgm.current_stream()))
             return res
 
         if dc_kwargs is not None and getattr(dc_kwargs, "base", 0) > 0:
@@ -601,7 +646,15 @@ class GaussianDiffusion:
             w = scg_kwargs.get(name, 1.)
             total = lp * w if total is None else total + lp * w
         total = total.float().view(nl, B).contiguous()
-        total_all = scg_shard.gather_totals(total) if sharded else total       # (n, B) on every rank
+        if sharded and record:
+            # --record under sharding: the per-rule log-probs ride the SAME all-gather as the totals ((nl, (1 + rules) B) instead of
+            # (nl, B)), so every rank can report the winner's per-rule loss whichever rank scored it (reference :594-600)
+            names = list(each)
+            allv = scg_shard.gather_totals(th.cat([total] + [each[k].float().view(nl, B) for k in names], dim=1).contiguous())
+            total_all = allv[:, :B].contiguous()
+            each = {k: allv[:, (i + 1) * B:(i + 2) * B] for i, k in enumerate(names)}
+        else:
+            total_all = scg_shard.gather_totals(total) if sharded else total   # (n, B) on every rank
         out = th.empty_like(mean_pred)
         max_ind = th.empty(B, dtype=th.int64, device=dev)
         with th.cuda.device(dev):
@@ -615,7 +668,22 @@ class GaussianDiffusion:
                                                    _rgm.current_stream()))
                 out = rebuild(max_ind)                                         # on the device: no host sync in a guided step
         if record:
-            self._record_scg(t, total_all, max_ind, each, x0, nl, B, record_freq, sharded)
+            def winner_x0():
+                if not sharded:
+                    return x0.view((nl, B) + tuple(x0.shape[1:]))[max_ind, th.arange(B, device=dev)].clone()
+                # the winner may have been scored on another rank: its decoded x0 estimate is recomputed from the rebuilt winner
+                # (one B-row forward + decode, only on the steps that keep a roll)
+                e = model(out, self._scale_timesteps(t), y=model_kwargs["y"])
+                if self._learned() and e.shape[1] == 2 * out.shape[1]:
+                    e = e[:, :out.shape[1]].contiguous()
+                xw = self._predict_xstart_from_eps(out, t, e)
+                if edit_kwargs is not None:
+                    xw = xw[:, :, int(edit_kwargs["l_start"]):int(edit_kwargs["l_end"]), :].contiguous()
+                xw = _decode(xw, embed_model, scale_factor=scale_factor) if embed_model is not None else xw
+                for name in model_kwargs["rule"]:          # the rule programs write into the roll they score (music_rules.py:23-26, :65):
+                    _extract_rule(name, xw)                # the roll the reference keeps carries those writes
+                return xw
+            self._record_scg(t, total_all, max_ind, each, winner_x0, B, record_freq)
         self.last_scg = {"total_log_prob": total_all, "max_ind": max_ind}
         return out
 
@@ -669,20 +737,22 @@ class GaussianDiffusion:
             return rebuild(max_ind, seg_rows=dc_kwargs.base)                     # (S,B) winners, rebuilt on the device
         return th.cat(pieces, dim=-2)
 
-    def _record_scg(self, t, total, max_ind, each, x0, nl, B, record_freq, sharded):
+    def _record_scg(self, t, total, max_ind, each, winner_x0, B, record_freq):
+        """--record bookkeeping of a search step (reference :594-632): total (n,B) log-probs, each {rule: (n,B) log-probs} of ALL
+        candidates (gathered under sharding), winner_x0() -> the winners' decoded x0 estimates."""
         t0 = self._t0(t)
         ar = th.arange(B, device=total.device)
         best = total[max_ind, ar][0].item()
         self.log_probs.append((t0, best))
         self.loss_std.append((t0, total.std().item()))
         self.loss_range.append((t0, abs(best - total.min().item())))
-        if not sharded:
-            for name, lp in each.items():
-                self.each_loss[name].append((t0, (-lp.view(nl, B))[max_ind, ar][0].item()))
-            if (t0 + 1) % record_freq == 0:
-                xs = x0.view((nl, B) + tuple(x0.shape[1:]))[max_ind, ar].clone()
-                xs[xs <= -0.95] = -1.
-                self.inter_piano_rolls.append(((xs + 1) * 63.5).clamp(0, 127).to(th.uint8).cpu())
+        n = total.shape[0]
+        for name, lp in each.items():
+            self.each_loss[name].append((t0, (-lp.reshape(n, B))[max_ind, ar][0].item()))
+        if (t0 + 1) % record_freq == 0:
+            xs = winner_x0()
+            xs[xs <= -0.95] = -1.
+            self.inter_piano_rolls.append(((xs + 1) * 63.5).clamp(0, 127).to(th.uint8).cpu())
 
     # ------------------------------------------------------------------ one reverse step
     def _use_guidance(self, guidance_kwargs, t):
@@ -719,8 +789,12 @@ class GaussianDiffusion:
             return {"sample": sample, "pred_xstart": x0}
         eps = self._model_eps(x, self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
-            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
+            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
         if dps:
+            if self._learned():
+                raise NotImplementedError("DPS guidance on a learn_sigma=True network: the reference's condition_mean feeds the 2C-channel "
+                                          "output to _predict_xstart_from_eps and dies in its shape assert (gaussian_diffusion.py:421; "
+                                          "tests/golden/round3.npz 'reference_raises') -- there is no behaviour to reproduce")
             mean, x0, g = self._step("ddpm", x, eps, None, None, t, clip_denoised, want_g=True)
             # the reference hands the UNWRAPPED model to condition_mean (:692-697): on a re-spaced chain the DPS forward
             # runs at the un-mapped t, like scg_sample's.  Reproduced, not fixed.
@@ -782,7 +856,7 @@ class GaussianDiffusion:
             return {"sample": sample, "pred_xstart": x0}
         eps = self._model_eps(x, wrapped(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
-            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs)
+            eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
         grad = None
         if cond_fn is not None and use_guidance:
             grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
@@ -835,6 +909,8 @@ class GaussianDiffusion:
                 self._t_host = None
             yield out
             img = out["sample"]
+        from .dit import check_native_status        # a stream-K GEMM that timed out inside the chain invalidates it: raise (no device sync)
+        check_native_status()
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, t_end=0,
                                   cond_fn=None, model_kwargs=None, device=None, progress=False, embed_model=None,

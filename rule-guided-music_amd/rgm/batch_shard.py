@@ -50,15 +50,24 @@ def partition_rows(B, world_size=None, rank=None):
 _orig_partition_rows = partition_rows        # (tests replace partition_rows with one rank's view and still need the rule itself)
 
 
-def slice_rows(obj, B, b0, nb):
-    """Rows [b0, b0+nb) of every tensor with leading dimension B inside a (nested) dict / list / tuple; other values pass through
-    (per-call scalars, namespaces, tensors broadcast over the batch such as a (1,C,H,W) edit mask)."""
+PER_SAMPLE_VECTORS = ("y", "t", "timesteps")      # the only 1-D tensors that carry one entry per sample
+
+
+def slice_rows(obj, B, b0, nb, key=None):
+    """Rows [b0, b0+nb) of every per-sample tensor inside a (nested) dict / list / tuple; other values pass through (per-call scalars,
+    namespaces, tensors broadcast over the batch such as a (1,C,H,W) edit mask).  Per-sample means: at least 2-D with leading
+    dimension B (latents, (B,K) rule targets, masks), or a 1-D tensor of length B stored under one of PER_SAMPLE_VECTORS (class labels,
+    timesteps) -- an unbatched 1-D tensor that merely happens to have B entries (a (16,) target with B = 16) is NOT cut."""
     if torch.is_tensor(obj):
-        return obj[b0:b0 + nb].contiguous() if obj.dim() >= 1 and obj.shape[0] == B else obj
+        if obj.dim() >= 2 and obj.shape[0] == B:
+            return obj[b0:b0 + nb].contiguous()
+        if obj.dim() == 1 and obj.shape[0] == B and key in PER_SAMPLE_VECTORS:
+            return obj[b0:b0 + nb].contiguous()
+        return obj
     if isinstance(obj, dict):
-        return {k: slice_rows(v, B, b0, nb) for k, v in obj.items()}
+        return {k: slice_rows(v, B, b0, nb, k) for k, v in obj.items()}
     if isinstance(obj, (list, tuple)):
-        return type(obj)(slice_rows(v, B, b0, nb) for v in obj)
+        return type(obj)(slice_rows(v, B, b0, nb, key) for v in obj)
     return obj
 
 

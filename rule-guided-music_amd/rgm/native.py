@@ -38,6 +38,8 @@ def _load():
         "rgm_randn": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_uint64, vp]),
         "rgm_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp]),
         "rgm_ddpm_step_learned": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp]),
+        "rgm_ddpm_step_learned_g": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp]),
+        "rgm_scg_rebuild_g": (C.c_int, [vp, vp, vp, C.c_uint64, C.c_uint64, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_ddim_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp, i32, i32, vp]),
         "rgm_scg_candidates": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_xstart_from_eps": (C.c_int, [vp, vp, vp, vp, f32, vp, i32, i32, vp]),
@@ -76,6 +78,8 @@ def _load():
         "rgm_gemm_split": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp]),
         "rgm_gemm_streamk_workspace_bytes": (sz, []),
         "rgm_set_streamk": (C.c_int, [i32]),
+        "rgm_gemm_streamk_status": (C.c_int, [vp, vp]),
+        "rgm_dit_status": (C.c_int, [vp]),
         "rgm_gemm_split_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_gemm_split_epi": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_split_rows_ld": (C.c_int, [vp, i32, vp, i32, C.c_int64, i32, vp]),

@@ -81,31 +81,45 @@ def main(argv=None):
         sample = sample_fn(eps_fn, shape, clip_denoised=args.clip_denoised, model_kwargs=model_kwargs, device=device,
                            progress=args.progress)
         u8 = midi_util.decode_sample_for_midi(sample, embed_model=embed_model, scale_factor=args.scale_factor, threshold=-0.95)
-        if world > 1:
-            gathered = [th.zeros_like(u8) for _ in range(world)]
-            dist.all_gather(gathered, u8.contiguous())
-        else:
-            gathered = [u8]
+        gathered, gl = gather_batch(u8, classes, world)
         rolls.extend(g.cpu().numpy() for g in gathered)
-        if classes is not None:
-            if world > 1:
-                gl = [th.zeros_like(classes) for _ in range(world)]
-                dist.all_gather(gl, classes)
-            else:
-                gl = [classes]
-            labels.extend(g.cpu().numpy() for g in gl)
+        labels.extend(g.cpu().numpy() for g in gl)
         logger.log(f"created {len(rolls) * args.batch_size} samples")
 
-    arr = np.concatenate(rolls, axis=0)                                    # (n, 128, T, C) uint8
-    arr = arr.squeeze(axis=-1) if arr.shape[-1] == 1 else arr.transpose(0, 3, 1, 2)
-    arr = arr[:args.num_samples]
-    label_arr = np.concatenate(labels, axis=0)[:args.num_samples] if labels else None
+    arr, label_arr = assemble(rolls, labels, args.num_samples)
     if rank == 0:
         midi_util.save_piano_roll_midi(arr, save_dir, args.fs, y=label_arr)
     if world > 1:
         dist.barrier()
     logger.log("sampling complete")
     return arr
+
+
+def gather_batch(u8, classes, world):
+    """One batch of every rank, in rank order (reference scripts/cfg_sample.py:102-109: all_gather of the uint8 rolls -- 0.4 MB per
+    sample -- and of the labels): -> ([rolls of rank 0, rank 1, ...], [labels ...]); one rank: the batch itself."""
+    if world > 1:
+        gathered = [th.zeros_like(u8) for _ in range(world)]
+        dist.all_gather(gathered, u8.contiguous())
+    else:
+        gathered = [u8]
+    gl = []
+    if classes is not None:
+        if world > 1:
+            gl = [th.zeros_like(classes) for _ in range(world)]
+            dist.all_gather(gl, classes)
+        else:
+            gl = [classes]
+    return gathered, gl
+
+
+def assemble(rolls, labels, num_samples):
+    """[(B,128,T,C) uint8 per rank and round] -> the first num_samples rolls as (n,C,128,T) (reference :111-117), labels alike."""
+    arr = np.concatenate(rolls, axis=0)                                    # (n, 128, T, C) uint8
+    arr = arr.squeeze(axis=-1) if arr.shape[-1] == 1 else arr.transpose(0, 3, 1, 2)
+    arr = arr[:num_samples]
+    label_arr = np.concatenate(labels, axis=0)[:num_samples] if labels else None
+    return arr, label_arr
 
 
 def create_argparser():

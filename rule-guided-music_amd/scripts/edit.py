@@ -29,6 +29,7 @@ from guided_diffusion import dist_util, logger, midi_util                       
 from guided_diffusion.gaussian_diffusion import _encode, _extract_rule                      # noqa: E402
 from guided_diffusion.midi_util import (HORIZONTAL_ND_BOUNDS, HORIZONTAL_ND_CENTER, VERTICAL_ND_BOUNDS,  # noqa: E402
                                         VERTICAL_ND_CENTER)
+import sample_rule as _sr                                                                                         # noqa: E402
 from sample_rule import build_pipeline, setup_chord_backend, create_argparser as _sample_argparser              # noqa: E402
 
 
@@ -43,12 +44,14 @@ def synthetic_roll(seed, T):
     return th.from_numpy(r)
 
 
-def load_source(source, T, fs, device):
+def load_source(source, T, fs, device, allow_synthetic=False):
     """-> ground-truth roll (1,3,128,T) float32 in [-1,1], right-padded with background (reference :169-174)."""
     if source == "dataset":
         # the reference draws a test-set excerpt here (edit.py :140-168); the dataset loader is out of scope (SURVEY 2 row 15)
-        logger.log("WARNING: edit.source 'dataset' needs the reference's data loader; using the synthetic source "
-                   "(give a .npy roll or a MIDI file for real use)")
+        if not allow_synthetic:
+            raise RuntimeError("edit.source 'dataset' needs the reference's data loader (out of scope): give a .npy roll or a MIDI "
+                               "file as edit.source, or opt in to a seeded synthetic roll with --allow_synthetic_source True")
+        logger.log("WARNING: --allow_synthetic_source: edit.source 'dataset' replaced by the seeded synthetic roll")
         source = "synthetic"
     if source == "synthetic":
         gt = synthetic_roll(0, T)
@@ -116,8 +119,13 @@ def main(argv=None):
     from rgm import native as _native
     _native.set_gemm_precision(args.gemm_precision)
     comm = dist_util.setup_dist(port=args.port)
-    logger.configure(args=args, comm=comm)
     config = setup_chord_backend(args, midi_util.load_config(args.config_path))
+    substituted = vars(config.edit).get("source", "synthetic") == "dataset" and args.allow_synthetic_source
+    if _sr.DROPPED_RULES:
+        args.dir += "_nochord"
+    if substituted:
+        args.dir += "_synthsrc"
+    logger.configure(args=args, comm=comm)
     if config.sampling.use_ddim:
         args.timestep_respacing = config.sampling.timestep_respacing
     device = dist_util.dev()
@@ -137,7 +145,9 @@ def main(argv=None):
 
     edit_kwargs = dict(vars(config.edit))
     edit_kwargs["l_start_pix"], edit_kwargs["l_end_pix"] = edit_kwargs["l_start"] * 8, edit_kwargs["l_end"] * 8
-    gt = load_source(edit_kwargs.get("source", "synthetic"), gen_shape[2] * 8, args.fs, device)
+    gt = load_source(edit_kwargs.get("source", "synthetic"), gen_shape[2] * 8, args.fs, device, allow_synthetic=args.allow_synthetic_source)
+    if args.save_files and rank0:
+        _sr.write_run_metadata(save_dir, args, {"source": edit_kwargs.get("source", "synthetic"), "source_substituted_by_synthetic": bool(substituted)})
     gt_latent = _encode(gt, embed_model, scale_factor=args.scale_factor)
     mask = th.ones_like(gt_latent)
     mask[:, :, edit_kwargs["l_start"]:edit_kwargs["l_end"], :] = 0.
@@ -187,7 +197,11 @@ def main(argv=None):
 
 
 def create_argparser():
-    return _sample_argparser()
+    parser = _sample_argparser()
+    parser.add_argument("--allow_synthetic_source", default=False, type=lambda v: str(v).lower() in ("yes", "true", "t", "y", "1"),
+                        help="edit.source 'dataset' needs the reference's data loader; True substitutes a seeded synthetic roll "
+                             "(marked in the output directory name and run_metadata.json)")
+    return parser
 
 
 if __name__ == "__main__":

@@ -37,12 +37,18 @@ import diff_collage as dc  # noqa: E402
 NOISE_FN = None     # tests only: callable(shape, device) -> tensor installed as diffusion.noise_fn (teacher-forced parity runs)
 
 
+DROPPED_RULES = []    # what setup_chord_backend removed under --skip_chord_rules (run_metadata.json, output directory suffix)
+
+
 def setup_chord_backend(args, config):
     """Chord rules (`chord_progression*`) need a host analyser with the signature of the reference's piano_roll_to_chords
     (music21; not installable here).  --chord_backend module:function registers one (music_rules.register_chord_backend).
-    Without one the reference's chord entries are ACCEPTED and skipped with a warning: they are removed from target_rules,
-    from the SCG weights and from the cond_fn lists, so a reference YAML runs with its remaining rules."""
+    Without one a config that asks for chord conditioning is an ERROR -- a run that silently lacks the requested rule would write
+    tables that look like a fully conditioned one.  The explicit opt-in `--skip_chord_rules True` removes the chord entries from
+    target_rules, from the SCG weights and from the cond_fn lists instead; what was removed is logged, recorded in
+    run_metadata.json and marked in the output directory name (`_nochord`)."""
     from music_rule_guidance import music_rules
+    del DROPPED_RULES[:]
     if getattr(args, "chord_backend", ""):
         import importlib
         mod, _, fn = args.chord_backend.partition(":")
@@ -50,15 +56,24 @@ def setup_chord_backend(args, config):
         return config
     if music_rules._CHORD_BACKEND is not None:
         return config
-    dropped = []
     tr = vars(config.target_rules)
+    cf = getattr(config.guidance, "cond_fn", None)
+    wanted = [f"target_rules.{k}" for k in tr if "chord" in k]
+    if cf is not None:
+        wanted += [f"cond_fn.{r}" for r in cf.rule_names if "chord" in r]
+    if not wanted:
+        return config
+    if not getattr(args, "skip_chord_rules", False):
+        raise RuntimeError("this config conditions on chord rules (" + ", ".join(wanted) + ") but no chord analyser is registered: "
+                           "pass --chord_backend module:function (signature of the reference's piano_roll_to_chords), or opt in to "
+                           "running WITHOUT them with --skip_chord_rules True")
+    dropped = []
     for k in [k for k in tr if "chord" in k]:
         tr.pop(k)
         dropped.append(f"target_rules.{k}")
     if getattr(config, "scg", None) is not None:
         for k in [k for k in vars(config.scg) if "chord" in k]:
             vars(config.scg).pop(k)
-    cf = getattr(config.guidance, "cond_fn", None)
     if cf is not None and any("chord" in r for r in cf.rule_names):
         keep = [i for i, r in enumerate(cf.rule_names) if "chord" not in r]
         dropped += [f"cond_fn.{cf.rule_names[i]}" for i in range(len(cf.rule_names)) if i not in keep]
@@ -73,9 +88,51 @@ def setup_chord_backend(args, config):
         if not keep:
             config.guidance.cond_fn = None
             config.guidance.nn = False
-    if dropped:
-        logger.log("WARNING: no chord analyser registered (--chord_backend module:function); skipping " + ", ".join(dropped))
+    DROPPED_RULES.extend(dropped)
+    logger.log("WARNING: --skip_chord_rules: running WITHOUT " + ", ".join(dropped))
     return config
+
+
+def write_run_metadata(save_dir, args, extra=None):
+    """run_metadata.json next to results.csv: what this run was NOT conditioned on / substituted (empty lists for a faithful run)."""
+    import json
+    meta = {"config_path": args.config_path, "dropped_rules": list(DROPPED_RULES), "synthetic_weights": bool(args.synthetic_weights),
+            "targets_npz": getattr(args, "targets_npz", "") or None}
+    meta.update(extra or {})
+    with open(os.path.join(save_dir, "run_metadata.json"), "w") as f:
+        json.dump(meta, f, indent=1)
+
+
+def targets_from_npz(path, target_rules, batch_size, device):
+    """`target_rules: Null` (reference :147-168: the targets are the rules of a dataset batch).  The dataset loader is out of scope;
+    the batch itself is not: --targets_npz gives either `gt`, the ground-truth rolls ((B,3,128,T) float32 in [-1,1], what the
+    reference's load_data yields) from which every rule is extracted with _extract_rule exactly like the reference does, or one
+    array per rule ((B,K) or (K,)).  vertical_nd / horizontal_nd collapse into the fused note_density rule as in the reference."""
+    names = list(target_rules)
+    if "vertical_nd" in names:
+        names = [k for k in names if k not in ("vertical_nd", "horizontal_nd")] + ["note_density"]
+    z = np.load(path)
+    out = {}
+    if "gt" in z.files:
+        gt = th.from_numpy(np.ascontiguousarray(z["gt"], dtype=np.float32)).to(device)
+        if gt.shape[0] < batch_size:
+            raise ValueError(f"{path}: gt holds {gt.shape[0]} rolls, batch_size is {batch_size}")
+        gt = gt[:batch_size].contiguous()
+        with th.no_grad():
+            for k in names:
+                out[k] = _extract_rule(k, gt)
+        return out
+    for k in names:
+        if k not in z.files:
+            raise KeyError(f"{path}: no array for rule '{k}' (has {z.files}); give `gt` or one array per rule")
+        v = th.from_numpy(np.ascontiguousarray(z[k])).to(device)
+        v = v.float() if v.is_floating_point() else v
+        if v.dim() == 1:
+            v = v.repeat(batch_size, 1)
+        if v.shape[0] < batch_size:
+            raise ValueError(f"{path}: '{k}' holds {v.shape[0]} rows, batch_size is {batch_size}")
+        out[k] = v[:batch_size].contiguous()
+    return out
 
 
 def output_dir_for(config_path, class_label):
@@ -197,8 +254,10 @@ def main(argv=None):
     from rgm import native as _native
     _native.set_gemm_precision(args.gemm_precision)      # "bf16x3_presplit" / "bf16x3" (fast, fp32-grade) or "fp32" (exact fp32 MFMA)
     comm = dist_util.setup_dist(port=args.port)
-    logger.configure(args=args, comm=comm)
     config = setup_chord_backend(args, midi_util.load_config(args.config_path))
+    if DROPPED_RULES:
+        args.dir += "_nochord"
+    logger.configure(args=args, comm=comm)
     if config.sampling.use_ddim:
         args.timestep_respacing = config.sampling.timestep_respacing
     device = dist_util.dev()
@@ -210,9 +269,13 @@ def main(argv=None):
 
     target_rules = vars(config.target_rules)
     if any(v is None for v in list(target_rules.values())[:1]):
-        raise NotImplementedError("target rules 'Null' are drawn from a dataset batch in the reference (:147-168); "
-                                  "the dataset loader is out of scope -- give the targets in the YAML")
-    model_kwargs = {"rule": build_target_rules(target_rules, args.batch_size, device)}
+        if not args.targets_npz:
+            raise NotImplementedError("target rules 'Null' are the rules of a dataset batch in the reference (:147-168); the dataset "
+                                      "loader is out of scope -- pass that batch with --targets_npz (`gt` rolls or one array per "
+                                      "rule), or give the targets in the YAML")
+        model_kwargs = {"rule": targets_from_npz(args.targets_npz, target_rules, args.batch_size, device)}
+    else:
+        model_kwargs = {"rule": build_target_rules(target_rules, args.batch_size, device)}
     classes = None
     if args.class_cond:
         classes = th.ones(size=(args.batch_size,), device=device, dtype=th.int) * args.class_label
@@ -220,6 +283,8 @@ def main(argv=None):
 
     save_dir = logger.get_dir()
     os.makedirs(os.path.expanduser(save_dir), exist_ok=True)
+    if args.save_files and rank0:
+        write_run_metadata(save_dir, args)
     sample_fn = partial(diffusion.ddim_sample_loop, eta=1.) if config.sampling.use_ddim else diffusion.p_sample_loop
     use_scg = bool(getattr(config.guidance, "scg", getattr(config.guidance, "beam", False)))
 
@@ -268,6 +333,7 @@ def create_argparser():
         port=None,
         # additions of this implementation
         synthetic_weights=False, progress=True, gemm_precision="bf16x3_presplit", chord_backend="", chord_workers=4,
+        skip_chord_rules=False, targets_npz="",
     )
     defaults.update(model_and_diffusion_defaults())
     parser = argparse.ArgumentParser()

@@ -49,11 +49,42 @@ class DiagonalGaussianDistribution:
         return self.mean
 
 
+# globals a tensor checkpoint legitimately needs (the same set torch's weights_only unpickler admits, plus data-only numpy
+# reconstruction for the scalars Lightning keeps in callback state); everything else -- the rest of builtins included --
+# resolves to an inert stub, so a REDUCE op in a crafted file can call nothing but these constructors
+_SAFE_GLOBALS = {
+    ("collections", "OrderedDict"), ("collections", "defaultdict"),
+    ("builtins", "set"), ("builtins", "frozenset"), ("builtins", "dict"), ("builtins", "list"), ("builtins", "tuple"),
+    ("builtins", "int"), ("builtins", "float"), ("builtins", "bool"), ("builtins", "str"), ("builtins", "bytes"),
+    ("builtins", "bytearray"), ("builtins", "complex"), ("builtins", "slice"),
+    ("_codecs", "encode"),
+    ("torch._utils", "_rebuild_tensor"), ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_parameter"),
+    ("torch._utils", "_rebuild_parameter_with_state"), ("torch._tensor", "_rebuild_from_type_v2"),
+    ("torch", "Size"), ("torch", "device"), ("torch", "Tensor"), ("torch.nn.parameter", "Parameter"),
+    ("torch.storage", "UntypedStorage"), ("torch.storage", "TypedStorage"),
+    ("numpy", "dtype"), ("numpy", "ndarray"), ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"),
+}
+_SAFE_TORCH_ATTRS = {"float32", "float64", "float16", "bfloat16", "int64", "int32", "int16", "int8", "uint8", "bool", "complex64",
+                     "FloatStorage", "DoubleStorage", "HalfStorage", "BFloat16Storage", "LongStorage", "IntStorage", "ShortStorage",
+                     "CharStorage", "ByteStorage", "BoolStorage"}
+
+
+def _numpy_scalar(dtype, data):
+    """data-only stand-in for numpy.core.multiarray.scalar (the real one unpickles `data` for object dtypes)"""
+    import numpy as np
+    dtype = np.dtype(dtype)
+    if dtype.hasobject or not isinstance(data, (bytes, bytearray)):
+        return None
+    return np.frombuffer(data, dtype=dtype, count=1)[0]
+
+
 def read_lightning_state_dict(path):
     """["state_dict"] of a torch / pytorch-lightning checkpoint without importing what else it pickles: tensors and plain
     containers load normally (weights_only first); if the file references classes this stack does not have (Lightning
-    callbacks, omegaconf nodes), it is re-read with an unpickler that replaces every global outside torch / collections /
-    numpy by an inert stub -- only tensor storage is ever materialised."""
+    callbacks, omegaconf nodes), it is re-read with an unpickler that resolves ONLY an explicit allow-list of constructors
+    (_SAFE_GLOBALS: tensor / storage rebuilders, torch dtypes, OrderedDict, plain builtin containers and scalars, data-only
+    numpy reconstruction) and replaces every other global -- builtins such as eval / exec / getattr / __import__ and all other
+    torch / numpy callables included -- by an inert stub class: a crafted checkpoint cannot run code through a pickle REDUCE."""
     import pickle
     try:
         obj = torch.load(path, map_location="cpu", weights_only=True)
@@ -70,8 +101,10 @@ def read_lightning_state_dict(path):
 
         class _Unpickler(pickle.Unpickler):
             def find_class(self, module, name):
-                if module.split(".")[0] in ("torch", "collections", "numpy", "builtins", "_codecs"):
+                if (module, name) in _SAFE_GLOBALS or (module == "torch" and name in _SAFE_TORCH_ATTRS):
                     return super().find_class(module, name)
+                if (module, name) in (("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")):
+                    return _numpy_scalar
                 return type(name, (_Stub,), {"__module__": module})
 
         class _Pickle:

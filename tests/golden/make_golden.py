@@ -47,6 +47,8 @@ def err(name, a, b):
 
 
 def save(name, **arrs):
+    stored = {k: int(v) for k, v in arrs.items() if k.endswith("seed") and np.ndim(v) == 0}
+    assert stored == FIXTURE_SEEDS.get(name, {}), f"{name}: stored seeds {stored} != FIXTURE_SEEDS[{name!r}] {FIXTURE_SEEDS.get(name, {})}"
     p = os.path.join(HERE, name + ".npz")
     np.savez_compressed(p, **arrs)
     print(f"  wrote {name}.npz  {os.path.getsize(p) / 1024:.1f} KiB")
@@ -401,6 +403,29 @@ def g_steps(vae):
     save("steps", **out)
 
 
+# Every seed a fixture STORES (weights / inputs / noise the tests regenerate from it), by fixture and key.  save() refuses to write a
+# fixture whose stored seeds disagree with this table, and tests/test_oracle_golden.py checks every COMMITTED fixture against it (the
+# table is read with ast, the reference is not needed): a script edit that changes a seed fails a CPU test instead of silently leaving
+# a fixture that HEAD can no longer reproduce (round 2: `circ` had been generated with 1415 while the script's counter said 1414).
+FIXTURE_SEEDS = {
+    "chord_quantise": {"seed": 1300},
+    "classifier": {"chord.seed": 5, "s8.seed": 3, "s8d2.seed": 4},
+    "cli2": {"scg_noise_seed": 1502, "xT_seed": 1501},
+    "dit_xl_d2": {"seed": 1},
+    "dit_xl_d28": {"seed": 1},
+    "dps_rule": {"ph.rseed": 1202, "vjp.gseed": 1201},
+    "e2e_ddim50_sm": {"seed": 11},
+    "e2e_ddim50_xl28": {"seed": 1},
+    "edit": {"seed": 2},
+    "learned": {"seed": 21},
+    "next2": {"dpsscg.noise_seed": 1910, "dpsscg_off.noise_seed": 2410},
+    "round3": {"lsig.seed": 21},
+    "seg": {"noise_seed": 1451},
+    "steps2": {"circ.noise_seed": 1415, "dcg.noise_seed": 1411, "dscg.noise_seed": 1412, "dscgc.noise_seed": 1413},
+    "vae_decoder": {"seed": 2},
+}
+
+
 def g_steps2(vae):
     """Round-2 pins: DDIM + classifier guidance (condition_score), DDIM + SCG, segment-wise SCG (dc.base)
     on a 256-row latent and on demo2.yml's one-window circle collage, classifier-free guidance through model_fn / dc_model_fn."""
@@ -414,13 +439,13 @@ def g_steps2(vae):
     x = rng.randn(B, 4, 128, 16).astype(F32)
     y = np.array([1, 2], dtype=np.int64)
     out = {"x": x, "y": y}
-    nseed = [1410]
-
     def seeded_noise(tag, *shape):
-        """noise of this item = RandomState(seed).randn(shape): the tests regenerate it from the stored seed"""
-        nseed[0] += 1
-        out[f"{tag}.noise_seed"] = np.array(nseed[0])
-        return np.random.RandomState(nseed[0]).randn(*shape).astype(F32)
+        """noise of this item = RandomState(seed).randn(shape): the tests regenerate it from the stored seed.  The seed of every
+        item is pinned by NAME (FIXTURE_SEEDS): a running counter made every later seed drift when an item moved to another fixture
+        (round 2: `circ` was generated with 1415, the script then said 1414)."""
+        seed = FIXTURE_SEEDS["steps2"][f"{tag}.noise_seed"]
+        out[f"{tag}.noise_seed"] = np.array(seed)
+        return np.random.RandomState(seed).randn(*shape).astype(F32)
     mf = ref_model_fn(m, 3, True)
     omf = np_model(sd, SM)
     rule = {"note_density": rng.rand(B, 16).astype(F32) * 4}
@@ -817,6 +842,134 @@ def g_learned():
         out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].numpy(), f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
         print(f"    {tag}: sample range {r['sample'].min().item():.3f} .. {r['sample'].max().item():.3f}")
     save("learned", **out)
+
+
+LSIG_FINAL_GAIN = 12.0      # tests/test_gpu_round3.py rebuilds the same weights
+
+
+def g_round3(vae):
+    """Round-3 pins: (a) denoised_fn TOGETHER with edit_kwargs -- the reference runs process_xstart before the replacement (:294-296)
+    and again on the replaced x0 (:336-342), so a non-idempotent denoised_fn is applied twice; (b) ModelMeanType.PREVIOUS_X
+    (:331-338; the model predicts x_{t-1}, the mean is its output whatever clip_denoised says); (c) what the reference does with SCG /
+    DPS on a learn_sigma=True network: both RAISE (AssertionError in _predict_xstart_from_eps: the 2C-channel output is never split on
+    those paths) -- recorded here so that the parity claim is checkable; (d) the reference's scg_sample fed a per-element (tensor)
+    g_coeff, as p_sample (:706-711) feeds it at a learned-variance step, with the candidates' eps taken from the first C channels the
+    way p_mean_variance splits them (:299-301) -- the natural completion of (c), pinned to the reference's own selection code."""
+    print("[round3: denoised_fn + edit, PREVIOUS_X, learned-variance SCG]")
+    import json
+    from functools import partial
+    from types import SimpleNamespace
+    m, sd = ref_dit(SM, 11)
+    mf = ref_model_fn(m, 3, True)
+    rng = np.random.RandomState(3100)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    gt = (rng.randn(B, 4, 128, 16) * 0.8).astype(F32)
+    ls, le = 32, 96
+    mask = np.ones_like(gt)
+    mask[:, :, ls:le, :] = 0.
+    ek = {"gt": torch.from_numpy(gt), "mask": torch.from_numpy(mask), "l_start": ls, "l_end": le, "noise_level": 3}
+    out = {"x": x, "y": y, "gt": gt, "mask": mask, "l_start": np.array(ls), "l_end": np.array(le)}
+
+    def dfn(v):
+        return v.clamp(-0.5, 0.5) * 0.9
+    for tag, rs, ddim, ti, clip in (("dfn_edit_ddpm", "", False, 500, True), ("dfn_edit_ddim", "ddim50", True, 25, False)):
+        d = make_diffusion(rs)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        kw = dict(clip_denoised=clip, denoised_fn=dfn, model_kwargs={"y": torch.from_numpy(y)}, edit_kwargs=ek)
+        r = (d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), eta=1.0, **kw) if ddim
+             else d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), **kw))
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.clip": np.array(int(clip)), f"{tag}.sample": r["sample"].numpy(),
+                    f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
+        NQ.q.clear()
+        print(f"    {tag}: pred_xstart range {r['pred_xstart'].min().item():.3f} .. {r['pred_xstart'].max().item():.3f}")
+
+    # ---- (b) PREVIOUS_X
+    for tag, rs, ddim, ti, clip in (("prevx_ddpm", "", False, 420, True), ("prevx_ddim", "ddim50", True, 17, False)):
+        betas = rgd.get_named_beta_schedule("linear", 1000)
+        d = rrs.SpacedDiffusion(use_timesteps=rrs.space_timesteps(1000, rs or [1000]), betas=betas, model_mean_type=rgd.ModelMeanType.PREVIOUS_X,
+                                model_var_type=rgd.ModelVarType.FIXED_LARGE, loss_type=rgd.LossType.MSE, rescale_timesteps=False)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        kw = dict(clip_denoised=clip, model_kwargs={"y": torch.from_numpy(y)})
+        r = (d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), eta=1.0, **kw) if ddim
+             else d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), **kw))
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.clip": np.array(int(clip)), f"{tag}.sample": r["sample"].numpy(),
+                    f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
+        print(f"    {tag}: sample range {r['sample'].min().item():.3f} .. {r['sample'].max().item():.3f}")
+
+    # ---- (c) + (d) learn_sigma=True
+    arch = dict(SM, out_ch=8)
+    sd8 = synth.dit_state_dict(21, **arch)
+    for k in ("final_layer.linear.weight", "final_layer.linear.bias"):      # a wide spread of variance values (and a small t below):
+        sd8[k] = sd8[k] * F32(LSIG_FINAL_GAIN)                              # the noise scale must vary visibly per element
+    m8 = rdit.DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6, num_classes=3, learn_sigma=True)
+    m8.load_state_dict(tsd(sd8), strict=True)
+    m8.eval()
+    mf8 = ref_model_fn(m8, 3, True)
+    cm, csd = ref_cls(CLS2, 4)
+    n = 4
+    tgt = {"pitch_hist": np.tile(np.array([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], dtype=F32), (B, 1)),
+           "note_density": np.tile(np.array([3.] * 8 + [3.] * 8, dtype=F32), (B, 1))}
+    scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
+    g = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    mk = {"y": torch.from_numpy(y), "rule": {k: torch.from_numpy(v) for k, v in tgt.items()}}
+    raised = {}
+    d = rsu.create_diffusion(learn_sigma=True, diffusion_steps=1000, noise_schedule="linear", timestep_respacing="", use_kl=False,
+                             predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+    d.t_end = 0
+    t = np.full((B,), 3, dtype=np.int64)
+    nz = rng.randn(n, B, 4, 128, 16).astype(F32)
+    NQ.push(nz)
+    try:
+        d.p_sample(mf8, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, model_kwargs=mk, embed_model=vae, scale_factor=1.2465,
+                   guidance_kwargs=g, scg_kwargs=scg)
+        raised["scg_learned"] = "ok"
+    except Exception as e:
+        import traceback
+        raised["scg_learned"] = f"{type(e).__name__} in {traceback.extract_tb(e.__traceback__)[-1].name}"
+    NQ.q.clear()
+    d250 = rsu.create_diffusion(learn_sigma=True, diffusion_steps=1000, noise_schedule="linear", timestep_respacing="250", use_kl=False,
+                                predict_xstart=False, rescale_timesteps=False, rescale_learned_sigmas=False)
+    d250.t_end = 0
+    cond = partial(rcf.composite_nn_zt, fns=["nn_z0_mse_dummy"], classifier_scales=[1.], classifiers=[cm], rule_names=["note_density"])
+    torch.set_grad_enabled(True)
+    NQ.push(rng.randn(B, 4, 128, 16).astype(F32))
+    try:
+        d250.p_sample(mf8, torch.from_numpy(x), torch.from_numpy(np.full((B,), 100, dtype=np.int64)), clip_denoised=False, cond_fn=cond,
+                      guidance_kwargs=SimpleNamespace(schedule=False, method="dps", step_size=1.5, nn=True, vae=False),
+                      model_kwargs={"y": torch.from_numpy(y), "rule": {"note_density": torch.from_numpy(tgt["note_density"])}})
+        raised["dps_learned"] = "ok"
+    except Exception as e:
+        import traceback
+        raised["dps_learned"] = f"{type(e).__name__} in {traceback.extract_tb(e.__traceback__)[-1].name}"
+    torch.set_grad_enabled(False)
+    NQ.q.clear()
+    print("    reference on learn_sigma=True:", raised)
+    out["reference_raises"] = np.array(json.dumps(raised, sort_keys=True))
+
+    def mf8_split(xx, tt, **kw):                       # 2C channels for the x_t forward (p_mean_variance splits them), eps half for the candidates
+        o = mf8(xx, tt, **kw)
+        return o if xx.shape[0] == B else o[:, :4]
+    pm = d.p_mean_variance(mf8, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, model_kwargs=mk)
+    NQ.push(nz)
+    r = d.p_sample(mf8_split, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, model_kwargs=mk, embed_model=vae,
+                   scale_factor=1.2465, guidance_kwargs=g, scg_kwargs=scg)
+    mean, gco = pm["mean"].numpy(), np.exp(F32(0.5) * pm["log_variance"].numpy())
+    cands = mean[None] + gco[None] * nz
+    ref_ind = np.array([int(np.argmin([np.abs(cands[k, b] - r["sample"].numpy()[b]).max() for k in range(n)])) for b in range(B)])
+    resid = max(float(np.abs(cands[ref_ind[b], b] - r["sample"].numpy()[b]).max()) for b in range(B))
+    print(f"    learned-variance SCG: reference picked {ref_ind}, residual {resid:.2e}; g range {gco.min():.4f} .. {gco.max():.4f}")
+    assert resid < 1e-5 and gco.max() / gco.min() > 1.05, "the noise scale must really vary per element"
+    out.update({"lsig.seed": np.array(21), "lsig.final_gain": np.array(LSIG_FINAL_GAIN), "lsig.t": t, "lsig.noise": nz, "lsig.mean": mean, "lsig.g": gco, "lsig.sample": r["sample"].numpy(),
+                "lsig.max_ind": ref_ind, "lsig.target.pitch_hist": tgt["pitch_hist"], "lsig.target.note_density": tgt["note_density"]})
+    save("round3", **out)
 
 
 def g_configs():
@@ -1252,7 +1405,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1263,7 +1416,7 @@ if __name__ == "__main__":
         g_dit("xl_d28", XL28, 1)
     if "cls" in which:
         g_cls()
-    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e"}:
+    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e", "round3"}:
         vae = g_vae() if "vae" in which else RefVAE(2)
     if "rules" in which:
         g_rules()
@@ -1281,6 +1434,8 @@ if __name__ == "__main__":
         g_hooks()
     if "cfgdps" in which:
         g_cfgdps()
+    if "round3" in which:
+        g_round3(vae)
     if "learned" in which:
         g_learned()
     if "configs" in which:

@@ -46,8 +46,16 @@ COMMON = ["--model", "DiTRotary_B_8", "--image_size", "128", "16", "--in_channel
 def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
     monkeypatch.chdir(tmp_path)
     cli = _cli()
+    has_chord = "chord" in open(os.path.join(CFG, cfg)).read()
+    if has_chord:                                 # a chord config without an analyser is an error unless the run opts out of those rules
+        with pytest.raises(RuntimeError, match="skip_chord_rules"):
+            cli.main(["--config_path", os.path.join(CFG, cfg), "--batch_size", "2", "--num_samples", "2"] + COMMON + extra)
+        extra = extra + ["--skip_chord_rules", "True"]
     res = cli.main(["--config_path", os.path.join(CFG, cfg), "--batch_size", "2", "--num_samples", "2"] + COMMON + extra)
-    out_dir = os.path.join("loggings", cli.output_dir_for(os.path.join(CFG, cfg), 1))
+    out_dir = os.path.join("loggings", cli.output_dir_for(os.path.join(CFG, cfg), 1)) + ("_nochord" if has_chord else "")
+    import json
+    meta = json.load(open(os.path.join(out_dir, "run_metadata.json")))
+    assert bool(meta["dropped_rules"]) == has_chord and meta["synthetic_weights"] is True
     df = pd.read_csv(os.path.join(out_dir, "results.csv"))
     assert len(df) == 2 and len(res) == 2
     for r in rules:
@@ -59,6 +67,44 @@ def test_sample_rule_cli(tmp_path, monkeypatch, cfg, extra, rules):
     roll = np.load(os.path.join(out_dir, rolls[0]))
     T = 4096 if "long" in cfg else 1024
     assert roll.shape == (3, 128, T) and roll.dtype == np.uint8 and roll.max() <= 127
+
+
+def test_sample_rule_cli_takes_null_targets_from_a_dataset_batch_file(tmp_path, monkeypatch):
+    """`target_rules: Null` (every cond_table/** YAML of the reference; its targets are the rules of a dataset batch, reference
+    scripts/sample_rule.py:147-168): --targets_npz hands that batch over (`gt` rolls) and the CLI extracts every rule with
+    _extract_rule like the reference; vertical_nd / horizontal_nd collapse into note_density.  Also the one-array-per-rule form."""
+    import torch
+    monkeypatch.chdir(tmp_path)
+    cli = _cli()
+    cfg = os.path.join(str(tmp_path), "configs", "cond_table", "all", "null_targets.yml")
+    os.makedirs(os.path.dirname(cfg))
+    src = open(os.path.join(CFG, "cond_table", "no_guidance", "nd.yml")).read()
+    text = src[:src.index("target_rules:")] + "target_rules: {pitch_hist: Null, vertical_nd: Null, horizontal_nd: Null}\n"
+    open(cfg, "w").write(text)
+    rng = np.random.RandomState(4)
+    gt = -np.ones((2, 3, 128, 1024), dtype=np.float32)
+    for b in range(2):
+        for _ in range(40):
+            pch, st, ln = rng.randint(30, 100), rng.randint(0, 1000), rng.randint(8, 100)
+            gt[b, 0, pch, st:st + ln] = rng.uniform(-0.2, 1.0)
+            gt[b, 1, pch, st] = 1.0
+    npz = os.path.join(str(tmp_path), "batch.npz")
+    np.savez(npz, gt=gt)
+    args = ["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "24"] + COMMON
+    with pytest.raises(NotImplementedError, match="targets_npz"):
+        cli.main(args)
+    res = cli.main(args + ["--targets_npz", npz])
+    want = {k: cli._extract_rule(k, torch.from_numpy(gt).cuda()).cpu().numpy() for k in ("pitch_hist", "note_density")}
+    for k, w in want.items():
+        got = np.array([np.asarray(v, dtype=np.float64) for v in res[f"{k}.target_rule"]])
+        assert got.shape == w.shape and np.allclose(got, w, atol=1e-6), k
+        assert np.isfinite(res[f"{k}.loss"]).all()
+    assert not np.allclose(want["pitch_hist"][0], want["pitch_hist"][1])          # per-sample targets, not one broadcast row
+    npz2 = os.path.join(str(tmp_path), "rules.npz")
+    np.savez(npz2, pitch_hist=want["pitch_hist"], note_density=want["note_density"][0])
+    res2 = cli.main(args + ["--targets_npz", npz2])
+    got = np.array([np.asarray(v, dtype=np.float64) for v in res2["note_density.target_rule"]])
+    assert np.allclose(got, np.stack([want["note_density"][0]] * 2), atol=1e-6)
 
 
 def test_edit_cli_keeps_the_fixed_part_and_rewrites_the_excerpt(tmp_path, monkeypatch):
@@ -74,10 +120,15 @@ def test_edit_cli_keeps_the_fixed_part_and_rewrites_the_excerpt(tmp_path, monkey
     cfg = os.path.join(str(tmp_path), "configs", "edit", "nd_short.yml")
     os.makedirs(os.path.dirname(cfg))
     open(cfg, "w").write(open(cfg_src).read().replace("noise_level: 500", "noise_level: 12"))
-    res, sample = cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "24"] + COMMON)
+    with pytest.raises(RuntimeError, match="allow_synthetic_source"):          # `source: dataset` is never replaced silently
+        cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "24"] + COMMON)
+    res, sample = cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "24",
+                            "--allow_synthetic_source", "True"] + COMMON)
     assert len(res) == 2 and {"note_density.loss", "note_density.orig_rule"} <= set(res.columns)
     assert np.isfinite(res["note_density.loss"]).all()
-    out_dir = os.path.join("loggings", "edit_demo", "edit", "nd_short_cls_1")
+    out_dir = os.path.join("loggings", "edit_demo", "edit", "nd_short_cls_1_synthsrc")
+    import json
+    assert json.load(open(os.path.join(out_dir, "run_metadata.json")))["source_substituted_by_synthetic"] is True
     assert os.path.exists(os.path.join(out_dir, "results.csv")) and os.path.exists(os.path.join(out_dir, "gt", "sample_0_y_1.npy"))
     assert sample.shape == (2, 128, 1024, 3) and sample.dtype == torch.uint8
 

