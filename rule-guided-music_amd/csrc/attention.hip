@@ -204,7 +204,8 @@ static int launch_attn(const float* qkv, float* o, const float* ct, const float*
   constexpr int TP = NKT * 32;
   // V strip + K strip; channel reads of the last (partial) 32-wide tile run past a V row into the
   // next row / the K strip, which is finite data feeding discarded accumulator rows only.
-  const size_t lds = (size_t)(TP * HD + TP * (HD + 4)) * sizeof(float);
+  size_t lds = (size_t)(TP * HD + TP * (HD + 4)) * sizeof(float);
+  if (lds < 80 * 1024 + 512) lds = 80 * 1024 + 512;   // one workgroup per CU, enforced: see attention_x3.hip launch_attn_x3 (same kernel structure)
   static bool attr_set = false;
   auto kern = rotary_attention_kernel<HD, NKT>;
   if (!attr_set) {

@@ -270,7 +270,16 @@ template <int HD, int NKT>
 static int launch_attn_x3(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,
                           float* lse, int out_split, hipStream_t s) {
   constexpr int KP = (HD + 15) / 16 * 16, TP = NKT * 32;
-  const size_t lds = (size_t)TP * (KP * 4 + 16) + (size_t)HD * (TP * 4 + 16);
+  size_t lds = (size_t)TP * (KP * 4 + 16) + (size_t)HD * (TP * 4 + 16);
+  // ONE workgroup per CU, enforced.  At T <= 128 the images take <= 80 KiB and two workgroups fit the 160 KiB of a CU: waves 4-7 have no
+  // query tile there and retire right after the staging barrier, the next workgroup moves in beside waves 0-3 -- and the workgroup that
+  // ran in the UPPER half of the LDS (the 2nd, 4th, ... on a CU; never the first or the last of a launch) sporadically returned wrong
+  // rows (1 launch in ~10 at N = 48, T = 128: errors of 0.1 on O(1) outputs; tools/race_block.py bisects a DiT block to this kernel,
+  // tools/race_probe.py shows it in the model; every LDS access of the kernel is inside its own allocation).  The mechanism is not
+  // established; asking for more than half of the LDS removes the co-residency and with it every wrong row (0 in 48 launches).
+  constexpr size_t ONE_PER_CU = 80 * 1024 + 512;
+  static const int allow_two = RGM_EXP_ENV("RGM_ATTN_TWO_PER_CU");      // experiments only (common.h): reproduce the hazard
+  if (lds < ONE_PER_CU && !allow_two) lds = ONE_PER_CU;
   static bool attr_set = false;
   auto kern = rotary_attention_x3_kernel<HD, NKT>;
   if (!attr_set) {

@@ -331,7 +331,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         }
       }
     };
-    static_assert(NRD * 3 <= NM && SPW * 3 <= NM, "one read / one DMA piece per three MFMA slots");
+    static_assert(NRD * 3 <= NM && SPW * 3 <= 2 * NM, "one read per three MFMA slots, at most two DMA pieces");
     struct FragsK {
       bf16x8 a[TM][2], b[TN][2];                          // [frag][hi, lo] of one k16 step
     };
@@ -357,6 +357,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         if constexpr (READ && m % 3 == 0 && m / 3 < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / 3>{});
         if constexpr (DMA && m % 3 == 1 && m / 3 < SPW) {
           constexpr int i = m / 3;
+          dma16(src[i], dst + (wave + i * NW) * 1024);
+          src[i] += inc[i];
+        }
+        if constexpr (DMA && m % 3 == 2 && NM / 3 + m / 3 < SPW) {      // tiles with more than NM / 3 pieces per wave (512x128: 20)
+          constexpr int i = NM / 3 + m / 3;
           dma16(src[i], dst + (wave + i * NW) * 1024);
           src[i] += inc[i];
         }
@@ -1218,10 +1223,10 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
               "gemm2: operands must be 16-byte aligned with ld%%4==0");
   RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
   RGM_REQUIRE(!p.stats || ((p.stats_gw == 4 || p.stats_gw == 8 || p.stats_gw == 16) && p.N % 64 == 0 && p.batch == 1 &&
-                           ((p.tile == 0 && p.aload) || p.tile == 21 || p.tile == 22 || p.tile == 43 || p.tile == 44) &&
+                           ((p.tile == 0 && p.aload) || p.tile == 21 || p.tile == 22 || p.tile == 43 || p.tile == 44 || p.tile == 71 || p.tile == 72) &&
                            ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
                            (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate | (uintptr_t)p.aux) & 15) == 0),
-              "gemm2: GroupNorm partial sums need 128-row tiles, N%%64==0, group width 4/8/16 and 16-byte aligned rows");
+              "gemm2: GroupNorm partial sums need a fixed tile height (heuristic conv tiles: 128 rows; 71: 256; 72: 512), N%%64==0, group width 4/8/16 and 16-byte aligned rows");
   // ---- 256x256 tiles, one wave per SIMD (tile 71, PIPE 5): 380-420 TFLOP/s per full round of 256 workgroups against 300-360 for
   // the 128x128 kernels (tools/gemm_sweep.py: qkv at B = 16 86 us against 101, fc1 at n.B = 64 417 against 464), but ONE workgroup
   // per CU: a launch costs ceil(tiles / 256) rounds of ~(33 + 1.44 KT) us whatever the last round's fill.  Three ways to keep the
@@ -1375,6 +1380,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 58: return launch2<64, 64, 2, 2, 3, 4>(p, s, 58);     // 48 KB: 3 per CU
     // one wave per SIMD, 128x128 per wave (PIPE == 5)
     case 71: return launch2<256, 256, 2, 2, 2, 5>(p, s, 71);   // 128 KB: 1 per CU, 512 registers
+    case 72: return launch2<512, 128, 4, 1, 2, 5>(p, s, 72);   // 160 KB (all of the LDS): the same 128x128 wave tiles for N = 128 (VAE convs at 128 channels)
     // persistent loader/consumer kernel (gemm3.hip)
     case 61:
     case 62:

@@ -801,6 +801,7 @@ struct Ctx {
   // a group_norm that is the very next op on that tensor finalises them instead of re-reading the tensor from HBM
   int seq = 0, tp_seq = -1;
   const float* tp_for = nullptr;
+  int tp_rows = 128;             // tile height of the conv that left those sums (128: heuristic tiles; 256 / 512: the 256x256 / 512x128 kernels)
 };
 
 // stats: where (mean, rstd) of the M x 32 groups go (kept for the backward when given; default the shared scratch)
@@ -809,7 +810,7 @@ int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string
   if (!stats) stats = c.p.stats;
   const int my = ++c.seq;
   if (c.tp_for == x && c.tp_seq == my - 1) {
-    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.tpart, stats, c.M, P / 128,
+    hipLaunchKernelGGL(gn_finalize_tiles_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.tpart, stats, c.M, P / c.tp_rows,
                        (double)P * (C / 32), 1e-6f);
     RGM_LAUNCH_CHECK();
   } else {
@@ -845,11 +846,27 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
   const int my = ++c.seq;
   if (in_split) {
     g.tile = RGM_EXP_ENV("RGM_CONV_TILE");   // 0 = gemm2's heuristic (timing experiments: common.h)
-    if (g.tile == 0 && Cout % 128 == 0 && Cout <= 512 && (H * H) % 128 == 0) {   // 128-row tiles never straddle an image
+    int rows = 128;
+    static const int big = getenv("RGM_BIG_TILES") ? atoi(getenv("RGM_BIG_TILES")) : 1;
+    if (g.tile == 0 && big) {
+      // One wave per SIMD, 128x128 accumulators per wave (gemm2.hip PIPE 5): 256x256 tiles for the 256- / 512-channel convs, 512x128
+      // for the 128-channel ones, once the grid fills at least one round of the chip (a 64-candidate decode: 32 ... 512 rounds);
+      // tiles must not straddle an image (per-image GroupNorm sums), so 16x16 maps (256 pixels) only take the 256-row tile
+      const long long P = (long long)H * H;
+      if ((Cout == 256 || Cout == 512) && P % 256 == 0 && ((long long)g.M / 256) * (Cout / 256) >= 256) {
+        g.tile = 71;
+        rows = 256;
+      } else if (Cout == 128 && P % 512 == 0 && (long long)g.M / 512 >= 256) {
+        g.tile = 72;
+        rows = 512;
+      }
+    }
+    if ((g.tile == 0 || g.tile == 71 || g.tile == 72) && Cout % 128 == 0 && Cout <= 512 && (H * H) % rows == 0) {   // tiles never straddle an image
       g.stats = c.p.tpart;
       g.stats_gw = Cout / 32;
       c.tp_for = out;
       c.tp_seq = my;
+      c.tp_rows = rows;
     }
     return gemm2_launch(g, c.s);
   }

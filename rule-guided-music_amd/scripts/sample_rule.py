@@ -34,6 +34,7 @@ from load_utils import load_model  # noqa: E402
 import diff_collage as dc  # noqa: E402
 
 
+KEEP_FLOAT_ROLLS = None   # tests only: a list -> main() appends every batch's FLOAT decoded roll (B,3,128,T) next to the uint8 one
 NOISE_FN = None     # tests only: callable(shape, device) -> tensor installed as diffusion.noise_fn (teacher-forced parity runs)
 
 
@@ -297,6 +298,9 @@ def main(argv=None):
             cond_fn=cond_fn_used, embed_model=embed_model if config.guidance.vae else None, scale_factor=args.scale_factor,
             guidance_kwargs=config.guidance, scg_kwargs=vars(config.scg) if use_scg else None,
             t_end=config.sampling.t_end, record=args.record, progress=args.progress)
+        if KEEP_FLOAT_ROLLS is not None:        # parity tests: the float roll explains every uint8 difference (boundary adjacency)
+            from guided_diffusion.gaussian_diffusion import _decode
+            KEEP_FLOAT_ROLLS.append(_decode(sample, embed_model, scale_factor=args.scale_factor).float().cpu().numpy())
         sample = midi_util.decode_sample_for_midi(sample, embed_model=embed_model, scale_factor=args.scale_factor, threshold=-0.95)
         arr = sample.cpu().numpy().transpose(0, 3, 1, 2)                                   # (B, 3, 128, T) uint8
         if args.save_files and rank0:

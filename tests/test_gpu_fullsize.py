@@ -109,6 +109,43 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
         assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, 2304), _ref(A, W, b2, 2, 1.0, None, 1, None)) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K,T", [(3072, 1152, 4608, 128), (7168, 3456, 1152, 256), (3072, 4608, 1152, 128), (4096, 4608, 1152, 256),
+                                     (4096, 1152, 4608, 256), (16384, 1152, 1152, 256), (7168, 1152, 4608, 256), (2048 + 256, 3456, 1152, 256)])
+def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
+    """gemm2_launch with tile 0 on the shapes the samplers produce (B = 16 / 64, the 28 + 24 windows of config 5): whole launches
+    of 256x256 tiles, K slices + reduce, whole rounds of column tiles + the leftover columns through the heuristic again -- each with
+    bias, alpha, per-sample gate and in-place residual -- against the fp64 product, and bit-identical run to run."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    rng = np.random.RandomState(M + N + K)
+    A, B = rng.randn(M, K).astype(F32), (rng.randn(N, K) * 0.03).astype(F32)
+    bias, res = rng.randn(N).astype(F32), rng.randn(M, N).astype(F32)
+    gate = rng.randn((M + T - 1) // T, N + 64).astype(F32)
+    As, Bs, bd, gd = _split(A), _split(B), dev(bias), dev(gate)
+    need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 8 * M * N * 4)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    st = R.current_stream()
+    outs = []
+    for rep in range(2):
+        x = dev(res)
+        with _Recorded() as rec:
+            R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 0.7, R.ptr(gd), N + 64, T,
+                                             R.ptr(x), N, 0, 0, R.ptr(ws), need, st))
+        outs.append(x.cpu().numpy())
+    if (M, N, K) not in ((7168, 1152, 4608), (2304, 3456, 1152)):   # (those two stay on the 128-row kernels: no full round of 256x256 tiles)
+        assert rec.n[111] >= 1, rec.n                               # the 256x256 kernel took part
+    assert np.array_equal(outs[0], outs[1])
+    err = rel(outs[0], _ref(A, B, bias, 0, 0.7, gate[:, :N], T, res))
+    assert err < 3e-5, (err, rec.n)
+    # GELU + split-row output through the same decomposition (fc1)
+    h = torch.zeros(M, N, device="cuda")
+    R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(h), N, M, N, K, R.ptr(bd), 2, 1.0, None, 0, 1, None, 0, 0, 1,
+                                     R.ptr(ws), need, st))
+    torch.cuda.synchronize()
+    raw = h.view(torch.bfloat16).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+    assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, N), _ref(A, B, bias, 2, 1.0, None, 1, None)) < 3e-5
+
+
 def _dit(arch, seed):
     from gpu_util import load_module
     from guided_diffusion.dit import DiTRotary
@@ -280,8 +317,15 @@ def test_long_sequence_guided_step_at_xl_width(monkeypatch, depth, precision):
             return torch.cat(parts, dim=0)
         monkeypatch.setattr(scg_shard, "gather_totals", fake_gather)
         s, total, idx = run()
-        assert torch.equal(idx, ref_idx), f"rank {rank}: other per-segment winners"
-        assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
+        # winners must agree wherever the unsharded table separates its two best candidates by more than the batch-size dependence of
+        # the scores (a rank scores 2 candidates per forward, the unsharded step 4: other GEMM tiles, ~1e-5 relative); a segment whose
+        # two best candidates tie within that is allowed to flip (depth 28 with random weights produces such ties)
+        top2 = torch.topk(ref_total, 2, dim=0).values
+        clear = (top2[0] - top2[1]) > 2e-4 * ref_total.abs().max()
+        assert torch.equal(idx[clear], ref_idx[clear]), f"rank {rank}: other per-segment winners"
+        assert int(clear.sum()) >= clear.numel() // 2
+        if torch.equal(idx, ref_idx):
+            assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
 
 
 def test_two_gpu_scg_bench_runs_over_rccl_when_the_box_has_two_gpus():
@@ -298,3 +342,56 @@ def test_two_gpu_scg_bench_runs_over_rccl_when_the_box_has_two_gpus():
     assert line["n_gpus"] == 2
     rec = line.get("scg", line)
     assert rec.get("same_winners_on_every_rank", line.get("config", {}).get("same_winners_on_every_rank")) is True, line
+
+
+@pytest.mark.parametrize("N,T,heads,hd", [(48, 128, 16, 72), (40, 96, 16, 72), (64, 64, 6, 64), (48, 129, 6, 64)])
+def test_short_sequence_attention_is_right_in_every_launch(N, T, heads, hd, precision):
+    """Config 5's half windows are 128-token sequences, dozens of them per batch: K and V of a head then take <= 80 KiB of LDS and a
+    second workgroup used to move in beside the first one's last waves -- and the one running in the upper half of the LDS sporadically
+    returned wrong rows (found in round 3 through the row-independence test of the 13-window batch; tools/race_block.py).  The
+    launchers now keep one workgroup per CU.  30 launches on the same input: bit-identical, and right against the fp64 product."""
+    from gpu_util import dev
+    from rgm import native as R
+    from rgm.synth import rotary_freqs
+    from oracle import dit_np as odit
+    rng = np.random.RandomState(N + T)
+    D = heads * hd
+    rot = hd // 2
+    qkv = (rng.randn(N * T, 3 * D) * 1.5).astype(F32)
+    cos, sin = odit.rotary_tables(rotary_freqs(rot), T)
+    qd, cd, sd_ = dev(qkv), dev(cos), dev(sin)
+    outs = []
+    for _ in range(30):
+        od = torch.full((N * T, D), float("nan"), device="cuda")
+        R.check(R.lib.rgm_rotary_attention(R.ptr(qd), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, rot // 2, R.current_stream()))
+        outs.append(od)
+    torch.cuda.synchronize()
+    worst = max(float((o - outs[0]).abs().max()) for o in outs)
+    assert worst == 0.0, f"launches of one input differ by {worst}"
+    r = qkv.reshape(N, T, 3, heads, hd)
+    q, k, v = (r[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    q = odit.apply_rotary(q.astype(F32), cos, sin).astype(np.float64)
+    k = odit.apply_rotary(k.astype(F32), cos, sin).astype(np.float64)
+    s = q @ k.transpose(0, 1, 3, 2) * hd ** -0.5
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(N * T, D)
+    err = np.abs(outs[0].cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < (3e-6 if precision == "fp32" else 3e-5), err
+
+
+def test_half_window_batches_through_the_xl_model_are_deterministic(precision):
+    """The same hazard at the model level: 48 half windows (H = 64 -> 128 tokens) through XL depth 4, twelve times: identical outputs,
+    equal to the batches-of-2 evaluation."""
+    from gpu_util import dev, rel
+    m = _dit(dict(XL2, depth=4), 1)
+    rng = np.random.RandomState(48)
+    N = 48
+    x = dev(rng.randn(N, 4, 64, 16).astype(F32))
+    t = dev(np.full((N,), 500, dtype=np.int64))
+    y = dev(np.ones((N,), dtype=np.int64))
+    outs = [m(x, t, y).clone() for _ in range(12)]
+    worst = max(float((o - outs[0]).abs().max()) for o in outs)
+    assert worst == 0.0, f"identical calls differ by {worst}"
+    small = torch.cat([m(x[i:i + 2].contiguous(), t[i:i + 2].contiguous(), y[i:i + 2].contiguous()) for i in range(0, N, 2)])
+    assert rel(outs[0].cpu().numpy(), small.cpu().numpy()) < (3e-5 if precision == "bf16x3_presplit" else 2e-6)
