@@ -249,7 +249,7 @@ def roofline_pass(work, steps=2):
         n, ms, fl = C.c_int(), C.c_double(), C.c_double()
         R.check(R.lib.rgm_prof_report(kid, C.byref(n), C.byref(ms), C.byref(fl)))
         if n.value:
-            rows[kid] = dict(launches=n.value, ms=ms.value, flops=fl.value)
+            rows[kid] = dict(launches=n.value, ms=ms.value, flops=fl.value, bytes=float(R.lib.rgm_prof_bytes(kid)) if kid >= 40 else 0.0)
     R.check(R.lib.rgm_prof_reset())
     # kernel ids (csrc/gemm.hip, gemm2.hip): < 40 gemm_kernel<BM,BN,WM,WN,ALOAD,PREC> = tile + 10*ALOAD + 20*PREC;
     # >= 40 gemm2_kernel<BM,BN,WM,WN,ALOAD,NSTAGE,0,PIPE> = 40 + tile + 10*ALOAD (tiles: gemm2_launch)
@@ -289,8 +289,54 @@ def roofline_pass(work, steps=2):
                           else "f32-input MFMA v_mfma_f32_32x32x2_f32"),
             "avg_launch_us": round(1e3 * r["ms"] / r["launches"], 2), "launches_per_step": r["launches"] // steps,
             "gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3),
+            "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]) if r.get("bytes") else None,
             "share_of_gemm_time": round(r["ms"] / all_ms, 3),
             "all_gemm_tflops": round(sum(v["flops"] for v in rows.values()) / (all_ms * 1e-3) / 1e12, 2)}
+
+
+def measure_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` measured IN SITU: this same workload re-run as a child under `rocprofv3 --pmc` (FETCH_SIZE and
+    WRITE_SIZE in SEPARATE passes, --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), every dispatch of the
+    kernel inside the sampling steps averaged -- all the shapes it runs on, weights cold as in the step -- with the guide's gfx950
+    corrections (counters in KiB; FETCH_SIZE counts half of a wide coalesced read stream).  -> (bytes per launch, detail) or (None, why)."""
+    import glob
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    want = re.sub(r"\s+", "", kernel)
+    out = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="rgm_pmc_", dir="/tmp")
+        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
+               "--workload", args.workload, "--precision", args.precision, "--steps", "3", "--warmup", "1"]
+        if args.batch:
+            cmd += ["--batch", str(args.batch)]
+        try:
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=420, check=True)
+            dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
+            cur = sqlite3.connect(dbs[0]).cursor()
+            rows = cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+        except Exception as e:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"{counter} pass failed: {e!r}"
+        shutil.rmtree(d, ignore_errors=True)
+        vals = [v for n, v in rows if want in re.sub(r"\s+", "", n)]
+        if not vals:
+            return None, f"{counter}: no dispatch of {kernel} in the profiled run"
+        out[counter] = (float(np.mean(vals)), len(vals), float(np.min(vals)), float(np.max(vals)))
+    fetch = 2.0 * out["FETCH_SIZE"][0] * 1024.0
+    write = out["WRITE_SIZE"][0] * 1024.0
+    detail = {"method": "rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) over this workload, all in-situ launches of the kernel",
+              "fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "launches_sampled": out["FETCH_SIZE"][1],
+              "fetch_kib_min_max": [round(out["FETCH_SIZE"][2]), round(out["FETCH_SIZE"][3])],
+              "formula": "2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)"}
+    return round(fetch + write), detail
 
 
 def cpu_baseline(work):
@@ -477,6 +523,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip fp32_exact, scg, uint8_flips, cpu_baseline)")
     ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)   # internal: the profiled child of measure_traffic
+    ap.add_argument("--no-traffic", action="store_true", help="skip the in-situ rocprofv3 --pmc passes (roofline.traffic from profiles/traffic.json)")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="--workload scg on ONE GPU: time the per-rank work of an R-GPU run (this process scores candidates "
                          "[0, n/R) like rank 0 would, the all-gather is a local stand-in): an estimate of the sharded step "
@@ -530,6 +578,11 @@ def main():
         work.d.batch_shard = False            # the headline runs one independent chain per GPU (weak scaling): nothing to shard
     for _ in range(args.warmup):
         work.step()
+    if args.traffic_child:                                       # under rocprofv3 --pmc: just the steps, no timing, no JSON
+        for _ in range(args.steps):
+            work.step()
+        torch.cuda.synchronize()
+        return
     regions = [time_steps(work, args.steps, world, dist) for _ in range(max(1, args.repeats))]
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     dt, gpu_ms = regions[order[len(order) // 2]]
@@ -539,6 +592,16 @@ def main():
         log("roofline pass failed:", repr(e))
         roof = None
 
+    if roof is not None and rank == 0 and world == 1 and not args.no_traffic and not args.no_extras and args.simulate_ranks <= 1:
+        try:
+            tb, detail = measure_traffic(roof["kernel"], args)
+        except Exception as e:
+            tb, detail = None, repr(e)
+        if tb is not None:
+            roof["traffic"], roof["traffic_detail"] = tb, detail
+            roof["traffic_over_algorithmic"] = round(tb / max(1.0, roof.get("algorithmic_bytes_per_launch", 0) or 1.0), 3) if roof.get("algorithmic_bytes_per_launch") else None
+        else:
+            roof["traffic_detail"] = {"method": "profiles/traffic.json lookup (in-situ measurement unavailable: %s)" % detail}
     extras = {}
     if args.workload == "c2" and not args.no_extras and args.simulate_ranks <= 1:
         def attempt(name, fn):

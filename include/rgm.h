@@ -307,6 +307,8 @@ int rgm_rotary_attention_bwd(const float* qkv, const float* o, const float* d_o,
 int rgm_prof_enable(int on);
 int rgm_prof_reset(void);
 int rgm_prof_report(int kernel, int* launches, double* total_ms, double* total_flops);
+/* algorithmic HBM bytes (every operand read once, the output written once) summed over the recorded launches of a pre-split kernel id */
+double rgm_prof_bytes(int kernel);
 /* per-launch records of the pre-split GEMM kernels in launch order (kernel id, milliseconds, algorithmic FLOPs); returns the count */
 int rgm_prof_dump(int cap, int* ids, double* ms, double* flops);
 int rgm_gemm2_dbg(int mode, long long* out64);

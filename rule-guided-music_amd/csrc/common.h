@@ -137,6 +137,9 @@ struct GemmParams {
   int H = 0, W = 0, Cin = 0, logH = 0, logW = 0, ups = 0;
   // tile override for experiments: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
   int tile = 0;
+  // gemm2 raster: row-tiles per column sweep of the XCD-contiguous grouped raster (0 = 8).  The one-wave-per-SIMD kernels set it to
+  // ~sqrt(tiles per XCD): an XCD's tiles then form a near-square block and its L2 fetches the fewest operand panels
+  int raster_group = 0;
   // arithmetic: -1 library default (rgm_set_gemm_precision), 0 fp32 MFMA, 1 bf16x3 split
   int prec = -1;
   // gemm2 (pre-split operands): write C in split-row format (N bf16 hi | N bf16 lo per row) for the next GEMM
@@ -171,6 +174,7 @@ int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_
 void gemm2_prof(bool on);
 void gemm2_prof_reset();
 int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total_flops);
+double gemm2_prof_bytes(int kernel);
 
 // elementwise / reductions (elementwise.hip)
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,

@@ -18,6 +18,7 @@
 // SOURCE address (the LDS image of a DMA is lane-linear).  3-stage LDS ring, DMA two K-tiles ahead,
 // counted `s_waitcnt vmcnt(N)` + one raw `s_barrier` per K-tile (never __syncthreads: it would drain the DMA queue).
 // Out-of-range rows (M / N tails, conv zero padding) read a zero page, so the kernel has no divergent loads.
+#include <math.h>
 #include <stdlib.h>
 #include <stdint.h>
 #include <vector>
@@ -55,7 +56,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   const int nb = tiles_m * tiles_n;
   const int xcd = bid & 7, loc = bid >> 3, q = nb >> 3, r = nb & 7;
   const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  constexpr int GROUP = 8;
+  const int GROUP = (PIPE == 5 && p.raster_group > 0) ? p.raster_group : 8;
   const int per_group = GROUP * tiles_n;
   const int grp = sid / per_group;
   const int first_m = grp * GROUP;
@@ -1045,6 +1046,7 @@ struct Prof2 {
   hipEvent_t a, b;
   int tile;
   double flops;
+  double bytes;     // algorithmic HBM bytes of the launch: every operand read once, the output written once
 };
 static bool g2_prof_on = false;
 static std::vector<Prof2> g2_prof;
@@ -1072,12 +1074,26 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     }
   }
   dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64 * (PIPE == 4 ? 2 : 1));
+  GemmParams pr = p;
+  if (PIPE == 5 && p.raster_group == 0) {
+    // every XCD computes tm * tn / 8 contiguous tiles of the raster: a gm x gn block of them reads gm A panels and gn B panels
+    // through that XCD's L2 -- fewest for gm ~ gn (weighted by the tile sides).  In-situ PMC, C2 step: 2.9x the algorithmic bytes
+    // on the K slices of fc2 with the fixed 8-row sweep (an XCD's 10 tiles = 8 rows x 1.25 columns)
+    const double per_xcd = (double)tm * tn / 8.0;
+    int g = (int)(sqrt(per_xcd * (double)BN / (double)BM) + 0.5);
+    static const int fixed = RGM_EXP_ENV("RGM_RASTER_GROUP");       // experiments (common.h): a fixed sweep height for A/B runs
+    if (fixed > 0) g = fixed;
+    pr.raster_group = g < 1 ? 1 : (g > tm ? tm : g);
+  }
   Prof2 rec{};
   if (g2_prof_on) {
     RGM_CHECK_HIP(hipEventCreate(&rec.a));
     RGM_CHECK_HIP(hipEventCreate(&rec.b));
     rec.tile = 40 + tile_id + (p.aload ? 10 : 0);
     rec.flops = 2.0 * p.M * (double)p.N * p.K * p.batch;
+    // A once (the implicit conv reads its NHWC input, not the 9-tap im2col matrix), B once, C once; K slices (batch) write partials
+    const double a_elems = p.aload ? (double)p.M * p.Cin / (double)(1 << (2 * p.ups)) : (double)p.M * p.K * p.batch;
+    rec.bytes = 4.0 * (a_elems + (double)p.N * p.K * p.batch + (double)p.M * p.N * p.batch);
     RGM_CHECK_HIP(hipEventRecord(rec.a, s));
   }
 #ifdef RGM_GEMM2_STAMPS   // make CXXFLAGS+=-DRGM_GEMM2_STAMPS: also build the s_memtime-stamped kernels (tools/gemm_stamp.py)
@@ -1088,13 +1104,13 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
       RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attrd = true;
     }
-    hipLaunchKernelGGL(kd, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
+    hipLaunchKernelGGL(kd, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
   } else
 #endif
   if (p.aload == 0)
-    hipLaunchKernelGGL(k0, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
+    hipLaunchKernelGGL(k0, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   else
-    hipLaunchKernelGGL(k1, grid, block, lds, s, p, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
+    hipLaunchKernelGGL(k1, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   RGM_LAUNCH_CHECK();
   if (g2_prof_on) {
     RGM_CHECK_HIP(hipEventRecord(rec.b, s));
@@ -1433,6 +1449,7 @@ int gemm2_prof_begin(int id, double flops, hipStream_t s) {
   if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return -1;
   rec.tile = id;
   rec.flops = flops;
+  rec.bytes = 0.0;
   (void)hipEventRecord(rec.a, s);
   g2_prof.push_back(rec);
   return (int)g2_prof.size() - 1;
@@ -1465,6 +1482,14 @@ int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total
   return RGM_OK;
 }
 
+// algorithmic bytes summed over the recorded launches of `kernel` (0 for kernels that do not record them)
+double gemm2_prof_bytes(int kernel) {
+  double b = 0.0;
+  for (auto& r : g2_prof)
+    if (r.tile == kernel) b += r.bytes;
+  return b;
+}
+
 // raw per-launch records of the pre-split kernels, in launch order (tools/insitu_probe.py): kernel id, milliseconds, FLOPs
 int gemm2_prof_dump(int cap, int* ids, double* ms, double* flops) {
   int n = 0;
@@ -1482,6 +1507,9 @@ int gemm2_prof_dump(int cap, int* ids, double* ms, double* flops) {
 }
 
 }  // namespace rgm
+
+// Sum of the algorithmic HBM bytes (operands read once, output written once) of the recorded launches of a pre-split kernel id.
+extern "C" double rgm_prof_bytes(int kernel) { return rgm::gemm2_prof_bytes(kernel); }
 
 // Profiling aid: the per-launch records behind rgm_prof_report for the pre-split GEMM kernels, in launch order; returns the count.
 extern "C" int rgm_prof_dump(int cap, int* ids, double* ms, double* flops) {

@@ -89,6 +89,7 @@ def _load():
         "rgm_prof_enable": (C.c_int, [i32]),
         "rgm_prof_reset": (C.c_int, []),
         "rgm_prof_report": (C.c_int, [i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "rgm_prof_bytes": (C.c_double, [i32]),
         "rgm_prof_dump": (C.c_int, [i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rgm_gemm2_dbg": (C.c_int, [i32, C.POINTER(C.c_longlong)]),
     }
