@@ -119,6 +119,9 @@ int rgm_gemm_split(const float* A_split, const float* B_split, float* C, int M, 
 int rgm_split_rows_ld(const float* x, int ld_in, float* out, int ld_out, int64_t rows, int K, void* stream);
 int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
                       const float* bias, int act, int tile, int out_split, void* stream);
+/* The one-wave-per-SIMD kernels (tiles 71 = 256x256, 72 = 512x128; csrc/gemm2.hip PIPE 5): mode 0 keeps the heuristics off them, 1 (default)
+ * lets them choose; min_tiles = tiles a VAE conv launch must have before it takes them (default 256: one round of the chip). */
+int rgm_set_big_tiles(int mode, int min_tiles);
 /* Workspace-backed decompositions of the pre-split GEMM (csrc/gemm4.hip stream-K, csrc/gemm2.hip deterministic split-K): the
  * scratch is caller memory like every other workspace.  rgm_gemm_streamk_workspace_bytes() bytes, 16-byte aligned; tile 0 lets
  * the heuristic choose, 47 forces the persistent stream-K kernel.  The entry zeroes the scratch's flag words on `stream`. */

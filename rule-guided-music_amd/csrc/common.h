@@ -175,6 +175,8 @@ void gemm2_prof(bool on);
 void gemm2_prof_reset();
 int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total_flops);
 double gemm2_prof_bytes(int kernel);
+int big_tiles_mode();   // rgm_set_big_tiles (gemm2.hip)
+int big_tiles_min();
 
 // elementwise / reductions (elementwise.hip)
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,

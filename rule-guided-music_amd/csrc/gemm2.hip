@@ -750,6 +750,22 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         for (int e = 0; e < 16; ++e) slab[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
       });
     };
+    // Output stores.  The one-wave-per-SIMD kernels (PIPE 5) finish a whole round of 256 KB tiles at the same moment and their
+    // epilogue runs at the chip's write rate: non-temporal stores (the 57-76 MB of a qkv / fc1 output pass through the 32 MB of L2
+    // anyway) take 1.7-4.4 % off those launches (tools/which_kernel.py, same box: 86.9 -> 85.4 us at 224 tiles, 98.3 -> 94.0 at 256).
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    auto out16 = [&](float* dst, const float (&v)[4]) {
+      if constexpr (PIPE == 5) {
+        const f32x4 nv = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(dst));
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    };
+    auto out8 = [&](__bf16* dst, const bf16x4_t& v) {
+      if constexpr (PIPE == 5) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4_t*>(dst));
+      else *reinterpret_cast<bf16x4_t*>(dst) = v;
+    };
     auto store_row = [&](int row, const float (&v)[4]) {
       if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
         typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -760,10 +776,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
           lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
         }
         __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-        *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
-        *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+        out8(rowp + split_idx(col), hi);
+        out8(rowp + split_idx(col) + 32, lo);
       } else if (exp != 4) {
-        *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+        out16(Cb + (long long)row * p.ldc + col, v);
       }
     };
     // Three row bodies, chosen by uniform branches.  The general one carries every epilogue variant (activations and their
@@ -811,10 +827,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                     lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
                   }
                   __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-                  *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
-                  *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+                  out8(rowp + split_idx(col), hi);
+                  out8(rowp + split_idx(col) + 32, lo);
                 } else {
-                  if (exp != 4) *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                  if (exp != 4) out16(Cb + (long long)row * p.ldc + col, v);
                 }
               }
             }
@@ -1037,7 +1053,13 @@ __global__ __launch_bounds__(256) void gemm2_dual_kernel(GemmParams pb, GemmPara
 }
 
 static char* g_zero_page = nullptr;
-static int g_big_tiles = getenv("RGM_BIG_TILES") ? atoi(getenv("RGM_BIG_TILES")) : 1;   // 0: heuristic never picks the 256x256 kernel (A/B runs)
+// rgm_set_big_tiles: mode 0 = the heuristics never pick the one-wave-per-SIMD kernels (tiles 71 / 72), 1 = they do (default); min_tiles =
+// tiles a launch must have before the VAE convs take them (default 256 = one round of the chip; parity tests set 1 so that the small
+// golden inputs run through the big-tile kernels too).  RGM_BIG_TILES=0 in the environment: same as mode 0 (A/B runs).
+static int g_big_tiles = getenv("RGM_BIG_TILES") ? atoi(getenv("RGM_BIG_TILES")) : 1;
+static int g_big_min_tiles = 256;
+int big_tiles_mode() { return g_big_tiles; }
+int big_tiles_min() { return g_big_min_tiles; }
 static long long* g_dbg = nullptr;   // set by rgm_gemm2_dbg: stamped kernel variant (tools/gemm_stamp.py)
 // timing experiments only (wrong results): RGM_GEMM2_EXP=1 no DMA after the prologue, =2 DMA + barriers only
 static int g_exp = RGM_EXP_ENV("RGM_GEMM2_EXP");
@@ -1507,6 +1529,13 @@ int gemm2_prof_dump(int cap, int* ids, double* ms, double* flops) {
 }
 
 }  // namespace rgm
+
+extern "C" int rgm_set_big_tiles(int mode, int min_tiles) {
+  RGM_REQUIRE((mode == 0 || mode == 1) && min_tiles >= 1, "set_big_tiles: mode %d (0 / 1), min_tiles %d (>= 1)", mode, min_tiles);
+  rgm::g_big_tiles = mode;
+  rgm::g_big_min_tiles = min_tiles;
+  return RGM_OK;
+}
 
 // Sum of the algorithmic HBM bytes (operands read once, output written once) of the recorded launches of a pre-split kernel id.
 extern "C" double rgm_prof_bytes(int kernel) { return rgm::gemm2_prof_bytes(kernel); }

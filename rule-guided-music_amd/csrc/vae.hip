@@ -847,16 +847,16 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
   if (in_split) {
     g.tile = RGM_EXP_ENV("RGM_CONV_TILE");   // 0 = gemm2's heuristic (timing experiments: common.h)
     int rows = 128;
-    static const int big = getenv("RGM_BIG_TILES") ? atoi(getenv("RGM_BIG_TILES")) : 1;
-    if (g.tile == 0 && big) {
+    if (g.tile == 0 && big_tiles_mode()) {
       // One wave per SIMD, 128x128 accumulators per wave (gemm2.hip PIPE 5): 256x256 tiles for the 256- / 512-channel convs, 512x128
       // for the 128-channel ones, once the grid fills at least one round of the chip (a 64-candidate decode: 32 ... 512 rounds);
       // tiles must not straddle an image (per-image GroupNorm sums), so 16x16 maps (256 pixels) only take the 256-row tile
       const long long P = (long long)H * H;
-      if ((Cout == 256 || Cout == 512) && P % 256 == 0 && ((long long)g.M / 256) * (Cout / 256) >= 256) {
+      const long long min_tiles = big_tiles_min();
+      if ((Cout == 256 || Cout == 512) && P % 256 == 0 && ((long long)g.M / 256) * (Cout / 256) >= min_tiles) {
         g.tile = 71;
         rows = 256;
-      } else if (Cout == 128 && P % 512 == 0 && (long long)g.M / 512 >= 256) {
+      } else if (Cout == 128 && P % 512 == 0 && (long long)g.M / 512 >= min_tiles) {
         g.tile = 72;
         rows = 512;
       }

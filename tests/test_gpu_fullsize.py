@@ -62,7 +62,7 @@ class _Recorded:
         from rgm import native as R
         torch.cuda.synchronize()
         R.check(R.lib.rgm_prof_enable(0))
-        self.n = _launches([83, 84, 47, 111, 112, 113])
+        self.n = _launches([83, 84, 47, 111, 112, 113, 121, 122])
         self.big = self.n[47] + self.n[111] + self.n[112] + self.n[113]
         R.check(R.lib.rgm_prof_reset())
 
@@ -244,14 +244,21 @@ def test_scg_search_step_at_c4_size_matches_its_two_rank_replay(monkeypatch, pre
         assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt winner differs"
 
 
-@pytest.mark.parametrize("depth", [2, 28])
-def test_long_sequence_guided_step_at_xl_width(monkeypatch, depth, precision):
+@pytest.fixture(params=[("fp32", 2), ("bf16x3", 2), ("bf16x3_presplit", 2), ("bf16x3_presplit", 28)], ids=lambda p: f"{p[0]}-d{p[1]}")
+def prec_depth(request):
+    """every arithmetic at depth 2, depth 28 once in the arithmetic the bench runs"""
+    from rgm import native as R
+    R.set_gemm_precision(request.param[0])
+    yield request.param
+    R.set_gemm_precision("fp32")
+
+
+def test_long_sequence_guided_step_at_xl_width(monkeypatch, prec_depth):
     """BASELINE config 5 (diff_collage/condind_long.py:24-51 + gaussian_diffusion.py:562-592): a 4 x 512 x 16 latent = 7 windows + 6
     overlap halves through the XL eps-network per evaluation, 32 squares per candidate through the decoder, segment-wise SCG
     (dc.base 128), B = 1, n = 4.  (a) the collage eps of the 13-window batch equals the same windows evaluated one pair at a time
     (row independence at M = 13 x 256 .. 4 x 13 x 256 rows); (b) the guided step equals its 'rank r of 2' replay."""
-    if depth == 28 and precision != "bf16x3_presplit":
-        pytest.skip("depth 28 once, in the arithmetic the bench runs")
+    precision, depth = prec_depth
     from functools import partial
     from types import SimpleNamespace
     from gpu_util import rel
@@ -395,3 +402,28 @@ def test_half_window_batches_through_the_xl_model_are_deterministic(precision):
     assert worst == 0.0, f"identical calls differ by {worst}"
     small = torch.cat([m(x[i:i + 2].contiguous(), t[i:i + 2].contiguous(), y[i:i + 2].contiguous()) for i in range(0, N, 2)])
     assert rel(outs[0].cpu().numpy(), small.cpu().numpy()) < (3e-5 if precision == "bf16x3_presplit" else 2e-6)
+
+
+def test_vae_decoder_golden_through_the_big_tile_conv_kernels():
+    """The VAE's 3x3 convs take the 256x256 / 512x128 one-wave-per-SIMD kernels (implicit-GEMM loader, GroupNorm sums in the epilogue at
+    256- / 512-row granularity) once a launch fills the chip -- far above the golden fixtures' two squares.  rgm_set_big_tiles lowers that
+    threshold to 1 tile so that the reference's decoder golden (and the decode -> uint8 path) runs through exactly those kernels."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    from guided_diffusion.gaussian_diffusion import _decode
+    g = load_golden("vae_decoder")
+    R.set_gemm_precision("bf16x3_presplit")
+    try:
+        vae = _vae(int(g["seed"]))
+        base = vae.decode(dev(g["z"]))                                   # heuristic: 128-row kernels on this small input
+        R.check(R.lib.rgm_set_big_tiles(1, 1))
+        with _Recorded() as rec:
+            out = vae.decode(dev(g["z"]))
+        assert rec.n[121] >= 10 and rec.n[122] >= 5, rec.n           # 256x256 (N = 256 / 512) and 512x128 (N = 128) conv launches
+        roll = _decode(dev(g["lat"]), vae, scale_factor=1.2465)
+    finally:
+        R.check(R.lib.rgm_set_big_tiles(1, 256))
+        R.set_gemm_precision("fp32")
+    assert rel(out.cpu().numpy(), g["out"]) < 5e-5
+    assert rel(out.cpu().numpy(), base.cpu().numpy()) < 2e-5
+    assert bool(torch.isfinite(roll).all())
