@@ -1281,7 +1281,10 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     const long long total = (long long)tm * tn;
     const long long rounds = (total + 255) / 256;
     const double waste = (double)((long long)tn * 256 - p.N) / ((double)tn * 256);      // columns of the edge tiles beyond N
-    if (total >= 200 && (double)total / (double)(rounds * 256) >= 0.84 && waste <= 0.08) {
+    // one (partial) round: from 150 tiles up the 256x256 kernel beats every 128-row kernel (B = 32 sweep, profiles/r03_tile71_sweep_b32.txt:
+    // proj 160 tiles 74 us against 89 / 103, fc2 240 against 307 / 264); several rounds: the last one at least 84 % full
+    const bool fills = rounds == 1 ? total >= 150 : (double)total / (double)(rounds * 256) >= 0.84;
+    if (fills && waste <= 0.11) {
       GemmParams q = p;
       q.tile = 71;
       return gemm2_launch(q, s);
