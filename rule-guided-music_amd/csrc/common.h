@@ -135,6 +135,9 @@ struct GemmParams {
   // implicit-GEMM 3x3 conv A operand (aload == 1): A is NHWC [img][Hin][Win][Cin], M = imgs*H*W
   int aload = 0;
   int H = 0, W = 0, Cin = 0, logH = 0, logW = 0, ups = 0;
+  // K order of the implicit conv: 0 = (tap, cin) as the weights are repacked [cout][9][cin]; 1 = (cin / 32, tap, cin % 32) -- the nine
+  // taps of a 32-channel block are consecutive K-tiles (gemm2.hip PIPE 5 only, ups == 0; weights [cout][cin/32][9][32])
+  int conv_kmajor = 0;
   // tile override for experiments: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
   int tile = 0;
   // gemm2 raster: row-tiles per column sweep of the XCD-contiguous grouped raster (0 = 8).  The one-wave-per-SIMD kernels set it to

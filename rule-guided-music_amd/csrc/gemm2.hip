@@ -168,6 +168,25 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         inc[i] = a_row_ok[i] ? 128 : 0;
         a_y[i] = a_x[i] = 0;
         a_img[i] = 0;
+      } else if (ALOAD == 2) {
+        // channel-block-major K (GemmParams::conv_kmajor) on the one-wave-per-SIMD kernels: K-tile kt = (kc, tap) = (kt / 9, kt % 9) reads
+        // the 128-byte line kc of the neighbour pixel `tap`.  Per piece: the byte offset of the CENTRE pixel's source line 0 (a_img), a 9-bit
+        // mask of the taps whose neighbour exists (a_y) and, for the nearest-x2 upsampling convs (the source of (y, x) is (y >> 1, x >> 1)),
+        // the parities of y and x (a_x): the tap's source offset is then one of two wave-uniform values per axis, picked by parity
+        const int y = (row >> p.logW) & (p.H - 1), x = row & (p.W - 1);
+        const int img = row >> (p.logH + p.logW);
+        const int Hin = p.H >> p.ups, Win = p.W >> p.ups;
+        a_img[i] = ((((long long)img * Hin + (y >> p.ups)) * Win + (x >> p.ups)) * p.Cin) * 4 + csrc[i];
+        int m9 = 0;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+          if (a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) m9 |= 1 << tap;
+        }
+        a_y[i] = m9;
+        a_x[i] = (y & 1) | ((x & 1) << 1);
+        src[i] = zero_page + csrc[i];
+        inc[i] = 0;
       } else {  // NHWC split activations: a pixel = Cin/32 lines of [32 hi | 32 lo]; source recomputed per tap
         const int img = row >> (p.logH + p.logW);
         a_y[i] = (row >> p.logW) & (p.H - 1);
@@ -187,23 +206,33 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     }
   }
   const int cpt = (ALOAD == 1) ? (p.Cin >> 5) : 1;  // K-tiles per 3x3 tap
+  // Implicit conv (ALOAD 1): re-aim the A pieces.  Tap-major K (the weights as repacked [cout][9][cin]): once per tap, the pieces then walk
+  // the pixel's Cin/32 lines.  Channel-block-major K (GemmParams::conv_kmajor, weights [cout][cin/32][9][32]): K-tile kt = (kc, tap) =
+  // (kt / 9, kt % 9) reads line kc of the tap's neighbour, so every K-tile is re-aimed -- the nine taps of a channel block re-read the
+  // same input lines within nine K-tiles, i.e. from the XCD's L2 (the one-wave-per-SIMD kernels have their own fast path: ALOAD 2).
+  // Both orders sum the same products; every conv of the pre-split mode uses ONE order so that results do not depend on the tile shape.
+  auto conv_retarget = [&](int kt) {
+    if (ALOAD != 1) return;
+    const bool km = p.conv_kmajor != 0;
+    if (!km && kt % cpt != 0) return;
+    const int tap = km ? kt % 9 : kt / cpt;
+    const long long line = km ? (long long)(kt / 9) * 128 : 0;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int Win = p.W >> p.ups;
+#pragma unroll
+    for (int i = 0; i < SPW; ++i) {
+      if (!is_a[i]) continue;
+      const int yy = a_y[i] + dy, xx = a_x[i] + dx;
+      const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+      src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + line + csrc[i]
+                  : zero_page + csrc[i];
+      inc[i] = (ok && !km) ? 128 : 0;
+    }
+  };
 
   auto issue = [&](int kt, int stage) {
     char* dst = ring + stage * STAGE;
-    if (ALOAD == 1 && kt % cpt == 0) {               // entering a new tap: re-aim the A segments
-      const int tap = kt / cpt;
-      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-      const int Win = p.W >> p.ups;
-#pragma unroll
-      for (int i = 0; i < SPW; ++i) {
-        if (!is_a[i]) continue;
-        const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-        const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
-                    : zero_page + csrc[i];
-        inc[i] = ok ? 128 : 0;
-      }
-    }
+    conv_retarget(kt);               // entering a new tap (or, channel-block-major, every K-tile): re-aim the A segments
 #pragma unroll
     for (int i = 0; i < SPW; ++i) {
       dma16(src[i], dst + (wave + i * NW) * 1024);
@@ -316,22 +345,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     static_assert(NSTAGE == 2, "PIPE 5: 2-stage ring");
     constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
     constexpr int NRD = 2 * (TM + TN);                    // ds_read_b128 per k16 step
-    auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
-      if (ALOAD == 1 && kt % cpt == 0) {
-        const int tap = kt / cpt;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int Win = p.W >> p.ups;
-#pragma unroll
-        for (int i = 0; i < SPW; ++i) {
-          if (!is_a[i]) continue;
-          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-          const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
-                      : zero_page + csrc[i];
-          inc[i] = ok ? 128 : 0;
-        }
-      }
-    };
+    auto retarget = [&](int kt) { conv_retarget(kt); };
     static_assert(NRD * 3 <= NM && SPW * 3 <= 2 * NM, "one read per three MFMA slots, at most two DMA pieces");
     struct FragsK {
       bf16x8 a[TM][2], b[TN][2];                          // [frag][hi, lo] of one k16 step
@@ -346,16 +360,53 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         f.b[fi - TM][lo] = *reinterpret_cast<const bf16x8*>(As + BM * 128 + (bcol0 + (fi - TM) * 32 + l31) * 128 + chunk);
       }
     };
+    // ALOAD == 2: the A pieces of a K-tile (tap, kc) point at line kc of the tap's neighbour pixel, or at the zero page
+    constexpr int APIECES = BM / 8 / NW;                  // the first APIECES pieces of a wave are A pieces
+    // wave-uniform description of a K-tile's tap: source-pixel steps for even / odd y and x (without upsampling both are dy / dx;
+    // with it a step only crosses into the next source pixel from the matching parity), in bytes, plus the channel block's line
+    struct TapStep {
+      int tap;
+      int row_e, row_o, col_e, col_o;      // bytes
+      long long line;
+    };
+    auto tap_step = [&](int tap, int kc) {
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int Win = p.W >> p.ups;
+      const int pix = p.Cin * 4, rowb = Win * pix;
+      TapStep t;
+      t.tap = tap;
+      t.row_e = (p.ups ? (dy < 0 ? -1 : 0) : dy) * rowb;
+      t.row_o = (p.ups ? (dy > 0 ? 1 : 0) : dy) * rowb;
+      t.col_e = (p.ups ? (dx < 0 ? -1 : 0) : dx) * pix;
+      t.col_o = (p.ups ? (dx > 0 ? 1 : 0) : dx) * pix;
+      t.line = (long long)kc * 128;
+      return t;
+    };
+    auto aim_piece = [&](auto ic, const TapStep& t) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < APIECES) {
+        const int d = ((a_x[i] & 1) ? t.row_o : t.row_e) + ((a_x[i] & 2) ? t.col_o : t.col_e);
+        src[i] = ((a_y[i] >> t.tap) & 1) ? Ab + a_img[i] + t.line + d : zero_page + csrc[i];
+      }
+    };
+    auto aim_all = [&](int tap, int kc) {
+      const TapStep t = tap_step(tap, kc);
+      static_for<0, APIECES>([&](auto ic) { aim_piece(ic, t); });
+    };
     // one k16 step: NM MFMAs from `cur`; READ: the NRD reads of step `stn` of the tile at `rd` into `nxt`; DMA: this wave's SPW
-    // pieces of the next-but-one tile into `dst`
-    auto phase = [&](const FragsK& cur, FragsK& nxt, auto readc, auto dmac, auto stnc, const char* rd, char* dst) {
+    // pieces of the next-but-one tile into `dst`; AIM (ALOAD 2, phases without DMA): the A pieces' sources of the next-but-one tile
+    auto phase_aim = [&](const FragsK& cur, FragsK& nxt, auto readc, auto dmac, auto stnc, const char* rd, char* dst, auto aimc,
+                         const TapStep& aim) {
       constexpr bool READ = decltype(readc)::value != 0, DMA = decltype(dmac)::value != 0;
+      constexpr bool AIM = decltype(aimc)::value != 0;
+      static_assert(!(AIM && DMA), "the sources are re-aimed in the phase that does not issue them");
       static_for<0, NM>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
         acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
         if constexpr (READ && m % 3 == 0 && m / 3 < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / 3>{});
+        if constexpr (AIM && m % 3 == 1 && m / 3 < APIECES) aim_piece(std::integral_constant<int, m / 3>{}, aim);
         if constexpr (DMA && m % 3 == 1 && m / 3 < SPW) {
           constexpr int i = m / 3;
           dma16(src[i], dst + (wave + i * NW) * 1024);
@@ -371,7 +422,22 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     };
     using Y = std::integral_constant<int, 1>;
     using Nn = std::integral_constant<int, 0>;
+    auto phase = [&](const FragsK& cur, FragsK& nxt, auto readc, auto dmac, auto stnc, const char* rd, char* dst) {
+      phase_aim(cur, nxt, readc, dmac, stnc, rd, dst, Nn{}, TapStep{});
+    };
     FragsK f0, f1;
+    // (tap, kc) of the K-tile whose A sources are aimed next (ALOAD 2): K-tile kt = (kt % 9, kt / 9)
+    int tap_n = 0, kc_n = 0;
+    auto next_ktile = [&]() {
+      if (++tap_n == 9) {
+        tap_n = 0;
+        ++kc_n;
+      }
+    };
+    if (ALOAD == 2) {
+      aim_all(0, 0);
+      next_ktile();
+    }
     retarget(0);
     static_for<0, SPW>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -379,6 +445,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       src[i] += inc[i];
     });
     if (KT > 1) {
+      if (ALOAD == 2) {
+        aim_all(tap_n, kc_n);
+        next_ktile();
+      }
       retarget(1);
       static_for<0, SPW>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
@@ -404,7 +474,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     for (; kt + 2 < KT; ++kt) {                           // steady state: tiles kt+1 and kt+2 exist
       char* cs = ring + (kt & 1) * STAGE;
       char* ns = ring + ((kt + 1) & 1) * STAGE;
-      phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
+      if constexpr (ALOAD == 2) {                            // K-tile kt + 2's A sources, computed in the gaps of this phase's MFMAs
+        phase_aim(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr, Y{}, tap_step(tap_n, kc_n));
+        next_ktile();
+      } else {
+        phase(f0, f1, Y{}, Nn{}, Y{}, cs, nullptr);
+      }
       RGM_STAMP(4)
       retarget(kt + 2);
       if (DBG) {
@@ -446,22 +521,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     struct Frags {
       bf16x8 ah[2][TM], al[2][TM], bh[2][TN], bl[2][TN];
     };
-    auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
-      if (ALOAD == 1 && kt % cpt == 0) {
-        const int tap = kt / cpt;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int Win = p.W >> p.ups;
-#pragma unroll
-        for (int i = 0; i < SPW; ++i) {
-          if (!is_a[i]) continue;
-          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-          const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
-                      : zero_page + csrc[i];
-          inc[i] = ok ? 128 : 0;
-        }
-      }
-    };
+    auto retarget = [&](int kt) { conv_retarget(kt); };
     auto load_frags = [&](Frags& f, const char* As) {
       const char* Bs = As + BM * 128;
       static_for<0, 2>([&](auto sc) {
@@ -561,22 +621,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // (a burst of 8 pieces right after the barrier cost each wave ~800 cycles in the TA queue: tools/gemm_stamp.py).
     static_assert(NSTAGE == 2, "PIPE 1: 2-stage ring only");
     constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
-    auto retarget = [&](int kt) {                         // conv: entering a new 3x3 tap re-aims the A pieces
-      if (ALOAD == 1 && kt % cpt == 0) {
-        const int tap = kt / cpt;
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int Win = p.W >> p.ups;
-#pragma unroll
-        for (int i = 0; i < SPW; ++i) {
-          if (!is_a[i]) continue;
-          const int yy = a_y[i] + dy, xx = a_x[i] + dx;
-          const bool ok = a_row_ok[i] && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-          src[i] = ok ? Ab + a_img[i] + ((long long)(yy >> p.ups) * Win + (xx >> p.ups)) * p.Cin * 4 + csrc[i]
-                      : zero_page + csrc[i];
-          inc[i] = ok ? 128 : 0;
-        }
-      }
-    };
+    auto retarget = [&](int kt) { conv_retarget(kt); };
     retarget(0);
     static_for<0, SPW>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
@@ -1084,6 +1129,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   static bool attr0 = false, attr1 = false;
   auto k0 = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 0, PIPE>;
   auto k1 = gemm2_kernel<BM, BN, WM, WN, PIPE == 4 ? 0 : 1, NSTAGE, 0, PIPE>;
+  auto k2 = gemm2_kernel<BM, BN, WM, WN, PIPE == 5 ? 2 : 0, NSTAGE, 0, PIPE>;   // implicit conv with channel-block-major K (PIPE 5 only)
+  RGM_REQUIRE(!p.conv_kmajor || (p.aload == 1 && p.Cin % 32 == 0), "gemm2: conv_kmajor is a property of the implicit 3x3 conv (aload == 1)");
   RGM_REQUIRE(PIPE != 4 || p.aload == 0, "gemm2: the loader/consumer kernels take dense operands only");
   if (lds > 65536) {
     if (p.aload == 0 && !attr0) {
@@ -1092,6 +1139,7 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     }
     if (p.aload == 1 && !attr1) {
       RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      if (PIPE == 5) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       attr1 = true;
     }
   }
@@ -1131,6 +1179,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
 #endif
   if (p.aload == 0)
     hipLaunchKernelGGL(k0, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
+  else if (PIPE == 5 && p.conv_kmajor)
+    hipLaunchKernelGGL(k2, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   else
     hipLaunchKernelGGL(k1, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, (long long*)nullptr);
   RGM_LAUNCH_CHECK();

@@ -302,6 +302,19 @@ __global__ void repack_conv3_kernel(const float* __restrict__ in, float* __restr
   out[i] = in[((long long)co * Cin + ci) * 9 + tap];
 }
 
+// [Cout][9][Cin] -> [Cout][Cin/32][9][32]: the K order of the one-wave-per-SIMD conv kernels (gemm2.hip PIPE 5, GemmParams::conv_kmajor):
+// the nine taps of one 32-channel block are consecutive K-tiles, so the same input lines are re-read within 9 K-tiles instead of once
+// per Cin/32 K-tiles -- they then come from the XCD's L2 instead of the fabric (in-situ PMC, 128-channel convs of a 64-candidate decode:
+// 47.7 GB fetched per launch = the whole im2col matrix, L2 hit 36 %, the launch at 5 TB/s)
+__global__ void repack_conv3_kmajor_kernel(const float* __restrict__ in, float* __restrict__ out, int Cout, int Cin) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)Cout * Cin * 9) return;
+  const int ci = (int)(i % Cin);
+  const int tap = (int)((i / Cin) % 9);
+  const long long co = i / ((long long)Cin * 9);
+  out[(co * (Cin / 32) + ci / 32) * 288 + tap * 32 + (ci & 31)] = in[i];
+}
+
 // x<=thr -> -1 ; clamp((x+1)*63.5, 0, 127) -> uint8 ; (B,3,128,T) -> (B,128,T,3)
 __global__ void quantise_roll_kernel(const float* __restrict__ roll, uint8_t* __restrict__ u8, int B, int T, float thr) {
   const long long total = (long long)B * 128 * T * 3;
@@ -565,6 +578,10 @@ static void vslot(rgm_vae* h, const std::string& key, size_t numel, int conv3 = 
     d.set = true;
     h->slots[key + ".S"] = d;
     h->arena_floats += (numel + 3) / 4 * 4;
+    VSlot k = d;                                        // the same weight, channel-block-major K, split rows (repack_conv3_kmajor_kernel)
+    k.off = h->arena_floats;
+    h->slots[key + ".K"] = k;
+    h->arena_floats += (numel + 3) / 4 * 4;
   }
 }
 
@@ -686,6 +703,12 @@ extern "C" int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, 
     auto sp = h->slots.find(std::string(key) + ".S");
     if (sp != h->slots.end())   // rows = cout, K = 9*cin: the 32-blocks of a split row never straddle a tap (cin % 32 == 0)
       RGM_TRY(split_rows_launch(h->arena + s.off, h->arena + sp->second.off, s.cout, 9 * s.cin, 9 * s.cin, 9 * s.cin, 0));
+    auto kp = h->slots.find(std::string(key) + ".K");
+    if (kp != h->slots.end()) {                          // stage <- kc-major fp32, then split rows into the slot
+      hipLaunchKernelGGL(repack_conv3_kmajor_kernel, dim3((unsigned)((numel + 255) / 256)), dim3(256), 0, 0, h->arena + s.off, h->stage, s.cout, s.cin);
+      RGM_LAUNCH_CHECK();
+      RGM_TRY(split_rows_launch(h->stage, h->arena + kp->second.off, s.cout, 9 * s.cin, 9 * s.cin, 9 * s.cin, 0));
+    }
     RGM_CHECK_HIP(hipStreamSynchronize(0));
   } else {
     RGM_CHECK_HIP(hipMemcpy(h->arena + s.off, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
@@ -860,6 +883,14 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
         g.tile = 72;
         rows = 512;
       }
+    }
+    // channel-block-major K for EVERY pre-split conv (weights: the .K copy), whatever tile the launch takes: results then do not depend
+    // on the batch size through the tile choice, and the nine taps of a channel block re-read their input lines from L2
+    static const int kmajor = getenv("RGM_CONV_KMAJOR") ? atoi(getenv("RGM_CONV_KMAJOR")) : 1;   // 0: tap-major (A/B runs)
+    static const int kmajor_ups = getenv("RGM_CONV_KMAJOR_UPS") ? atoi(getenv("RGM_CONV_KMAJOR_UPS")) : 0;
+    if (kmajor && (ups == 0 || kmajor_ups)) {
+      g.B = c.h->p(key + ".weight.K");
+      g.conv_kmajor = 1;
     }
     if ((g.tile == 0 || g.tile == 71 || g.tile == 72) && Cout % 128 == 0 && Cout <= 512 && (H * H) % rows == 0) {   // tiles never straddle an image
       g.stats = c.p.tpart;

@@ -368,8 +368,11 @@ def test_full_size_batch_is_row_independent_of_the_small_pinned_batches(precisio
     vae = _vae(2)
     z = dev(rng.randn(64, 4, 16, 16).astype(F32))
     dec = vae.decode(z)
+    # pre-split mode: the big batch's 3x3 convs run the one-wave-per-SIMD kernels with channel-block-major K (gemm2.hip ALOAD 2), the
+    # batch of 2 the 128-row kernels with tap-major K -- the same bf16x3 products in another fp32 summation order (measured 5e-6)
+    vtol = 2e-5 if precision == "bf16x3_presplit" else 2e-6
     for i in (0, 31, 62):
-        assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < 2e-6, i
+        assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < vtol, i
 
 
 def test_chord_rule_device_preamble_and_host_plugin():
@@ -437,15 +440,16 @@ def test_full_size_guidance_and_scg_decode_are_row_independent(precision):
     z = dev(rng.randn(512, 4, 16, 16).astype(F32))
     dec = vae.decode(z)
     assert dec.shape == (512, 3, 128, 128)
+    vtol = 2e-5 if precision == "bf16x3_presplit" else 2e-6          # other K order of the big batch's convs (see the test above)
     for i in (0, 255, 510):
-        assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < 2e-6, i
+        assert rel(dec[i:i + 2].cpu().numpy(), vae.decode(z[i:i + 2].contiguous()).cpu().numpy()) < vtol, i
     # and the latent-shaped path SCG uses (64 candidates x 8 squares, segment-major gather inside the kernel)
     from guided_diffusion.gaussian_diffusion import _decode
     lat = dev(rng.randn(64, 4, 128, 16).astype(F32))
     roll = _decode(lat, vae, scale_factor=1.2465)
     assert roll.shape == (64, 3, 128, 1024)
     for i in (0, 33, 62):
-        assert rel(roll[i:i + 2].cpu().numpy(), _decode(lat[i:i + 2].contiguous(), vae, scale_factor=1.2465).cpu().numpy()) < 2e-6, i
+        assert rel(roll[i:i + 2].cpu().numpy(), _decode(lat[i:i + 2].contiguous(), vae, scale_factor=1.2465).cpu().numpy()) < vtol, i
 
 
 @pytest.mark.parametrize("kind", ["ddpm_cls", "ddim", "dps"])
