@@ -272,8 +272,13 @@ template <int HD, int NKT>
 static int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const float* ct,
                       const float* st, int N, int T, int heads, int rot_half, hipStream_t s) {
   constexpr int TP = NKT * 32, HDP = HD + 4;
-  const size_t lds_q = (size_t)2 * TP * HDP * sizeof(float);
-  const size_t lds_kv = lds_q + (size_t)2 * TP * sizeof(float);
+  // one workgroup per CU, enforced (>= 80.5 KiB): the same single-pass structure as the forward kernels, whose idle waves retire early
+  // at short T and let a second workgroup in -- see attention_x3.hip launch_attn_x3 for what that did to the forward
+  constexpr size_t ONE_PER_CU = 80 * 1024 + 512;
+  size_t lds_q = (size_t)2 * TP * HDP * sizeof(float);
+  size_t lds_kv = lds_q + (size_t)2 * TP * sizeof(float);
+  if (lds_q < ONE_PER_CU) lds_q = ONE_PER_CU;
+  if (lds_kv < ONE_PER_CU) lds_kv = ONE_PER_CU;
   static bool attr_set = false;
   auto kq = attn_bwd_dq_kernel<HD, NKT>;
   auto kkv = attn_bwd_dkv_kernel<HD, NKT>;
