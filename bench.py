@@ -501,7 +501,7 @@ def spawn_ranks(n):
     import socket
     import subprocess
     have = torch.cuda.device_count()
-    if have < n:
+    if have < n and os.environ.get("RGM_BENCH_ONE_DEVICE") != "1":   # (one-device plumbing mode: every rank on cuda:0 over gloo)
         sys.exit(f"bench.py: --gpus {n} requested but this box has {have} HIP device(s)")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -631,6 +631,16 @@ def main():
             attempt("uint8_flips", lambda: uint8_flip_record(device))
             if world == 1 and not args.no_cpu_baseline:
                 attempt("cpu_baseline", lambda: cpu_baseline(work))
+    same_winners = None
+    if world > 1 and args.workload in ("scg", "long"):
+        # every rank must have picked the same candidates in the last step (identical gathered table -> identical first-argmax)
+        mine = work.d.last_scg["max_ind"].to(torch.int64).contiguous()
+        allm = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allm, mine)
+        tot = work.d.last_scg["total_log_prob"].contiguous()
+        allt = [torch.empty_like(tot) for _ in range(world)]
+        dist.all_gather(allt, tot)
+        same_winners = all(bool(torch.equal(allm[0], m)) for m in allm) and all(bool(torch.equal(allt[0], m)) for m in allt)
     if rank == 0:
         sharded = args.workload in ("scg", "long")
         units = args.steps * (1 if sharded else world)           # SCG shards ONE chain; C2 runs one chain per GPU
@@ -649,6 +659,8 @@ def main():
                        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
                        "algorithmic_tflops": round(work.flop_per_step * units / dt / 1e12, 2)},
         }
+        if same_winners is not None:
+            res["config"]["same_winners_on_every_rank"] = bool(same_winners)
         if "uint8_flips" in extras:
             res["config"]["uint8_flips"] = extras.pop("uint8_flips")
         res["roofline"] = roof

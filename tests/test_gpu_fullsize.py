@@ -335,6 +335,20 @@ def test_long_sequence_guided_step_at_xl_width(monkeypatch, prec_depth):
             assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
 
 
+def test_two_rank_scg_bench_control_flow_on_one_device():
+    """The command the 2-GPU test runs, with both ranks on this one device over gloo (RGM_BENCH_ONE_DEVICE=1: plumbing, never a
+    measurement): the sharded search step, both collectives, the same-winners check and the JSON line's shape."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGM_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--no-extras", "--workload", "scg", "--steps", "2",
+                          "--warmup", "1", "--repeats", "1"], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "PLUMBING" in line["data"]
+    assert line["config"]["same_winners_on_every_rank"] is True, line
+
+
 def test_two_gpu_scg_bench_runs_over_rccl_when_the_box_has_two_gpus():
     """Multi-GPU readiness: on a box with >= 2 GPUs this runs the sharded SCG bench over RCCL (bench.py spawns its own ranks) and
     requires the same winners on every rank; on the 1-GPU boxes of this round it is skipped -- the only test that may skip."""
@@ -346,9 +360,8 @@ def test_two_gpu_scg_bench_runs_over_rccl_when_the_box_has_two_gpus():
                           "--warmup", "1"], capture_output=True, text=True, timeout=1500, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2
-    rec = line.get("scg", line)
-    assert rec.get("same_winners_on_every_rank", line.get("config", {}).get("same_winners_on_every_rank")) is True, line
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["config"]["same_winners_on_every_rank"] is True, line
 
 
 @pytest.mark.parametrize("N,T,heads,hd", [(48, 128, 16, 72), (40, 96, 16, 72), (64, 64, 6, 64), (48, 129, 6, 64)])

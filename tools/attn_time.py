@@ -23,7 +23,7 @@ o = torch.empty(N * T, D, device="cuda")
 
 
 def run(i):
-    R.check(R.lib.rgm_rotary_attention(R.ptr(bufs[i % 8]), R.ptr(o), R.ptr(cs), R.ptr(sn), N, T, heads, hd, rot // 2, R.current_stream()))
+    R.check(R.lib.rgm_rotary_attention(R.ptr(bufs[i % 8]), R.ptr(o), R.ptr(cs), R.ptr(sn), N, T, heads, hd, int(os.environ.get('ROT_HALF', rot // 2)), R.current_stream()))
 
 
 for i in range(10):
