@@ -346,7 +346,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     constexpr int NM = TM * TN * 3;                       // MFMAs per k16 step
     constexpr int NRD = 2 * (TM + TN);                    // ds_read_b128 per k16 step
     auto retarget = [&](int kt) { conv_retarget(kt); };
-    static_assert(NRD * 3 <= NM && SPW * 3 <= 2 * NM, "one read per three MFMA slots, at most two DMA pieces");
+    // MFMA slots per read / DMA piece: 3 for the 128x128 wave tile (48 MFMAs a phase, 16 reads, 16-20 pieces), 2 for 128x64 (24 / 12 / 12)
+    constexpr int EV = (NRD * 3 <= NM && SPW * 3 <= 2 * NM) ? 3 : 2;
+    static_assert(NRD * EV <= NM && (EV == 3 ? SPW * 3 <= 2 * NM : SPW * 2 <= NM), "reads and DMA pieces must fit the MFMA slots of a phase");
     struct FragsK {
       bf16x8 a[TM][2], b[TN][2];                          // [frag][hi, lo] of one k16 step
     };
@@ -405,14 +407,14 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
         acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
-        if constexpr (READ && m % 3 == 0 && m / 3 < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / 3>{});
-        if constexpr (AIM && m % 3 == 1 && m / 3 < APIECES) aim_piece(std::integral_constant<int, m / 3>{}, aim);
-        if constexpr (DMA && m % 3 == 1 && m / 3 < SPW) {
-          constexpr int i = m / 3;
+        if constexpr (READ && m % EV == 0 && m / EV < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / EV>{});
+        if constexpr (AIM && m % EV == 1 && m / EV < APIECES) aim_piece(std::integral_constant<int, m / EV>{}, aim);
+        if constexpr (DMA && m % EV == 1 && m / EV < SPW) {
+          constexpr int i = m / EV;
           dma16(src[i], dst + (wave + i * NW) * 1024);
           src[i] += inc[i];
         }
-        if constexpr (DMA && m % 3 == 2 && NM / 3 + m / 3 < SPW) {      // tiles with more than NM / 3 pieces per wave (512x128: 20)
+        if constexpr (DMA && EV == 3 && m % 3 == 2 && NM / 3 + m / 3 < SPW) {      // tiles with more than NM / 3 pieces per wave (512x128: 20)
           constexpr int i = NM / 3 + m / 3;
           dma16(src[i], dst + (wave + i * NW) * 1024);
           src[i] += inc[i];
@@ -1471,6 +1473,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 58: return launch2<64, 64, 2, 2, 3, 4>(p, s, 58);     // 48 KB: 3 per CU
     // one wave per SIMD, 128x128 per wave (PIPE == 5)
     case 71: return launch2<256, 256, 2, 2, 2, 5>(p, s, 71);   // 128 KB: 1 per CU, 512 registers
+    case 73: return launch2<128, 256, 1, 4, 2, 5>(p, s, 73);   // 96 KB: 128x64 wave tiles, for M of a few thousand rows (B = 8: the shapes B = 16 has at 256 rows)
     case 72: return launch2<512, 128, 4, 1, 2, 5>(p, s, 72);   // 160 KB (all of the LDS): the same 128x128 wave tiles for N = 128 (VAE convs at 128 channels)
     // persistent loader/consumer kernel (gemm3.hip)
     case 61:

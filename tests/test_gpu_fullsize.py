@@ -67,7 +67,7 @@ class _Recorded:
         R.check(R.lib.rgm_prof_reset())
 
 
-BIG_TILES = [47, 71]
+BIG_TILES = [47, 71, 72, 73]
 
 
 @pytest.mark.parametrize("tile", BIG_TILES)

@@ -25,6 +25,9 @@ elif os.environ.get("SWEEP_SHAPES") == "b32":        # XL backbone at B = 32 (C3
     SHAPES_OVERRIDE = [("qkv", 8192, 3456, 1152), ("proj", 8192, 1152, 1152), ("fc1", 8192, 4608, 1152), ("fc2", 8192, 1152, 4608)]
 elif os.environ.get("SWEEP_SHAPES") == "b64":        # XL backbone at n.B = 64 (C4's candidate batch)
     SHAPES_OVERRIDE = [("qkv", 16384, 3456, 1152), ("proj", 16384, 1152, 1152), ("fc1", 16384, 4608, 1152), ("fc2", 16384, 1152, 4608)]
+elif os.environ.get("SWEEP_SHAPES") == "mid":        # B = 6 / 8 / 12 latents: M of a few thousand rows
+    SHAPES_OVERRIDE = [(f"{n}_b{b}", 256 * b, N, K) for b in (6, 8, 12)
+                       for n, N, K in (("qkv", 3456, 1152), ("proj", 1152, 1152), ("fc1", 4608, 1152), ("fc2", 1152, 4608))]
 elif os.environ.get("SWEEP_SHAPES") == "ksweep":     # one full round of 256x256 tiles (16 x 14), K from 9 to 144 K-tiles: slope and intercept
     SHAPES_OVERRIDE = [(f"k{k}", 4096, 3584, k) for k in (288, 576, 1152, 2304, 4608)]
 else:
