@@ -291,7 +291,12 @@ def roofline_pass(work, steps=2):
             "gflop_per_launch": round(r["flops"] / r["launches"] / 1e9, 3),
             "algorithmic_bytes_per_launch": round(r["bytes"] / r["launches"]) if r.get("bytes") else None,
             "share_of_gemm_time": round(r["ms"] / all_ms, 3),
-            "all_gemm_tflops": round(sum(v["flops"] for v in rows.values()) / (all_ms * 1e-3) / 1e12, 2)}
+            "all_gemm_tflops": round(sum(v["flops"] for v in rows.values()) / (all_ms * 1e-3) / 1e12, 2),
+            # every GEMM kernel of the step with at least 2 % of the GEMM time: [name, launches per step, average us, TFLOP/s, fraction of its peak]
+            "by_kernel": [[names[k], v["launches"] // steps, round(1e3 * v["ms"] / v["launches"], 1),
+                           round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1),
+                           round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (BF16X3_EQUIV_PEAK_TFLOPS if k >= 20 else F32_MFMA_PEAK_TFLOPS), 3)]
+                          for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] >= 0.02 * all_ms]}
 
 
 def measure_traffic(kernel, args):

@@ -122,6 +122,11 @@ int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_split, int l
 /* The one-wave-per-SIMD kernels (tiles 71 = 256x256, 72 = 512x128; csrc/gemm2.hip PIPE 5): mode 0 keeps the heuristics off them, 1 (default)
  * lets them choose; min_tiles = tiles a VAE conv launch must have before it takes them (default 256: one round of the chip). */
 int rgm_set_big_tiles(int mode, int min_tiles);
+/* K-sliced fc2 of a DiT block (rgm_dit_forward, pre-split arithmetic): 1 (default) = the kernel that reduces the K slices also writes the
+ * next block's adaLN-LayerNorm of each row (ref guided_diffusion/dit.py:334-336 -- same values as the separate LayerNorm launch,
+ * tests/test_gpu_fullsize.py), 0 = separate launches.  rgm_fused_reduce_ln_launches: how many launches took the fused route so far. */
+int rgm_set_fuse_reduce_ln(int on);
+long long rgm_fused_reduce_ln_launches(void);
 /* Workspace-backed decompositions of the pre-split GEMM (csrc/gemm4.hip stream-K, csrc/gemm2.hip deterministic split-K): the
  * scratch is caller memory like every other workspace.  rgm_gemm_streamk_workspace_bytes() bytes, 16-byte aligned; tile 0 lets
  * the heuristic choose, 47 forces the persistent stream-K kernel.  The entry zeroes the scratch's flag words on `stream`. */

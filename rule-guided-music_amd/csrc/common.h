@@ -143,6 +143,15 @@ struct GemmParams {
   // gemm2 raster: row-tiles per column sweep of the XCD-contiguous grouped raster (0 = 8).  The one-wave-per-SIMD kernels set it to
   // ~sqrt(tiles per XCD): an XCD's tiles then form a near-square block and its L2 fetches the fewest operand panels
   int raster_group = 0;
+  // K-slice launches of gemm2_launch (fc2 of a DiT block): the reduce kernel holds whole output rows, so it can also write the NEXT
+  // adaLN-LayerNorm of that row -- LN(row, ln_eps) * (1 + ln_scale) + ln_shift, the arithmetic of ln_mod_kernel, to ln_out -- and
+  // save that kernel's launch and its read of the row.  Optional: *ln_done (host) is set to 1 only when the launch took this route.
+  float* ln_out = nullptr;
+  const float* ln_shift = nullptr;
+  const float* ln_scale = nullptr;
+  int ln_mod_ld = 0, ln_rows_per_batch = 1, ln_out_split = 0;
+  float ln_eps = 0.f;
+  int* ln_done = nullptr;
   // arithmetic: -1 library default (rgm_set_gemm_precision), 0 fp32 MFMA, 1 bf16x3 split
   int prec = -1;
   // gemm2 (pre-split operands): write C in split-row format (N bf16 hi | N bf16 lo per row) for the next GEMM

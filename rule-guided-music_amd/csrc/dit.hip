@@ -445,32 +445,41 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
   RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, p.N, D, s));
   RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, p.N, L, D, 0, s));
   const bool v2 = rgm_get_gemm_precision() == 2;   // bf16x3 with pre-split operands: producers emit split rows, gemm2 consumes
+  // next_mod (fc2 only): shift of the NEXT block's first adaLN-LayerNorm (its scale is D further).  A K-sliced fc2 then writes that
+  // LayerNorm from its reduce kernel (GemmParams::ln_out) and *ln_done tells the loop to skip the separate launch.
   auto lin2 = [&](const float* A, const std::string& wkey, const float* bias, float* C, int N, int K, int act, int out_split,
-                  const float* gate, const float* res, int tile) {
+                  const float* gate, const float* res, int tile, const float* next_mod = nullptr, int* ln_done = nullptr) {
     GemmParams g;
     g.tile = tile;
     g.A = A; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
     g.M = p.M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
     g.sk_ws = p.sk; g.sk_ws_bytes = p.sk_bytes;
     if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
+    if (next_mod) {
+      g.ln_out = p.xm; g.ln_shift = next_mod; g.ln_scale = next_mod + D; g.ln_mod_ld = L; g.ln_rows_per_batch = T;
+      g.ln_out_split = 1; g.ln_eps = 1e-6f; g.ln_done = ln_done;
+    }
     return gemm2_launch(g, s);
   };
   if (v2) RGM_TRY(sk_begin(h, p.sk, s));
   static const int dit_exp = RGM_EXP_ENV("RGM_DIT_EXP");   // timing experiments (common.h): 1 = fc1 without GELU/split, 2 = block-0 weights everywhere
+  int xm_ready = 0;   // the previous block's fc2 has already written this block's first LayerNorm to plan.xm
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
     if (v2) {
       // every producer (adaLN-LayerNorm, attention, fc1's GELU epilogue) writes split rows; all four GEMMs run on the
       // LDS-DMA kernel (gemm2.hip picks the tile)
-      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
+      if (!xm_ready) RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
+      xm_ready = 0;
       RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, RGM_EXP_ENV("RGM_QKV_TILE")));
       RGM_TRY(rotary_attention_fwd(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, 1));
       RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 0));
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
       RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr,
                    RGM_EXP_ENV("RGM_FC1_TILE")));
-      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, RGM_EXP_ENV("RGM_FC2_TILE")));
+      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, RGM_EXP_ENV("RGM_FC2_TILE"),
+                   i + 1 < c.depth ? m + 6 * D : nullptr, &xm_ready));
       continue;
     }
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));

@@ -1305,6 +1305,94 @@ static int splitk_factor(const GemmParams& p) {
   return best;
 }
 
+static int g_fuse_reduce_ln = getenv("RGM_FUSE_REDUCE_LN") ? atoi(getenv("RGM_FUSE_REDUCE_LN")) : 1;
+static long long g_fused_reduce_ln_launches = 0;
+
+// splitk_reduce_kernel with one wave per output row, followed by the next adaLN-LayerNorm of that row (GemmParams::ln_out).  The row
+// arithmetic is splitk_reduce_kernel's (act 0, fp32 rows), the LayerNorm is ln_mod_kernel's (dit_kernels.hip) with the same lane <->
+// column mapping and the same reduction order: what lands in ln_out is what the separate kernel writes.
+template <int MAXV, int S>
+__global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __restrict__ P, GemmParams p) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = p.N >> 2;
+  const long long MN = (long long)p.M * p.N;
+  // one wave holds the row and there are only M waves (1024 at B = 4): every load of the row -- S partial sums, bias, gate, residual
+  // per chunk -- is issued before the first sum (compile-time S and MAXV), or the wave walks through 5 S dependent round trips
+  float4 part[MAXV][S], bq[MAXV], gq[MAXV], rq[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    const int col = c * 4;
+    const bool ok = c < nv;
+#pragma unroll
+    for (int sidx = 0; sidx < S; ++sidx)
+      part[i][sidx] = ok ? *reinterpret_cast<const float4*>(P + sidx * MN + (long long)row * p.N + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bq[i] = (ok && p.bias) ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gq[i] = (ok && p.gate) ? *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    rq[i] = (ok && p.res) ? *reinterpret_cast<const float4*>(p.res + (long long)row * p.ldres + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      const int col = c * 4;
+      float4 a = part[i][0];
+#pragma unroll
+      for (int sidx = 1; sidx < S; ++sidx) {
+        const float4 b = part[i][sidx];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      float w[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+      if (p.bias) { w[0] += bq[i].x; w[1] += bq[i].y; w[2] += bq[i].z; w[3] += bq[i].w; }
+      if (p.gate) { w[0] *= gq[i].x; w[1] *= gq[i].y; w[2] *= gq[i].z; w[3] *= gq[i].w; }
+      if (p.res) { w[0] += rq[i].x; w[1] += rq[i].y; w[2] += rq[i].z; w[3] += rq[i].w; }
+      v[i] = make_float4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = v[i];
+    }
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float D = (float)p.N;
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + p.ln_eps);
+  const long long mo = (long long)(row / p.ln_rows_per_batch) * p.ln_mod_ld;
+  float4* orow = reinterpret_cast<float4*>(p.ln_out + (long long)row * p.N);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c >= nv) continue;
+    float4 y = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+    const float4 sc = reinterpret_cast<const float4*>(p.ln_scale + mo)[c], sh = reinterpret_cast<const float4*>(p.ln_shift + mo)[c];
+    y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
+    if (p.ln_out_split) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 hi, lo;
+      hi[0] = (__bf16)y.x; hi[1] = (__bf16)y.y; hi[2] = (__bf16)y.z; hi[3] = (__bf16)y.w;
+      lo[0] = (__bf16)(y.x - (float)hi[0]); lo[1] = (__bf16)(y.y - (float)hi[1]);
+      lo[2] = (__bf16)(y.z - (float)hi[2]); lo[3] = (__bf16)(y.w - (float)hi[3]);
+      __bf16* rp = reinterpret_cast<__bf16*>(p.ln_out + (long long)row * p.N);
+      const int si = split_idx(c * 4);
+      *reinterpret_cast<bf16x4*>(rp + si) = hi;
+      *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
+    } else {
+      orow[c] = y;
+    }
+  }
+}
+
 // A and B in split-row format (see top).  tile: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 5 = 256x128 (8 waves)
 int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0 && (p.K & 31) == 0, "gemm2: bad shape M=%d N=%d K=%d (K%%32)", p.M, p.N, p.K);
@@ -1359,6 +1447,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
       const int n_main = tn_main * 256;
       if (tn_main >= 1 && n_main < p.N && (double)main_tiles / (double)(((main_tiles + 255) / 256) * 256) >= 0.9) {
         GemmParams pm = p, pr = p;
+        pm.ln_out = pr.ln_out = nullptr;            // column blocks: no whole rows in either launch
         pm.N = n_main;
         pm.tile = 71;
         pr.N = p.N - n_main;
@@ -1409,6 +1498,28 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     q.bias = nullptr; q.act = 0; q.alpha = 1.0f; q.gate = nullptr; q.res = nullptr; q.out_split = 0;
     q.tile = sk_tile;
     RGM_TRY(gemm2_launch(q, s));
+    // the reduce holds whole rows: with GemmParams::ln_out it also writes the next adaLN-LayerNorm of each row (same values as
+    // ln_mod_kernel on the reduced rows; rgm_set_fuse_reduce_ln(0) / RGM_FUSE_REDUCE_LN=0 keep the two kernels apart: A/B runs, the parity test)
+    if (g_fuse_reduce_ln && p.ln_out && p.ln_shift && p.ln_scale && p.act == 0 && !p.out_split && (p.N & 3) == 0 && p.N <= 1280 && p.ldc == p.N &&
+        (p.ln_mod_ld & 3) == 0 && (((uintptr_t)p.ln_shift | (uintptr_t)p.ln_scale | (uintptr_t)p.ln_out) & 15) == 0 &&
+        ((p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0) {
+      const dim3 grid((unsigned)cdiv(p.M, 4)), block(256);
+      bool launched = true;
+      switch (S) {           // the slice counts the heuristics produce for K = 4608 (144 K-tiles); anything else: two kernels
+      case 2: hipLaunchKernelGGL((splitk_reduce_ln_kernel<5, 2>), grid, block, 0, s, (const float*)partial, p); break;
+      case 3: hipLaunchKernelGGL((splitk_reduce_ln_kernel<5, 3>), grid, block, 0, s, (const float*)partial, p); break;
+      case 4: hipLaunchKernelGGL((splitk_reduce_ln_kernel<5, 4>), grid, block, 0, s, (const float*)partial, p); break;
+      case 6: hipLaunchKernelGGL((splitk_reduce_ln_kernel<5, 6>), grid, block, 0, s, (const float*)partial, p); break;
+      case 8: hipLaunchKernelGGL((splitk_reduce_ln_kernel<5, 8>), grid, block, 0, s, (const float*)partial, p); break;
+      default: launched = false;
+      }
+      if (launched) {
+        RGM_LAUNCH_CHECK();
+        if (p.ln_done) *p.ln_done = 1;
+        ++g_fused_reduce_ln_launches;
+        return RGM_OK;
+      }
+    }
     const long long total4 = (long long)p.M * (p.N >> 2);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, s, (const float*)partial, p, S);
     RGM_LAUNCH_CHECK();
@@ -1592,6 +1703,14 @@ extern "C" int rgm_set_big_tiles(int mode, int min_tiles) {
   rgm::g_big_min_tiles = min_tiles;
   return RGM_OK;
 }
+
+// K-sliced GEMMs with GemmParams::ln_out (fc2 of a DiT block): 1 = the reduce kernel also writes the next LayerNorm (default), 0 = two kernels
+extern "C" int rgm_set_fuse_reduce_ln(int on) {
+  RGM_REQUIRE(on == 0 || on == 1, "set_fuse_reduce_ln: %d (0 / 1)", on);
+  rgm::g_fuse_reduce_ln = on;
+  return RGM_OK;
+}
+extern "C" long long rgm_fused_reduce_ln_launches(void) { return rgm::g_fused_reduce_ln_launches; }
 
 // Sum of the algorithmic HBM bytes (operands read once, output written once) of the recorded launches of a pre-split kernel id.
 extern "C" double rgm_prof_bytes(int kernel) { return rgm::gemm2_prof_bytes(kernel); }

@@ -176,6 +176,36 @@ def test_xl_model_at_c3_and_c4_batch_sizes_is_row_independent(B, depth, precisio
         assert rel(big[i:i + 2].cpu().numpy(), small.cpu().numpy()) < tol * (4 if depth == 28 else 1), (i, rec.n)
 
 
+@pytest.mark.parametrize("B", [4, 8, 16])
+def test_fc2_reduce_with_the_next_layernorm_equals_the_two_kernels(B):
+    """fc2 of a block runs as K slices at B = 4 / 8 / 16 (M = 1024 .. 4096 rows); the kernel that reduces the slices holds whole rows
+    and also writes the next block's adaLN-LayerNorm (GemmParams::ln_out, csrc/gemm2.hip; ref guided_diffusion/dit.py:334-336).
+    Same arithmetic in the same order as the separate LayerNorm launch: the outputs must be IDENTICAL with the fusion on and off,
+    and the library's counter must show that the fused route really ran (depth - 1 launches per forward)."""
+    from gpu_util import dev
+    from rgm import native as R
+    R.set_gemm_precision("bf16x3_presplit")          # K slices exist in the pre-split arithmetic only
+    depth = 4
+    m = _dit(dict(XL2, depth=depth), 3)
+    rng = np.random.RandomState(B)
+    x = dev(rng.randn(B, 4, 128, 16).astype(F32))
+    t = dev(rng.randint(0, 1000, size=B).astype(np.int64))
+    y = dev(rng.randint(0, 3, size=B).astype(np.int64))
+    try:
+        R.check(R.lib.rgm_set_fuse_reduce_ln(0))
+        n0 = R.lib.rgm_fused_reduce_ln_launches()
+        apart = m(x, t, y).clone()
+        assert R.lib.rgm_fused_reduce_ln_launches() == n0
+        R.check(R.lib.rgm_set_fuse_reduce_ln(1))
+        fused = m(x, t, y).clone()
+        assert R.lib.rgm_fused_reduce_ln_launches() == n0 + depth - 1, "fc2 did not take the K-slice route with the fused LayerNorm"
+    finally:
+        R.check(R.lib.rgm_set_fuse_reduce_ln(1))
+        R.set_gemm_precision("fp32")
+    assert bool(torch.isfinite(fused).all())
+    assert torch.equal(fused, apart), float((fused - apart).abs().max())
+
+
 def _vae(seed=2):
     from gpu_util import load_module
     from taming.models.klvae_pedal import AutoencoderKL
