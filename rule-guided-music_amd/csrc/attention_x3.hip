@@ -411,6 +411,22 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
 #endif
   ATTN_STAMP(0)
   request(0);
+  // ---- Q fragments of this wave's 32 queries (8 waves x 32 = 256 >= T): lane (query l31, half hh) holds Q[q][16j + 8hh .. +7].
+  // Requested HERE, before the table loop: that loop's LDS writes wait for its own loads and, loads returning in order, for block 0's
+  // as well -- Q requested after it was a second full round trip of every workgroup of the launch at the same moment.
+  const int q = wave * 32 + l31;
+  const int qc = min(q, T - 1);
+  float4 qraw[KS][2];
+  {
+    const float* qp = base + (long long)qc * D3;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int d0 = 16 * j + 8 * hh + 4 * u;
+        qraw[j][u] = d0 < HD ? *reinterpret_cast<const float4*>(qp + d0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+  }
   {
     // entry e = (position, chunk) holds the factors of channels 4 chunk .. +3 = table elements 2e, 2e+1: both tables are read as
     // contiguous float4 (two entries each) when they are 16-byte aligned
@@ -428,21 +444,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
       }
     }
   }
-  // ---- Q fragments of this wave's 32 queries (8 waves x 32 = 256 >= T): lane (query l31, half hh) holds Q[q][16j + 8hh .. +7]
   const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;   // log2 domain (see above)
-  const int q = wave * 32 + l31;
   bf16x8 qh[KS], ql[KS];
   {
-    const int qc = min(q, T - 1);
-    const float* qp = base + (long long)qc * D3;
-    float4 qraw[KS][2];
-#pragma unroll
-    for (int j = 0; j < KS; ++j)
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int d0 = 16 * j + 8 * hh + 4 * u;
-        qraw[j][u] = d0 < HD ? *reinterpret_cast<const float4*>(qp + d0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
     __syncthreads();                         // the rotary table is complete
 #pragma unroll
     for (int j = 0; j < KS; ++j) {
