@@ -1177,6 +1177,14 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
       attrd = true;
     }
     hipLaunchKernelGGL(kd, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
+  } else if (PIPE == 5 && p.conv_kmajor && g_dbg) {          // the channel-block-major conv of the one-wave-per-SIMD kernels (tools/conv_stamp.py)
+    auto kd = gemm2_kernel<BM, BN, WM, WN, PIPE == 5 ? 2 : 0, NSTAGE, 1, PIPE>;
+    static bool attrd2 = false;
+    if (lds > 65536 && !attrd2) {
+      RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attrd2 = true;
+    }
+    hipLaunchKernelGGL(kd, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
   } else
 #endif
   if (p.aload == 0)
