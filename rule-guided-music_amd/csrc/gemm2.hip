@@ -944,17 +944,18 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < p.M && col_ok) {
           if (p.gate) g4[j] = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
-          if (resb) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+          if (resb && exp != 8) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
         }
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int r = j * RPI + lr, row = row0 + j * RPI;
-        const float4 a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);
+        float4 a4 = make_float4(1.f, 2.f, 3.f, 4.f);
+        if (exp != 9) a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);
         if (row < p.M && col_ok) {
           const float v[4] = {(a4.x * p.alpha + bv.x) * g4[j].x + r4[j].x, (a4.y * p.alpha + bv.y) * g4[j].y + r4[j].y,
                               (a4.z * p.alpha + bv.z) * g4[j].z + r4[j].z, (a4.w * p.alpha + bv.w) * g4[j].w + r4[j].w};
-          if (p.stats) {
+          if (p.stats && exp != 7) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
               gs[q4] += (double)v[q4];
@@ -962,6 +963,66 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
             }
           }
           store_row(row, v);
+        }
+      }
+    };
+    // The big tiles (one slab at a time, 4 slabs per wave): linear_rows unrolled 16 x 4 times is ~100 KB of straight-line code that one
+    // wave per SIMD executes at the speed its instructions arrive -- 19 k cycles per slab on the residual convs of the VAE whatever was
+    // removed from it (tools/conv_stamp.py with RGM_GEMM2_EXP 4 / 7 / 8 / 9: no stores / sums / residual loads / slab reads, 77-85 k cycles
+    // of epilogue after 150 k of K loop every time).  Rolled instead: the slab's residual rows are requested up front as before, parked in
+    // a second LDS slab beside the accumulators', and a 4-row loop reads both.  A 32-row slab meets at most two gate rows
+    // (rows_per_gate >= 32): both are loaded before the loop.
+    constexpr bool STAGED_LINEAR = !ALL_IM && (size_t)2 * NW * 32 * WCOLS * 4 <= (size_t)NSTAGE * STAGE;
+    auto staged_linear_rows = [&](const float* slab, float* rslab, int row0, int slab_row0) {
+      float4 g_lo = make_float4(1.f, 1.f, 1.f, 1.f), g_hi = g_lo;
+      int bnd = 0x7fffffff;
+      if (p.gate) {
+        const int g0 = slab_row0 / p.rows_per_gate, glast = (p.M - 1) / p.rows_per_gate;
+        bnd = (g0 + 1) * p.rows_per_gate;
+        if (col_ok) {
+          g_lo = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0, glast) * p.gate_ld + col);
+          g_hi = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0 + 1, glast) * p.gate_ld + col);
+        }
+      }
+      {
+        float4 r4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int row = row0 + j * RPI;
+          r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row < p.M && col_ok && resb && exp != 8) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(rslab + (j * RPI + lr) * WCOLS + lc) = r4[j];
+      }
+      asm volatile("" : "+v"(g_lo.x), "+v"(g_lo.y), "+v"(g_lo.z), "+v"(g_lo.w), "+v"(g_hi.x), "+v"(g_hi.y), "+v"(g_hi.z), "+v"(g_hi.w));
+      constexpr int U = 4;
+      static_assert(NJ % U == 0, "row loop unroll must divide the rows of a slab");
+#pragma unroll 1
+      for (int j0 = 0; j0 < NJ; j0 += U) {
+        float4 a4s[U], r4s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          a4s[u] = *reinterpret_cast<const float4*>(slab + ((j0 + u) * RPI + lr) * WCOLS + lc);
+          r4s[u] = *reinterpret_cast<const float4*>(rslab + ((j0 + u) * RPI + lr) * WCOLS + lc);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int row = row0 + (j0 + u) * RPI;
+          if (row < p.M && col_ok) {
+            const float4 a4 = a4s[u], rr = r4s[u];
+            const float4 g = row < bnd ? g_lo : g_hi;
+            const float v[4] = {(a4.x * p.alpha + bv.x) * g.x + rr.x, (a4.y * p.alpha + bv.y) * g.y + rr.y,
+                                (a4.z * p.alpha + bv.z) * g.z + rr.z, (a4.w * p.alpha + bv.w) * g.w + rr.w};
+            if (p.stats && exp != 7) {
+#pragma unroll
+              for (int q4 = 0; q4 < 4; ++q4) {
+                gs[q4] += (double)v[q4];
+                gs[4 + q4] += (double)v[q4] * (double)v[q4];
+              }
+            }
+            store_row(row, v);
+          }
         }
       }
     };
@@ -990,8 +1051,19 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
           if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           estamp(1);
         }
-        if (linear) linear_rows(stg, row_w + decltype(im_c)::value * 32);
-        else rolled_rows(stg, row_w + decltype(im_c)::value * 32, NJ);
+        if (linear) {
+          bool staged = false;
+          if constexpr (STAGED_LINEAR) {
+            if (!p.gate || p.rows_per_gate >= 32) {
+              staged_linear_rows(stg, reinterpret_cast<float*>(ring) + (NW + wave) * 32 * WCOLS, row_w + decltype(im_c)::value * 32,
+                                 m0 + arow0 + decltype(im_c)::value * 32);
+              staged = true;
+            }
+          }
+          if (!staged) linear_rows(stg, row_w + decltype(im_c)::value * 32);
+        } else {
+          rolled_rows(stg, row_w + decltype(im_c)::value * 32, NJ);
+        }
         if (decltype(im_c)::value == 0) estamp(2);
         if (decltype(im_c)::value == 1) estamp(3);
       });
@@ -1429,9 +1501,11 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     const long long total = (long long)tm * tn;
     const long long rounds = (total + 255) / 256;
     const double waste = (double)((long long)tn * 256 - p.N) / ((double)tn * 256);      // columns of the edge tiles beyond N
-    // one (partial) round: from 150 tiles up the 256x256 kernel beats every 128-row kernel (B = 32 sweep, profiles/r03_tile71_sweep_b32.txt:
+    // one (partial) round: from 140 tiles up the 256x256 kernel beats every 128-row kernel (B = 32 sweep, profiles/r03_tile71_sweep_b32.txt:
     // proj 160 tiles 74 us against 89 / 103, fc2 240 against 307 / 264); several rounds: the last one at least 84 % full
-    const bool fills = rounds == 1 ? total >= 150 : (double)total / (double)(rounds * 256) >= 0.84;
+    // (fc1 at B = 8, 144 tiles, GELU + split output, cold weights: 74.4 us against 82.8-92.4 on the 128-row kernels, tools/fc1_mid_tiles.py;
+    // qkv at B = 8, 112 tiles, stays on one round of 128x128)
+    const bool fills = rounds == 1 ? total >= 140 : (double)total / (double)(rounds * 256) >= 0.84;
     if (fills && waste <= 0.11) {
       GemmParams q = p;
       q.tile = 71;
