@@ -776,6 +776,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   // per 8 lanes, instead of 64 dword stores of two half-lines each (tools/gemm_stamp.py: the scalar epilogue cost
   // 18-34k cycles per tile, a third of the tile's lifetime).
   if (vec) {
+    // lane coordinates re-derived from the thread index behind an opaque copy: the one-wave-per-SIMD kernels have no register to carry
+    // them through the K loop, and the compiler parked `hh` in scratch -- one scratch_load + s_waitcnt vmcnt(0) in front of every row
+    // loop, i.e. every slab waited for the previous slab's stores to retire
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int lane = tid_e & 63, l31 = tid_e & 31, hh = (tid_e >> 5) & 1;
     constexpr int WCOLS = TN * 32, LPR = WCOLS / 4, RPI = 64 / LPR;   // lanes per row, rows per wave-instruction
     static_assert(NW * 32 * WCOLS * 4 <= NSTAGE * STAGE, "epilogue slab must fit in the ring");
     __syncthreads();                                                  // every wave is done reading the last stage
@@ -950,8 +956,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int r = j * RPI + lr, row = row0 + j * RPI;
-        float4 a4 = make_float4(1.f, 2.f, 3.f, 4.f);
-        if (exp != 9) a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);
+        const float4 a4 = *reinterpret_cast<const float4*>(slab + r * WCOLS + lc);
         if (row < p.M && col_ok) {
           const float v[4] = {(a4.x * p.alpha + bv.x) * g4[j].x + r4[j].x, (a4.y * p.alpha + bv.y) * g4[j].y + r4[j].y,
                               (a4.z * p.alpha + bv.z) * g4[j].z + r4[j].z, (a4.w * p.alpha + bv.w) * g4[j].w + r4[j].w};
@@ -973,29 +978,23 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // a second LDS slab beside the accumulators', and a 4-row loop reads both.  A 32-row slab meets at most two gate rows
     // (rows_per_gate >= 32): both are loaded before the loop.
     constexpr bool STAGED_LINEAR = !ALL_IM && (size_t)2 * NW * 32 * WCOLS * 4 <= (size_t)NSTAGE * STAGE;
-    auto staged_linear_rows = [&](const float* slab, float* rslab, int row0, int slab_row0) {
-      float4 g_lo = make_float4(1.f, 1.f, 1.f, 1.f), g_hi = g_lo;
-      int bnd = 0x7fffffff;
-      if (p.gate) {
-        const int g0 = slab_row0 / p.rows_per_gate, glast = (p.M - 1) / p.rows_per_gate;
-        bnd = (g0 + 1) * p.rows_per_gate;
-        if (col_ok) {
-          g_lo = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0, glast) * p.gate_ld + col);
-          g_hi = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0 + 1, glast) * p.gate_ld + col);
-        }
-      }
-      {
-        float4 r4[NJ];
+    // The order of the memory operations is the point (vmcnt retires in order, loads and stores alike).  Per slab:
+    //   accumulators -> LDS slab | wait for this slab's residual rows (LDS-DMA into a second slab: no registers, no compiler-placed
+    //   wait) | pass 1, LDS -> LDS: (acc * alpha + bias) * gate + residual, GroupNorm sums | LDS-DMA of the NEXT slab's residual rows |
+    //   pass 2: LDS -> global stores.
+    // The next slab's rows are requested before this slab's stores are issued, so the wait for them is s_waitcnt vmcnt(<stores of
+    // one slab>) and never waits for a store.  With the residual loads behind the previous slab's stores (linear_rows) every slab
+    // sat out its own round trip AND the previous slab's last store: 15-19 k cycles per slab (tools/conv_stamp.py).
+    auto staged_dma_res = [&](int row0, float* rslab) {
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          const int row = row0 + j * RPI;
-          r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (row < p.M && col_ok && resb && exp != 8) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
-        }
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) *reinterpret_cast<float4*>(rslab + (j * RPI + lr) * WCOLS + lc) = r4[j];
+      for (int j = 0; j < NJ; ++j) {
+        const int row = row0 + j * RPI;
+        const float* src = (resb && row < p.M && col_ok && exp != 8) ? resb + (long long)row * p.ldres + col
+                                                                      : reinterpret_cast<const float*>(zero_page) + lc;
+        dma16(src, reinterpret_cast<char*>(rslab) + j * 1024);
       }
-      asm volatile("" : "+v"(g_lo.x), "+v"(g_lo.y), "+v"(g_lo.z), "+v"(g_lo.w), "+v"(g_hi.x), "+v"(g_hi.y), "+v"(g_hi.z), "+v"(g_hi.w));
+    };
+    auto staged_pass1 = [&](float* slab, const float* rslab, int row0, float4 g_lo, float4 g_hi, int bnd) {
       constexpr int U = 4;
       static_assert(NJ % U == 0, "row loop unroll must divide the rows of a slab");
 #pragma unroll 1
@@ -1009,18 +1008,34 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
           const int row = row0 + (j0 + u) * RPI;
-          if (row < p.M && col_ok) {
-            const float4 a4 = a4s[u], rr = r4s[u];
-            const float4 g = row < bnd ? g_lo : g_hi;
-            const float v[4] = {(a4.x * p.alpha + bv.x) * g.x + rr.x, (a4.y * p.alpha + bv.y) * g.y + rr.y,
-                                (a4.z * p.alpha + bv.z) * g.z + rr.z, (a4.w * p.alpha + bv.w) * g.w + rr.w};
-            if (p.stats && exp != 7) {
+          const float4 a4 = a4s[u], rr = r4s[u];
+          const float4 g = row < bnd ? g_lo : g_hi;
+          const float v[4] = {(a4.x * p.alpha + bv.x) * g.x + rr.x, (a4.y * p.alpha + bv.y) * g.y + rr.y,
+                              (a4.z * p.alpha + bv.z) * g.z + rr.z, (a4.w * p.alpha + bv.w) * g.w + rr.w};
+          if (p.stats && exp != 7 && row < p.M && col_ok) {
 #pragma unroll
-              for (int q4 = 0; q4 < 4; ++q4) {
-                gs[q4] += (double)v[q4];
-                gs[4 + q4] += (double)v[q4] * (double)v[q4];
-              }
+            for (int q4 = 0; q4 < 4; ++q4) {
+              gs[q4] += (double)v[q4];
+              gs[4 + q4] += (double)v[q4] * (double)v[q4];
             }
+          }
+          *reinterpret_cast<float4*>(slab + ((j0 + u) * RPI + lr) * WCOLS + lc) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    };
+    auto staged_pass2 = [&](auto full_c, const float* slab, int row0) {
+      constexpr bool FULL = decltype(full_c)::value != 0;
+      constexpr int U = 4;
+#pragma unroll 1
+      for (int j0 = 0; j0 < NJ; j0 += U) {
+        float4 a4s[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a4s[u] = *reinterpret_cast<const float4*>(slab + ((j0 + u) * RPI + lr) * WCOLS + lc);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int row = row0 + (j0 + u) * RPI;
+          if (FULL || (row < p.M && col_ok)) {
+            const float v[4] = {a4s[u].x, a4s[u].y, a4s[u].z, a4s[u].w};
             store_row(row, v);
           }
         }
@@ -1045,24 +1060,61 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         }
       };
       estamp(0);
+      if (STAGED_LINEAR && linear) {       // (launch2 requires rows_per_gate >= 32 of these tiles)
+        if constexpr (STAGED_LINEAR) {
+          float* rslab = reinterpret_cast<float*>(ring) + (NW + wave) * 32 * WCOLS;
+          const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
+          // gate rows of all TM slabs up front (a 32-row slab meets at most two): nothing is outstanding yet, so the wait for them is free
+          float4 g_lo[TM], g_hi[TM];
+          int bnd[TM];
+          static_for<0, TM>([&](auto im_c) {
+            constexpr int im = decltype(im_c)::value;
+            g_lo[im] = g_hi[im] = make_float4(1.f, 1.f, 1.f, 1.f);
+            bnd[im] = 0x7fffffff;
+            if (p.gate) {
+              const int g0 = (m0 + arow0 + im * 32) / p.rows_per_gate, glast = (p.M - 1) / p.rows_per_gate;
+              bnd[im] = (g0 + 1) * p.rows_per_gate;
+              if (col_ok) {
+                g_lo[im] = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0, glast) * p.gate_ld + col);
+                g_hi[im] = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0 + 1, glast) * p.gate_ld + col);
+              }
+            }
+          });
+          staged_dma_res(row_w, rslab);
+          static_for<0, TM>([&](auto im_c) {
+            constexpr int im = decltype(im_c)::value;
+            write_slab(im_c, stg);
+            if (im == 0) {
+              if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+              estamp(1);
+            }
+            // this slab's residual rows have landed: only the stores of the previous slab's pass 2 were issued after their DMA
+            if (im == 0 || !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (p.out_split) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
+            staged_pass1(stg, rslab, row_w + im * 32, g_lo[im], g_hi[im], bnd[im]);
+            if constexpr (im + 1 < TM) {
+              asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // pass 1 has read the residual slab: the DMA may overwrite it
+              staged_dma_res(row_w + (im + 1) * 32, rslab);
+            }
+            if (full) staged_pass2(std::integral_constant<int, 1>{}, stg, row_w + im * 32);
+            else staged_pass2(std::integral_constant<int, 0>{}, stg, row_w + im * 32);
+            if (im == 0) estamp(2);
+            if (im == 1) estamp(3);
+          });
+        }
+      } else
       static_for<0, TM>([&](auto im_c) {
         write_slab(im_c, stg);
         if (decltype(im_c)::value == 0) {
           if (DBG) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           estamp(1);
         }
-        if (linear) {
-          bool staged = false;
-          if constexpr (STAGED_LINEAR) {
-            if (!p.gate || p.rows_per_gate >= 32) {
-              staged_linear_rows(stg, reinterpret_cast<float*>(ring) + (NW + wave) * 32 * WCOLS, row_w + decltype(im_c)::value * 32,
-                                 m0 + arow0 + decltype(im_c)::value * 32);
-              staged = true;
-            }
-          }
-          if (!staged) linear_rows(stg, row_w + decltype(im_c)::value * 32);
-        } else {
+        if constexpr (STAGED_LINEAR) {
           rolled_rows(stg, row_w + decltype(im_c)::value * 32, NJ);
+        } else {
+          if (linear) linear_rows(stg, row_w + decltype(im_c)::value * 32);
+          else rolled_rows(stg, row_w + decltype(im_c)::value * 32, NJ);
         }
         if (decltype(im_c)::value == 0) estamp(2);
         if (decltype(im_c)::value == 1) estamp(3);
@@ -1229,6 +1281,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     if (fixed > 0) g = fixed;
     pr.raster_group = g < 1 ? 1 : (g > tm ? tm : g);
   }
+  RGM_REQUIRE(!p.gate || p.rows_per_gate >= 32 || BM * BN <= 128 * 128,
+              "gemm2: tiles above 128x128 take at most two gate rows per 32-row slab (rows_per_gate %d < 32)", p.rows_per_gate);
   Prof2 rec{};
   if (g2_prof_on) {
     RGM_CHECK_HIP(hipEventCreate(&rec.a));
