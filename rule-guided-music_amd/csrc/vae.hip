@@ -165,7 +165,7 @@ __global__ void gn_finalize_tiles_kernel(const double* __restrict__ tp, float* _
 // y = act((x - mean) * rstd * gamma + beta), act = swish (1) or identity (0); NHWC float4 pass
 __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ stats,
                                 const float* __restrict__ gamma, const float* __restrict__ beta, long long total4, int P, int C,
-                                int swish, int out_split) {
+                                int swish, int out_split, float* __restrict__ raw_split) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
   if (i >= total4) return;
   const int q = C >> 2;
@@ -175,6 +175,16 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
   const float mean = stats[(m * 32 + g) * 2], rstd = stats[(m * 32 + g) * 2 + 1];
   const float4 v = reinterpret_cast<const float4*>(x)[i];
   const float4 ga = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
+  if (raw_split) {   // the input itself as split rows, in the same pass (the 1x1 shortcut of a channel-changing ResnetBlock reads it)
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+    __bf16* px = reinterpret_cast<__bf16*>(raw_split + (i / q) * C);
+    *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4)) = hi;
+    *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4) + 32) = lo;
+  }
   float4 o;
   o.x = (v.x - mean) * rstd * ga.x + be.x;
   o.y = (v.y - mean) * rstd * ga.y + be.y;
@@ -538,6 +548,7 @@ struct VSlot {
   size_t off = 0, numel = 0;
   bool set = false;
   int conv3 = 0;  // 1: repack [co][ci][3][3] -> [co][9][ci]
+  int lin = 0;    // 1: 1x1 conv weight [cout][cin] of the decoder that also keeps a split-row copy "<key>.S" (pre-split GEMM, gemm2.hip)
   int cout = 0, cin = 0;
   bool derived = false;  // "<key>.S": split-row copy of a 3x3 weight for the pre-split conv GEMM (gemm2.hip), not a parameter
   int group = 0;         // 0: decoder + post_quant_conv (needed by decode), 1: encoder + quant_conv (needed by encode)
@@ -559,17 +570,27 @@ struct rgm_vae {
   const float* gp(const std::string& k) const { return garena + goff.at(k); }
 };
 
-static void vslot(rgm_vae* h, const std::string& key, size_t numel, int conv3 = 0, int cout = 0, int cin = 0) {
+static void vslot(rgm_vae* h, const std::string& key, size_t numel, int conv3 = 0, int cout = 0, int cin = 0, int lin = 0) {
   VSlot s;
   s.off = h->arena_floats;
   s.numel = numel;
   s.conv3 = conv3;
+  s.lin = (lin && cin % 32 == 0 && cout % 32 == 0 && h->cur_group == 0) ? 1 : 0;
   s.cout = cout;
   s.cin = cin;
   s.group = h->cur_group;
   h->slots[key] = s;
   h->arena_floats += (numel + 3) / 4 * 4;
   if (numel > h->stage_floats) h->stage_floats = numel;
+  if (s.lin) {
+    VSlot d;
+    d.off = h->arena_floats;
+    d.numel = numel;
+    d.derived = true;
+    d.set = true;
+    h->slots[key + ".S"] = d;
+    h->arena_floats += (numel + 3) / 4 * 4;
+  }
   if (conv3 && cin % 32 == 0 && h->cur_group == 0) {   // the encoder convs stay on the on-the-fly kernel
     VSlot d;
     d.off = h->arena_floats;
@@ -595,7 +616,7 @@ static void res_slots(rgm_vae* h, const std::string& p, int cin, int cout) {
   vslot(h, p + "conv2.weight", (size_t)cout * cout * 9, 1, cout, cout);
   vslot(h, p + "conv2.bias", cout);
   if (cin != cout) {
-    vslot(h, p + "nin_shortcut.weight", (size_t)cout * cin);
+    vslot(h, p + "nin_shortcut.weight", (size_t)cout * cin, 0, cout, cin, 1);
     vslot(h, p + "nin_shortcut.bias", cout);
   }
 }
@@ -616,7 +637,7 @@ extern "C" int rgm_vae_create(rgm_vae** out) {
   vslot(h, d + "mid.attn_1.norm.weight", bi);
   vslot(h, d + "mid.attn_1.norm.bias", bi);
   for (const char* nm : {"q", "k", "v", "proj_out"}) {
-    vslot(h, d + "mid.attn_1." + nm + ".weight", (size_t)bi * bi);
+    vslot(h, d + "mid.attn_1." + nm + ".weight", (size_t)bi * bi, 0, bi, bi, 1);
     vslot(h, d + "mid.attn_1." + nm + ".bias", bi);
   }
   res_slots(h, d + "mid.block_2.", bi, bi);
@@ -712,6 +733,10 @@ extern "C" int rgm_vae_set_param(rgm_vae* h, const char* key, const void* dptr, 
     RGM_CHECK_HIP(hipStreamSynchronize(0));
   } else {
     RGM_CHECK_HIP(hipMemcpy(h->arena + s.off, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice));
+    if (s.lin) {
+      RGM_TRY(split_rows_launch(h->arena + s.off, h->arena + h->slots.at(std::string(key) + ".S").off, s.cout, s.cin, s.cin, s.cin, 0));
+      RGM_CHECK_HIP(hipStreamSynchronize(0));
+    }
   }
   s.set = true;
   h->grad_ready = false;   // the input-gradient copies are stale: rgm_vae_enable_grad again
@@ -829,7 +854,7 @@ struct Ctx {
 
 // stats: where (mean, rstd) of the M x 32 groups go (kept for the backward when given; default the shared scratch)
 int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish, int out_split = 0,
-               float* stats = nullptr) {
+               float* stats = nullptr, float* raw_split = nullptr) {
   if (!stats) stats = c.p.stats;
   const int my = ++c.seq;
   if (c.tp_for == x && c.tp_seq == my - 1) {
@@ -845,7 +870,7 @@ int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string
   }
   const long long total4 = (long long)c.M * P * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, y, stats,
-                     c.h->p(key + ".weight"), c.h->p(key + ".bias"), total4, P, C, swish, out_split);
+                     c.h->p(key + ".weight"), c.h->p(key + ".bias"), total4, P, C, swish, out_split, raw_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
@@ -904,13 +929,22 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
   return gemm_launch(g, c.s);
 }
 
-int conv1(Ctx& c, const float* in, float* out, int rows, int Cin, int Cout, const std::string& key, const float* res) {
+// in_split: `in` holds split rows -> the pre-split LDS-DMA GEMM on the weight's ".S" copy (decoder 1x1 convs with Cin, Cout % 32 == 0)
+int conv1(Ctx& c, const float* in, float* out, int rows, int Cin, int Cout, const std::string& key, const float* res, int in_split = 0) {
   ++c.seq;
   GemmParams g;
   g.A = in; g.lda = Cin; g.B = c.h->p(key + ".weight"); g.ldb = Cin; g.C = out; g.ldc = Cout;
   g.M = rows; g.N = Cout; g.K = Cin; g.bias = c.h->p(key + ".bias");
   g.res = res; g.ldres = Cout;
+  if (in_split) {
+    g.B = c.h->p(key + ".weight.S");
+    return gemm2_launch(g, c.s);
+  }
   return gemm_launch(g, c.s);
+}
+static bool has_split_1x1(const Ctx& c, const std::string& key) {
+  static const int on = getenv("RGM_VAE_SPLIT_1X1") ? atoi(getenv("RGM_VAE_SPLIT_1X1")) : 1;   // 0: the fp32-operand kernel (A/B runs)
+  return on && c.split && c.h->slots.count(key + ".weight.S") != 0;
 }
 
 // ResnetBlock (taming model.py:78-137): out = shortcut(x) + conv2(swish(norm2(b))), b = conv1(swish(norm1(x))).
@@ -929,6 +963,16 @@ int resnet(Ctx& c, const float* x, float* b, float* hbuf, float* out, float* t1,
 // the three-buffer in-place form the plain decode / encode schedules use: cur <- block(cur)
 int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout, const std::string& key) {
   if (Cin == Cout) return resnet(c, cur, t2, nullptr, cur, t1, H, Cin, Cout, key);
+  if (has_split_1x1(c, key + "nin_shortcut")) {
+    // pre-split arithmetic: the shortcut runs on the LDS-DMA GEMM too.  norm1's pass over x also leaves x as split rows (t2), the
+    // shortcut turns them into nin(x) in x's own buffer, and conv2 adds that in place: three buffers, no extra pass over x.
+    const int P = H * H;
+    RGM_TRY(group_norm(c, cur, t1, P, Cin, key + "norm1", 1, 1, nullptr, t2));
+    RGM_TRY(conv1(c, t2, cur, c.M * P, Cin, Cout, key + "nin_shortcut", nullptr, 1));            // cur <- nin(x)
+    RGM_TRY(conv3(c, t1, t2, H, Cin, Cout, key + "conv1", 0, nullptr, 1));                          // t2 <- conv1(swish(norm1(x)))
+    RGM_TRY(group_norm(c, t2, t1, P, Cout, key + "norm2", 1, 1));
+    return conv3(c, t1, cur, H, Cout, Cout, key + "conv2", 0, cur, 1);                              // cur <- conv2(.) + nin(x)
+  }
   RGM_TRY(resnet(c, cur, t2, t2, t1, t1, H, Cin, Cout, key));   // conv2 has consumed t1 before nin writes it
   std::swap(cur, t1);
   return RGM_OK;
@@ -939,10 +983,11 @@ int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout
 int attn_block(Ctx& c, const float* cur, float* out, float* t1, const std::string& a, int C, float* st = nullptr) {
   const int M = c.M, rows = M * 256;
   hipStream_t s = c.s;
-  RGM_TRY(group_norm(c, cur, t1, 256, C, a + "norm", 0, 0, st));
-  RGM_TRY(conv1(c, t1, c.p.q, rows, C, C, a + "q", nullptr));
-  RGM_TRY(conv1(c, t1, c.p.k, rows, C, C, a + "k", nullptr));
-  RGM_TRY(conv1(c, t1, c.p.v, rows, C, C, a + "v", nullptr));
+  const int sp = has_split_1x1(c, a + "q") ? 1 : 0;   // pre-split arithmetic: the four 1x1 convs on the LDS-DMA GEMM
+  RGM_TRY(group_norm(c, cur, t1, 256, C, a + "norm", 0, sp, st));
+  RGM_TRY(conv1(c, t1, c.p.q, rows, C, C, a + "q", nullptr, sp));
+  RGM_TRY(conv1(c, t1, c.p.k, rows, C, C, a + "k", nullptr, sp));
+  RGM_TRY(conv1(c, t1, c.p.v, rows, C, C, a + "v", nullptr, sp));
   GemmParams g;  // scores[m] = q[m] . k[m]^T * C^-0.5
   g.A = c.p.q; g.lda = C; g.sA = 256LL * C; g.B = c.p.k; g.ldb = C; g.sB = 256LL * C;
   g.C = c.p.sc; g.ldc = 256; g.sC = 256LL * 256; g.M = 256; g.N = 256; g.K = C; g.batch = M;
@@ -955,6 +1000,10 @@ int attn_block(Ctx& c, const float* cur, float* out, float* t1, const std::strin
   o.A = c.p.sc; o.lda = 256; o.sA = 256LL * 256; o.B = c.p.vt; o.ldb = 256; o.sB = 256LL * C;
   o.C = t1; o.ldc = C; o.sC = 256LL * C; o.M = 256; o.N = C; o.K = 256; o.batch = M;
   RGM_TRY(gemm_launch(o, s));
+  if (sp) {   // vt is free once p.v has been formed: the attention output as split rows
+    RGM_TRY(split_rows_launch(t1, c.p.vt, rows, C, C, C, s));
+    return conv1(c, c.p.vt, out, rows, C, C, a + "proj_out", cur, 1);
+  }
   return conv1(c, t1, out, rows, C, C, a + "proj_out", cur);  // x + proj_out(o)
 }
 }  // namespace
