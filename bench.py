@@ -299,6 +299,45 @@ def roofline_pass(work, steps=2):
                           for k, v in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]) if v["ms"] >= 0.02 * all_ms]}
 
 
+def power_pass(work, seconds=2.0):
+    """Socket power and shader clock while the workload's steps run back to back for `seconds` (its own pass, after the timed regions):
+    `rocm-smi --showpower --showclocks` sampled from a thread.  The one-wave-per-SIMD GEMMs sit at the board's power limit on real
+    operands (profiles/r03_power_probe.txt): the clock the board sustains, not the nominal 2.4 GHz, is what the MFMA peak scales with."""
+    import subprocess
+    import threading
+    stop, out = threading.Event(), []
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                t = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                pw = [float(l.split(":")[-1]) for l in t.splitlines() if "Power (W)" in l]
+                ck = [float(l.split("(")[-1].split("Mhz")[0]) for l in t.splitlines() if "sclk" in l]
+                if pw and ck:
+                    out.append((pw[0], ck[0]))
+            except Exception:
+                return
+
+    for _ in range(3):
+        work.step()
+    torch.cuda.synchronize()
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.time()
+    while time.time() - t0 < seconds:
+        work.step()
+        torch.cuda.synchronize()
+    stop.set()
+    th.join(timeout=15)
+    busy = sorted(out[1:])                                      # the first sample may predate the load
+    if len(busy) < 2:
+        return None
+    pw = sorted(p for p, _ in busy)[len(busy) // 2]
+    ck = sorted(c for _, c in busy)[len(busy) // 2]
+    return {"socket_power_w_median": pw, "sclk_mhz_median": ck, "samples": len(busy),
+            "how": "rocm-smi --showpower --showclocks sampled while the steps of this workload ran back to back for %.1f s" % seconds}
+
+
 def measure_traffic(kernel, args):
     """HBM bytes per launch of `kernel` measured IN SITU: this same workload re-run as a child under `rocprofv3 --pmc` (FETCH_SIZE and
     WRITE_SIZE in SEPARATE passes, --kernel-trace only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes), every dispatch of the
@@ -607,6 +646,16 @@ def main():
             roof["traffic_over_algorithmic"] = round(tb / max(1.0, roof.get("algorithmic_bytes_per_launch", 0) or 1.0), 3) if roof.get("algorithmic_bytes_per_launch") else None
         else:
             roof["traffic_detail"] = {"method": "profiles/traffic.json lookup (in-situ measurement unavailable: %s)" % detail}
+    if roof is not None and rank == 0 and world == 1 and not args.no_extras and args.simulate_ranks <= 1:
+        try:
+            pw = power_pass(work)
+        except Exception as e:
+            log("power pass failed:", repr(e))
+            pw = None
+        if pw:
+            roof["power"] = pw
+            # the same fraction against the MFMA peak at the clock the board sustained over the whole step (nominal peak: 2.4 GHz)
+            roof["frac_at_sustained_clock"] = round(roof["frac"] * 2400.0 / max(pw["sclk_mhz_median"], 1.0), 4)
     extras = {}
     if args.workload == "c2" and not args.no_extras and args.simulate_ranks <= 1:
         def attempt(name, fn):
