@@ -366,6 +366,42 @@ def test_long_sequence_guided_step_at_xl_width(monkeypatch, prec_depth):
             assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
 
 
+_DECODE_SNIPPET = """
+import sys, numpy as np, torch
+sys.path[:0] = [{pkg!r}, {tests!r}]
+from rgm import native as R, synth
+from gpu_util import load_module
+from taming.models.klvae_pedal import AutoencoderKL
+from guided_diffusion.gaussian_diffusion import _decode
+R.set_gemm_precision("bf16x3_presplit")
+R.check(R.lib.rgm_set_big_tiles(1, {min_tiles}))
+vae = load_module(AutoencoderKL(), synth.vae_state_dict(2, encoder=True))
+z = torch.from_numpy(np.random.RandomState(5).randn({n}, 4, 128, 16).astype(np.float32) * 0.8).cuda()
+np.save({out!r}, _decode(z, vae, scale_factor=1.2465).cpu().numpy())
+"""
+
+
+@pytest.mark.parametrize("n,min_tiles", [(2, 256), (2, 1)])
+def test_decoder_1x1_convs_on_the_presplit_gemm_match_the_fp32_operand_kernel(tmp_path, n, min_tiles):
+    """Pre-split arithmetic: the decoder's 1x1 convs (attention q / k / v / proj_out, nin_shortcut) run on the LDS-DMA GEMM from split-row
+    weight copies, a channel-changing ResnetBlock computes its shortcut first, in x's own buffer (csrc/vae.hip; ref taming model.py:117-137,
+    :140-192).  RGM_VAE_SPLIT_1X1=0 keeps them on the fp32-operand kernel and the old order: the decoded rolls must agree -- with the
+    heuristic tiles of a small input and with the big-tile kernels forced (rgm_set_big_tiles(1, 1))."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for flag in ("0", "1"):
+        out = str(tmp_path / f"roll_{flag}.npy")
+        code = _DECODE_SNIPPET.format(pkg=os.path.join(root, "rule-guided-music_amd"), tests=os.path.join(root, "tests"), n=n,
+                                      min_tiles=min_tiles, out=out)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, RGM_VAE_SPLIT_1X1=flag))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(np.load(out))
+    from gpu_util import rel
+    assert np.isfinite(outs[1]).all()
+    assert rel(outs[1], outs[0]) < 2e-5, rel(outs[1], outs[0])
+
+
 def test_two_rank_scg_bench_control_flow_on_one_device():
     """The command the 2-GPU test runs, with both ranks on this one device over gloo (RGM_BENCH_ONE_DEVICE=1: plumbing, never a
     measurement): the sharded search step, both collectives, the same-winners check and the JSON line's shape."""
