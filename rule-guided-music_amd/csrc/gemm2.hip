@@ -1596,6 +1596,27 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
         return gemm2_launch(pr, s);
       }
     }
+    // the same along M when N is narrow (proj / fc2, 5 column tiles, at C5's 112-window batches: 560 tiles = 2.19 rounds): whole
+    // rounds of row tiles on this kernel, the leftover rows through the heuristic again.  A gate row never straddles the cut.
+    if (S == 1 && total > 256 && tn <= 128) {
+      const int tm_main = (int)((total / 256) * 256 / tn);
+      const long long main_tiles = (long long)tm_main * tn;
+      const long long rows_main = (long long)tm_main * 256;
+      if (tm_main >= 1 && rows_main < p.M && (double)main_tiles / (double)(((main_tiles + 255) / 256) * 256) >= 0.9 &&
+          (!p.gate || (p.rows_per_gate > 0 && rows_main % p.rows_per_gate == 0))) {
+        GemmParams pm = p, pr = p;
+        pm.ln_out = pr.ln_out = nullptr;            // the caller's fused LayerNorm needs ONE launch to own every row
+        pm.M = (int)rows_main;
+        pm.tile = 71;
+        pr.M = p.M - (int)rows_main;
+        pr.A = p.A + rows_main * p.lda;
+        pr.C = p.C + rows_main * p.ldc;
+        if (p.res) pr.res = p.res + rows_main * p.ldres;
+        if (p.gate) pr.gate = p.gate + (rows_main / p.rows_per_gate) * p.gate_ld;
+        RGM_TRY(gemm2_launch(pm, s));
+        return gemm2_launch(pr, s);
+      }
+    }
   }
   if (S == 1 && !p.stats) S = splitk_factor(p);
   if (S == 1 && p.tile == 0 && p.sk_ws && !p.stats && !p.aload && p.batch == 1 && p.act < 3 && (p.K >> 5) >= 96 &&

@@ -111,7 +111,8 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
 
 @pytest.mark.parametrize("M,N,K,T", [(3072, 1152, 4608, 128), (7168, 3456, 1152, 256), (3072, 4608, 1152, 128), (4096, 4608, 1152, 256),
                                      (4096, 1152, 4608, 256), (16384, 1152, 1152, 256), (7168, 1152, 4608, 256), (2048 + 256, 3456, 1152, 256),
-                                     (2048, 4608, 1152, 256)])     # fc1 at B = 8: 144 tiles, one partial round of the 256x256 kernel
+                                     (2048, 4608, 1152, 256),      # fc1 at B = 8: 144 tiles, one partial round of the 256x256 kernel
+                                     (28672, 1152, 1152, 256), (28672 + 128, 1152, 4608, 128)])   # C5's 112 windows: whole rounds of row tiles + the leftover rows
 def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
     """gemm2_launch with tile 0 on the shapes the samplers produce (B = 16 / 64, the 28 + 24 windows of config 5): whole launches
     of 256x256 tiles, K slices + reduce, whole rounds of column tiles + the leftover columns through the heuristic again -- each with
