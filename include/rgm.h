@@ -140,7 +140,8 @@ int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int 
 /* The general pre-split entry: C = (act(alpha * A . B^T + bias)) * gate + res with explicit row strides (elements), the per-sample
  * adaLN gate gate[(row / rows_per_gate) * gate_ld + col] and a residual that may alias C (the proj / fc2 epilogue of a DiT block,
  * guided_diffusion/dit.py:332-336), explicit tile as in rgm_gemm_split (47 = persistent stream-K, 71.. = 256x256 tiles) and the
- * caller's scratch (NULL: no workspace-backed decomposition). */
+ * caller's scratch (NULL: no workspace-backed decomposition).  The tiles above 128x128 (5, 45, 71, 72, 73) take a gate only with
+ * rows_per_gate >= 32 (RGM_ERR_INVALID otherwise); tile 0 keeps finer gates on the 128-row kernels. */
 int rgm_gemm_split_epi(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
                        const float* bias, int act, float alpha, const float* gate, int gate_ld, int rows_per_gate,
                        const float* res, int ldres, int tile, int out_split, void* ws, size_t ws_bytes, void* stream);

@@ -1548,6 +1548,8 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   int S = 1;
   int sk_tile = 44;
   const bool big_ok = p.tile == 0 && g_big_tiles && !p.aload && p.batch == 1 && !p.stats && p.act < 3 && !p.aux && p.M >= 2048 &&
+                      (!p.gate || p.rows_per_gate >= 32) &&     // the big tiles' gate / residual epilogue: at most two gate rows per 32-row slab
+
                       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 &&
                       (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0;
   if (big_ok) {

@@ -148,6 +148,35 @@ def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
     assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, N), _ref(A, B, bias, 2, 1.0, None, 1, None)) < 3e-5
 
 
+def test_fine_grained_gate_stays_off_the_big_tiles():
+    """The big tiles' gate / residual epilogue loads two gate rows per 32-row slab: a gate finer than 32 rows must keep the heuristic on the
+    128-row kernels (right result, no 256x256 launch) and make an explicit big tile refuse."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    M, N, K, rpg = 4096, 1152, 1152, 8
+    rng = np.random.RandomState(11)
+    A = rng.randn(M, K).astype(F32)
+    B = (rng.randn(N, K) * 0.03).astype(F32)
+    bias = rng.randn(N).astype(F32)
+    gate = rng.randn(M // rpg, N).astype(F32)
+    res = rng.randn(M, N).astype(F32)
+    As, Bs = _split(A), _split(B)
+    bd, gd = dev(bias), dev(gate)
+    need = int(R.lib.rgm_gemm_streamk_workspace_bytes())
+    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
+    st = R.current_stream()
+    x = dev(res)
+    with _Recorded() as rec:
+        R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 1.0, R.ptr(gd), N, rpg,
+                                         R.ptr(x), N, 0, 0, R.ptr(ws), need, st))
+    assert rec.n[111] == 0, rec.n
+    assert rel(x.cpu().numpy(), _ref(A, B, bias, 0, 1.0, gate, rpg, res)) < 3e-5
+    status = R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 1.0, R.ptr(gd), N, rpg,
+                                      R.ptr(x), N, 71, 0, R.ptr(ws), need, st)
+    assert status != 0 and b"rows_per_gate" in R.lib.rgm_last_error()
+    torch.cuda.synchronize()
+
+
 def _dit(arch, seed):
     from gpu_util import load_module
     from guided_diffusion.dit import DiTRotary
