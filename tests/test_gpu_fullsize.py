@@ -148,6 +148,35 @@ def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
     assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, N), _ref(A, B, bias, 2, 1.0, None, 1, None)) < 3e-5
 
 
+@pytest.mark.parametrize("tile", [71, 72, 73])
+@pytest.mark.parametrize("rpg,gate_only,split_out", [(48, False, False), (40, True, False), (129, False, True), (32, False, False)])
+def test_big_tile_epilogue_with_gate_rows_that_cut_through_slabs(tile, rpg, gate_only, split_out):
+    """The gate / residual epilogue of the big tiles works slab by slab (32 rows) with the slab's two possible gate rows loaded up front and
+    the residual rows brought in by LDS-DMA: gate periods that are not multiples of 32 (48, 40, the classifier's 129 tokens) put the switch
+    inside slabs; also without a residual (zero-page DMA), with split-row output, and on a ragged M and N (partial tiles: guarded stores)."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    M, N, K = 2048 + 72, 1152, 1152
+    rng = np.random.RandomState(tile + rpg)
+    A, B = rng.randn(M, K).astype(F32), (rng.randn(N, K) * 0.03).astype(F32)
+    bias = rng.randn(N).astype(F32)
+    res = None if gate_only else rng.randn(M, N).astype(F32)
+    gate = rng.randn((M + rpg - 1) // rpg, N).astype(F32)
+    As, Bs, bd, gd = _split(A), _split(B), dev(bias), dev(gate)
+    st = R.current_stream()
+    x = torch.zeros(M, N, device="cuda") if gate_only else dev(res)
+    R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 0.7, R.ptr(gd), N, rpg,
+                                     None if gate_only else R.ptr(x), N, tile, 1 if split_out else 0, None, 0, st))
+    torch.cuda.synchronize()
+    ref = _ref(A, B, bias, 0, 0.7, gate, rpg, res)
+    if split_out:
+        raw = x.view(torch.bfloat16).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+        got = (raw[:, :, 0] + raw[:, :, 1]).reshape(M, N)
+    else:
+        got = x.cpu().numpy()
+    assert rel(got, ref) < 3e-5
+
+
 def test_fine_grained_gate_stays_off_the_big_tiles():
     """The big tiles' gate / residual epilogue loads two gate rows per 32-row slab: a gate finer than 32 rows must keep the heuristic on the
     128-row kernels (right result, no 256x256 launch) and make an explicit big tile refuse."""
