@@ -204,14 +204,11 @@ static int launch_attn(const float* qkv, float* o, const float* ct, const float*
   constexpr int TP = NKT * 32;
   // V strip + K strip; channel reads of the last (partial) 32-wide tile run past a V row into the
   // next row / the K strip, which is finite data feeding discarded accumulator rows only.
-  size_t lds = (size_t)(TP * HD + TP * (HD + 4)) * sizeof(float);
-  if (lds < 80 * 1024 + 512) lds = 80 * 1024 + 512;   // one workgroup per CU, enforced: see attention_x3.hip launch_attn_x3 (same kernel structure)
-  static bool attr_set = false;
+  const size_t lds = attn_lds_one_per_cu((size_t)(TP * HD + TP * (HD + 4)) * sizeof(float));   // one workgroup per CU (common.h)
   auto kern = rotary_attention_kernel<HD, NKT>;
-  if (!attr_set) {
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  static bool prepared = false;
+  if (!prepared) RGM_TRY(attn_prepare_kernel(kern, 512, lds, "rotary_attention_kernel"));
+  prepared = true;
   hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;

@@ -272,20 +272,16 @@ template <int HD, int NKT>
 static int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const float* ct,
                       const float* st, int N, int T, int heads, int rot_half, hipStream_t s) {
   constexpr int TP = NKT * 32, HDP = HD + 4;
-  // one workgroup per CU, enforced (>= 80.5 KiB): the same single-pass structure as the forward kernels, whose idle waves retire early
-  // at short T and let a second workgroup in -- see attention_x3.hip launch_attn_x3 for what that did to the forward
-  constexpr size_t ONE_PER_CU = 80 * 1024 + 512;
-  size_t lds_q = (size_t)2 * TP * HDP * sizeof(float);
-  size_t lds_kv = lds_q + (size_t)2 * TP * sizeof(float);
-  if (lds_q < ONE_PER_CU) lds_q = ONE_PER_CU;
-  if (lds_kv < ONE_PER_CU) lds_kv = ONE_PER_CU;
-  static bool attr_set = false;
+  // one workgroup per CU (common.h attn_prepare_kernel): the same single-pass structure as the forward kernels
+  const size_t lds_q = attn_lds_one_per_cu((size_t)2 * TP * HDP * sizeof(float));
+  const size_t lds_kv = attn_lds_one_per_cu((size_t)2 * TP * HDP * sizeof(float) + (size_t)2 * TP * sizeof(float));
   auto kq = attn_bwd_dq_kernel<HD, NKT>;
   auto kkv = attn_bwd_dkv_kernel<HD, NKT>;
-  if (!attr_set) {
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kq), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q));
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kkv), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv));
-    attr_set = true;
+  static bool prepared = false;
+  if (!prepared) {
+    RGM_TRY(attn_prepare_kernel(kq, 512, lds_q, "attn_bwd_dq_kernel"));
+    RGM_TRY(attn_prepare_kernel(kkv, 512, lds_kv, "attn_bwd_dkv_kernel"));
+    prepared = true;
   }
   hipLaunchKernelGGL(kq, dim3(N * heads), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
   RGM_LAUNCH_CHECK();

@@ -43,6 +43,35 @@ __device__ long long g_attn_real[2 * 1024];   // s_memrealtime (100 MHz) at entr
 #define ATTN_STAMP(i)
 #endif
 
+#ifdef RGM_ATTN_HAZARD_DBG   // tools/ubench/attn_hazard.hip: where a workgroup ran (CU, LDS base), when, and what its barrier saw
+struct AttnDbg {
+  unsigned hw_id, lds_alloc, xcc_id, arrivals;
+  unsigned long long t0, t1;
+};
+__device__ AttnDbg* g_attn_dbg = nullptr;   // [grid]
+__device__ int* g_attn_cnt = nullptr;       // [grid], zeroed by the host: staging-complete arrivals counted through global memory
+__device__ float* g_attn_dump = nullptr;    // [grid][waves][ATTN_DUMP_ITEMS][64]: Q fragments, max, sum, scores, probabilities of every lane
+#define ATTN_DUMP_ITEMS 57
+#define ATTN_DUMP(item, val)                                                                                             \
+  if (g_attn_dump) g_attn_dump[(((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * ATTN_DUMP_ITEMS + (item)) * 64 + lane] = (val);
+__device__ int g_attn_mode = 0;             // bit 0: cross-half exchanges by v_permlane32_swap instead of ds_bpermute; 1: s_nop before them; 2: s_nop after the PV chain
+#define ATTN_DBG_MODE(bit) (g_attn_mode & (1 << (bit)))
+#else
+#define ATTN_DBG_MODE(bit) 0
+#endif
+
+// the other half-wave's value of v (lane ^ 32) -- __shfl_xor(v, 32, 64) is a ds_bpermute_b32 through the LDS crossbar
+__device__ __forceinline__ float other_half(float v) {
+#ifdef RGM_ATTN_HAZARD_DBG
+  if (ATTN_DBG_MODE(1)) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+  if (ATTN_DBG_MODE(0)) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // r[0] = lanes 0-31's v, r[1] = lanes 32-63's
+    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+  }
+#endif
+  return __shfl_xor(v, 32, 64);
+}
+
 template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                   const float* __restrict__ cos_tab,
@@ -70,9 +99,20 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_real[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
   ATTN_STAMP(0)
+#ifdef RGM_ATTN_HAZARD_DBG
+  if (g_attn_dbg && tid == 0) {
+    AttnDbg& d = g_attn_dbg[blockIdx.x];
+    d.hw_id = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    d.lds_alloc = __builtin_amdgcn_s_getreg((31 << 11) | 6);
+    d.xcc_id = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+    d.t0 = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   // ---- stage K (rotated, split) and V (split, transposed, keys permuted); padded keys / channels are zeros
+  // The workgroup is 64 * (query tiles, at most 8) threads: every wave owns a query tile (launch_attn_x3).
+  const int nthr = blockDim.x;
   constexpr int CPR = KP / 4;               // float4 chunks per padded K row
-  for (int c = tid; c < TP * CPR; c += 512) {
+  for (int c = tid; c < TP * CPR; c += nthr) {
     const int key = c / CPR, ch = c - key * CPR, d0 = ch * 4;   // consecutive lanes -> one row's chunks (coalesced global reads)
     float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
     if (key < T && d0 < HD) {
@@ -114,20 +154,81 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
     }
   }
   ATTN_STAMP(1)
+#ifdef RGM_ATTN_HAZARD_DBG
+  if (g_attn_cnt) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if ((tid & 63) == 0) __hip_atomic_fetch_add(&g_attn_cnt[blockIdx.x], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#endif
   __syncthreads();
+#ifdef RGM_ATTN_HAZARD_DBG
+  if (g_attn_cnt && g_attn_dbg && tid == 0)
+    g_attn_dbg[blockIdx.x].arrivals = __hip_atomic_load(&g_attn_cnt[blockIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
   ATTN_STAMP(2)
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int nwaves = nthr >> 6;
   // scores are kept in the log2 domain (log2(e) folded into the query scale): p = 2^(s - max) is ONE v_exp_f32 per element
   // instead of the 8-op double-float exp of the fp32 kernel (its ~2e-7 argument error is 100x below the bf16x3 product error)
-  const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;
+  float scale = rsqrtf((float)HD) * 1.44269504088896340736f;
+#ifdef RGM_ATTN_HAZARD_DBG
+  if (ATTN_DBG_MODE(3)) scale = (HD == 72 ? 0.11785113019775793f : 0.125f) * 1.44269504088896340736f;   // no v_rsq_f32
+#endif
   const int nqt = (T + 31) >> 5;
 
-  for (int qt = wave; qt < nqt; qt += 8) {
+  for (int qt = wave; qt < nqt; qt += nwaves) {
     const int q = qt * 32 + l31;
     const int qc = min(q, T - 1);
     // ---- Q fragments: lane (query l31, half hh) holds Q[q][16j + 8hh .. +7], rotated, pre-scaled, split
     bf16x8 qh[KS], ql[KS];
+#ifdef RGM_ATTN_HAZARD_DBG
+    unsigned dbg_raw[6] = {0, 0, 0, 0, 0, 0}, dbg_cs[6] = {0, 0, 0, 0, 0, 0};   // the rotary chunks j < 3: raw loaded Q values / factors
+    if (ATTN_DBG_MODE(6) || ATTN_DBG_MODE(7)) {   // every load of the Q prologue issued and RETIRED before the first value is used
+      const float* qp = base + (long long)qc * D3;
+      float4 qraw[KS][2];
+      float2 cf[KS][2][2];
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d0 = 16 * j + 8 * hh + 4 * u;
+          qraw[j][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          cf[j][u][0] = cf[j][u][1] = make_float2(1.f, 1.f);
+          if (d0 < HD) {
+            qraw[j][u] = *reinterpret_cast<const float4*>(qp + d0);
+            if (d0 < R) {
+              const int pi = qc * rot_half + (d0 >> 1);
+              cf[j][u][0] = *reinterpret_cast<const float2*>(cos_tab + pi);
+              cf[j][u][1] = *reinterpret_cast<const float2*>(sin_tab + pi);
+            }
+          }
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (ATTN_DBG_MODE(6)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        float v8[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d0 = 16 * j + 8 * hh + 4 * u;
+          float4 v = qraw[j][u];
+          if (d0 < R) {
+            const float c0 = cf[j][u][0].x, c1 = cf[j][u][0].y, s0 = cf[j][u][1].x, s1 = cf[j][u][1].y;
+            const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            v.x = x0 * c0 - x1 * s0;
+            v.y = x1 * c0 + x0 * s0;
+            v.z = x2 * c1 - x3 * s1;
+            v.w = x3 * c1 + x2 * s1;
+          }
+          v8[4 * u] = v.x * scale; v8[4 * u + 1] = v.y * scale; v8[4 * u + 2] = v.z * scale; v8[4 * u + 3] = v.w * scale;
+        }
+        split8(v8, qh[j], ql[j]);
+      }
+    } else
+#endif
     {
       const float* qp = base + (long long)qc * D3;
 #pragma unroll
@@ -139,9 +240,29 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (d0 < HD) {
             v = *reinterpret_cast<const float4*>(qp + d0);
+#ifdef RGM_ATTN_HAZARD_DBG
+#endif
             if (d0 < R) {
               const int pi = qc * rot_half + (d0 >> 1);
-              const float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
+              float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
+#ifdef RGM_ATTN_HAZARD_DBG
+              if (ATTN_DBG_MODE(8)) {   // the same two 8-byte loads with destinations that may NOT be the address registers
+                float2 cc, ss;
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(cc) : "v"(cos_tab + pi) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(ss) : "v"(sin_tab + pi) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                c0 = cc.x; c1 = cc.y; s0 = ss.x; s1 = ss.y;
+              }
+              if (ATTN_DBG_MODE(9)) {   // control: the same code with the destination forced ONTO the address registers
+                unsigned long long ca = (unsigned long long)(cos_tab + pi), sa = (unsigned long long)(sin_tab + pi);
+                asm volatile("global_load_dwordx2 %0, %0, off" : "+v"(ca) : : "memory");
+                asm volatile("global_load_dwordx2 %0, %0, off" : "+v"(sa) : : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                c0 = __uint_as_float((unsigned)ca); c1 = __uint_as_float((unsigned)(ca >> 32));
+                s0 = __uint_as_float((unsigned)sa); s1 = __uint_as_float((unsigned)(sa >> 32));
+              }
+              if (j < 3) dbg_cs[j * 2 + u] = __float_as_uint(c0) ^ (__float_as_uint(s0) * 3u) ^ (__float_as_uint(c1) * 5u) ^ (__float_as_uint(s1) * 7u);
+#endif
               const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
               v.x = x0 * c0 - x1 * s0;
               v.y = x1 * c0 + x0 * s0;
@@ -149,12 +270,23 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
               v.w = x3 * c1 + x2 * s1;
             }
           }
+#ifdef RGM_ATTN_HAZARD_DBG
+          if (j >= 2) dbg_raw[(j - 2) * 2 + u] = __float_as_uint(v.x) ^ (__float_as_uint(v.y) * 3u) ^ (__float_as_uint(v.z) * 5u) ^ (__float_as_uint(v.w) * 7u);
+#endif
           v8[4 * u] = v.x * scale; v8[4 * u + 1] = v.y * scale; v8[4 * u + 2] = v.z * scale; v8[4 * u + 3] = v.w * scale;
         }
         split8(v8, qh[j], ql[j]);
       }
     }
     ATTN_STAMP(3)
+#ifdef RGM_ATTN_HAZARD_DBG
+    unsigned ck_q = 0;
+    float ck_s = 0.f, ck_p = 0.f;
+#pragma unroll
+    for (int j = 0; j < KS; ++j)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) ck_q ^= (reinterpret_cast<const unsigned*>(&qh[j])[w] * 31u + (unsigned)(j * 8 + w)) ^ (reinterpret_cast<const unsigned*>(&ql[j])[w] * 17u);
+#endif
     // ---- S^T[key][query] = K . Q^T
     f32x16 sacc[NKT];
 #pragma unroll
@@ -172,6 +304,12 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       }
     }
     ATTN_STAMP(4)
+#ifdef RGM_ATTN_HAZARD_DBG
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ck_s += sacc[kt][e] * (float)(1 + ((kt * 16 + e) & 7));
+#endif
     // ---- softmax over keys: register e of tile kt is key kt*32 + (e&3) + 8*(e>>2) + 4*hh
     float mx = -INFINITY;
     const int ktr = T >> 5, tr = T & 31;   // ragged tile index / valid keys in it (wave-uniform)
@@ -188,8 +326,23 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = fmaxf(mx, other_half(mx));
     float sum = 0.f;
+#ifdef RGM_ATTN_HAZARD_DBG
+    if (ATTN_DBG_MODE(4)) {   // every v_exp_f32 retired long before anything reads a probability
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sacc[kt][e] = __builtin_amdgcn_exp2f(sacc[kt][e] - mx);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sum += sacc[kt][e];
+    } else
+#endif
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -198,11 +351,18 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
         sacc[kt][e] = pv;
         sum += pv;
       }
-    sum += __shfl_xor(sum, 32, 64);
+    sum += other_half(sum);
     const float inv = 1.0f / sum;
     // natural-log sum-exp of the scaled scores, saved for the backward (scores here are in the log2 domain)
     if (lse && hh == 0 && q < T) lse[((long long)n * heads + head) * T + q] = (mx + log2f(sum)) * 0.693147180559945309417f;
     ATTN_STAMP(5)
+#ifdef RGM_ATTN_HAZARD_DBG
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) ck_p += sacc[kt][e] * (float)(1 + ((kt * 16 + e) & 7));
+    const float dbg_mx = mx, dbg_sum = sum;
+#endif
     // ---- O^T[d][query] = V^T . P^T ; A operand = V^T rows (d = lane&31), B operand = the probability registers, split
     f32x16 oacc[DT];
 #pragma unroll
@@ -230,10 +390,20 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[dt], 0, 0, 0);
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[dt], 0, 0, 0);
         }
+#ifdef RGM_ATTN_HAZARD_DBG
+        if (ATTN_DBG_MODE(5)) {   // nothing may overwrite ph / pl (B operands written by VALU) until the MFMAs that read them are long under way
+          __builtin_amdgcn_sched_barrier(0);
+          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the V^T reads of later key tiles from being hoisted (spills)
     }
     ATTN_STAMP(6)
+#ifdef RGM_ATTN_HAZARD_DBG
+    if (ATTN_DBG_MODE(2)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+#endif
     // ---- store: lane = query (row), registers 4g..4g+3 = 4 consecutive channels
     if (q < T) {
       float* op = o + ((long long)n * T + q) * D + head * HD;
@@ -259,10 +429,34 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           }
         }
     }
+#ifdef RGM_ATTN_HAZARD_DBG
+    ATTN_DUMP(0, __uint_as_float(ck_q))
+    ATTN_DUMP(1, dbg_mx)
+    ATTN_DUMP(2, dbg_sum)
+    ATTN_DUMP(3, ck_s)
+    ATTN_DUMP(4, ck_p)
+#pragma unroll
+    for (int i2 = 0; i2 < 6; ++i2) {
+      ATTN_DUMP(5 + i2, __uint_as_float(dbg_raw[i2]))
+      ATTN_DUMP(11 + i2, __uint_as_float(dbg_cs[i2]))
+    }
+    if constexpr (KS <= 5) {
+#pragma unroll
+      for (int j = 0; j < KS; ++j)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          ATTN_DUMP(17 + j * 8 + w, __uint_as_float(reinterpret_cast<const unsigned*>(&qh[j])[w]))
+          ATTN_DUMP(17 + j * 8 + 4 + w, __uint_as_float(reinterpret_cast<const unsigned*>(&ql[j])[w]))
+        }
+    }
+#endif
     ATTN_STAMP(7)
   }
 #ifdef RGM_ATTN_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_real[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef RGM_ATTN_HAZARD_DBG
+  if (g_attn_dbg && tid == 0) g_attn_dbg[blockIdx.x].t1 = __builtin_amdgcn_s_memrealtime();
 #endif
 }
 
@@ -271,20 +465,20 @@ static int launch_attn_x3(const float* qkv, float* o, const float* ct, const flo
                           float* lse, int out_split, hipStream_t s) {
   constexpr int KP = (HD + 15) / 16 * 16, TP = NKT * 32;
   size_t lds = (size_t)TP * (KP * 4 + 16) + (size_t)HD * (TP * 4 + 16);
-  // ONE workgroup per CU, enforced.  At T <= 128 the images take <= 80 KiB and two workgroups fit the 160 KiB of a CU: waves 4-7 have no
-  // query tile there and retire right after the staging barrier, the next workgroup moves in beside waves 0-3 -- and the workgroup that
-  // ran in the UPPER half of the LDS (the 2nd, 4th, ... on a CU; never the first or the last of a launch) sporadically returned wrong
-  // rows (1 launch in ~10 at N = 48, T = 128: errors of 0.1 on O(1) outputs; tools/race_block.py bisects a DiT block to this kernel,
-  // tools/race_probe.py shows it in the model; every LDS access of the kernel is inside its own allocation).  The mechanism is not
-  // established; asking for more than half of the LDS removes the co-residency and with it every wrong row (0 in 48 launches).
-  constexpr size_t ONE_PER_CU = 80 * 1024 + 512;
+  // ONE workgroup per CU, enforced (common.h attn_prepare_kernel).  At T <= 128 the images take <= 80 KiB, waves 4-7 have no
+  // query tile and retire right after the staging barrier, and a second workgroup would move in beside waves 0-3: the co-residency under
+  // which this kernel returned wrong rows in round 3 (1 launch in ~10 at N = 48, T = 128).
   static const int allow_two = RGM_EXP_ENV("RGM_ATTN_TWO_PER_CU");      // experiments only (common.h): reproduce the hazard
-  if (lds < ONE_PER_CU && !allow_two) lds = ONE_PER_CU;
-  static bool attr_set = false;
   auto kern = rotary_attention_x3_kernel<HD, NKT>;
-  if (!attr_set) {
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
+  if (allow_two) {
+    static bool attr2 = false;
+    if (!attr2) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr2 = true;
+  } else {
+    lds = attn_lds_one_per_cu(lds);
+    static bool prepared = false;
+    if (!prepared) RGM_TRY(attn_prepare_kernel(kern, 512, lds, "rotary_attention_x3_kernel"));
+    prepared = true;
   }
   hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
   RGM_LAUNCH_CHECK();
@@ -613,14 +807,14 @@ template <int HD>
 static int launch_attn_x3_blocked(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,
                                   float* lse, int out_split, hipStream_t s) {
   constexpr int KP = (HD + 15) / 16 * 16;
-  const size_t lds = 2 * ((size_t)64 * (KP * 4 + 16) + (size_t)HD * (64 * 4 + 16)) + (size_t)T * (rot_half / 2) * 16;   // + the rotary table
-  static bool attr_set = false;
+  // two block buffers + the rotary table; never less than the one-workgroup-per-CU request (hd = 64 with a short rotary table would fit twice)
+  const size_t need = 2 * ((size_t)64 * (KP * 4 + 16) + (size_t)HD * (64 * 4 + 16)) + (size_t)T * (rot_half / 2) * 16;
+  RGM_REQUIRE(need <= 160 * 1024, "attention: %zu bytes of LDS", need);
+  const size_t lds = attn_lds_one_per_cu(need);
   auto kern = rotary_attention_x3_blocked_kernel<HD>;
-  if (!attr_set) {
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
-  RGM_REQUIRE(lds <= 160 * 1024, "attention: %zu bytes of LDS", lds);
+  static size_t prepared_lds = 0;      // the occupancy check is per LDS size class: the request grows with T
+  if (prepared_lds != lds) RGM_TRY(attn_prepare_kernel(kern, 512, lds, "rotary_attention_x3_blocked_kernel"));
+  prepared_lds = lds;
   hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
   RGM_LAUNCH_CHECK();
   return RGM_OK;

@@ -208,4 +208,29 @@ int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d
                                 int rot_half, hipStream_t s);
 int transpose_launch(const float* in, float* out, int R, int Cc, int out_ld, int batch, hipStream_t s);
 
+// ---------------------------------------------------------------------------------------------
+// ONE workgroup of an attention kernel per CU -- a correctness requirement, not a tuning choice.
+// Two workgroups of rotary_attention_x3_kernel<72,4> on one CU (T <= 128: their K / V images take 80 KiB each), started together and
+// running the same instruction stream on the same SIMDs, make the one dispatched second (LDS base != 0) read, in lanes 48-63 of one
+// wave, the OLD contents of the second destination register of a global_load_dwordx2 two instructions behind its s_waitcnt vmcnt(0)
+// (the rotary factors of Q chunk (j = 1, u = 0): v.z = x2*c1 - x3*s1 comes out as -x3*s1, 16 queries of the head wrong by ~0.1;
+// tools/ubench/attn_hazard.hip reproduces it standalone, ~1 workgroup in 4000; profiles/r04_attn_hazard_*.txt).  Alone on its CU -- or
+// beside a foreign workgroup -- the kernel has never produced a wrong value.  Every attention launcher therefore asks for more than half
+// of the 160 KiB LDS and checks with the occupancy API, once per instantiation, that the runtime agrees.
+// ---------------------------------------------------------------------------------------------
+constexpr size_t ATTN_ONE_PER_CU_LDS = 80 * 1024 + 512;
+inline size_t attn_lds_one_per_cu(size_t lds) { return lds < ATTN_ONE_PER_CU_LDS ? ATTN_ONE_PER_CU_LDS : lds; }
+// sets the dynamic-LDS limit of `kern` and requires that exactly one workgroup of (threads, lds) fits a CU
+template <class Kern>
+int attn_prepare_kernel(Kern kern, int threads, size_t lds, const char* what) {
+  RGM_REQUIRE(lds >= ATTN_ONE_PER_CU_LDS && lds <= 160 * 1024, "%s: %zu bytes of LDS (one workgroup per CU needs %zu .. %d)", what, lds,
+              ATTN_ONE_PER_CU_LDS, 160 * 1024);
+  RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  int per_cu = 0;
+  RGM_CHECK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, threads, lds));
+  RGM_REQUIRE(per_cu == 1, "%s: %d workgroups of %d threads / %zu bytes of LDS fit a CU; the attention kernels must run one per CU", what,
+              per_cu, threads, lds);
+  return RGM_OK;
+}
+
 }  // namespace rgm
