@@ -51,26 +51,10 @@ struct AttnDbg {
 __device__ AttnDbg* g_attn_dbg = nullptr;   // [grid]
 __device__ int* g_attn_cnt = nullptr;       // [grid], zeroed by the host: staging-complete arrivals counted through global memory
 __device__ float* g_attn_dump = nullptr;    // [grid][waves][ATTN_DUMP_ITEMS][64]: Q fragments, max, sum, scores, probabilities of every lane
-#define ATTN_DUMP_ITEMS 57
+#define ATTN_DUMP_ITEMS 42
 #define ATTN_DUMP(item, val)                                                                                             \
   if (g_attn_dump) g_attn_dump[(((size_t)blockIdx.x * (blockDim.x >> 6) + wave) * ATTN_DUMP_ITEMS + (item)) * 64 + lane] = (val);
-__device__ int g_attn_mode = 0;             // bit 0: cross-half exchanges by v_permlane32_swap instead of ds_bpermute; 1: s_nop before them; 2: s_nop after the PV chain
-#define ATTN_DBG_MODE(bit) (g_attn_mode & (1 << (bit)))
-#else
-#define ATTN_DBG_MODE(bit) 0
 #endif
-
-// the other half-wave's value of v (lane ^ 32) -- __shfl_xor(v, 32, 64) is a ds_bpermute_b32 through the LDS crossbar
-__device__ __forceinline__ float other_half(float v) {
-#ifdef RGM_ATTN_HAZARD_DBG
-  if (ATTN_DBG_MODE(1)) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-  if (ATTN_DBG_MODE(0)) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);   // r[0] = lanes 0-31's v, r[1] = lanes 32-63's
-    return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
-  }
-#endif
-  return __shfl_xor(v, 32, 64);
-}
 
 template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
@@ -171,10 +155,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   const int nwaves = nthr >> 6;
   // scores are kept in the log2 domain (log2(e) folded into the query scale): p = 2^(s - max) is ONE v_exp_f32 per element
   // instead of the 8-op double-float exp of the fp32 kernel (its ~2e-7 argument error is 100x below the bf16x3 product error)
-  float scale = rsqrtf((float)HD) * 1.44269504088896340736f;
-#ifdef RGM_ATTN_HAZARD_DBG
-  if (ATTN_DBG_MODE(3)) scale = (HD == 72 ? 0.11785113019775793f : 0.125f) * 1.44269504088896340736f;   // no v_rsq_f32
-#endif
+  const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;
   const int nqt = (T + 31) >> 5;
 
   for (int qt = wave; qt < nqt; qt += nwaves) {
@@ -182,9 +163,8 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
     const int qc = min(q, T - 1);
     // ---- Q fragments: lane (query l31, half hh) holds Q[q][16j + 8hh .. +7], rotated, pre-scaled, split
     bf16x8 qh[KS], ql[KS];
-#ifdef RGM_ATTN_HAZARD_DBG
-    unsigned dbg_raw[6] = {0, 0, 0, 0, 0, 0}, dbg_cs[6] = {0, 0, 0, 0, 0, 0};   // the rotary chunks j < 3: raw loaded Q values / factors
-    if (ATTN_DBG_MODE(6) || ATTN_DBG_MODE(7)) {   // every load of the Q prologue issued and RETIRED before the first value is used
+#ifdef RGM_ATTN_HAZARD_TWO_PHASE   // probe variant: every load of the Q prologue issued and RETIRED before the first value is used
+    if (true) {
       const float* qp = base + (long long)qc * D3;
       float4 qraw[KS][2];
       float2 cf[KS][2][2];
@@ -206,7 +186,6 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
         }
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (ATTN_DBG_MODE(6)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < KS; ++j) {
@@ -240,29 +219,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
           if (d0 < HD) {
             v = *reinterpret_cast<const float4*>(qp + d0);
-#ifdef RGM_ATTN_HAZARD_DBG
-#endif
             if (d0 < R) {
               const int pi = qc * rot_half + (d0 >> 1);
-              float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
-#ifdef RGM_ATTN_HAZARD_DBG
-              if (ATTN_DBG_MODE(8)) {   // the same two 8-byte loads with destinations that may NOT be the address registers
-                float2 cc, ss;
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(cc) : "v"(cos_tab + pi) : "memory");
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(ss) : "v"(sin_tab + pi) : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                c0 = cc.x; c1 = cc.y; s0 = ss.x; s1 = ss.y;
-              }
-              if (ATTN_DBG_MODE(9)) {   // control: the same code with the destination forced ONTO the address registers
-                unsigned long long ca = (unsigned long long)(cos_tab + pi), sa = (unsigned long long)(sin_tab + pi);
-                asm volatile("global_load_dwordx2 %0, %0, off" : "+v"(ca) : : "memory");
-                asm volatile("global_load_dwordx2 %0, %0, off" : "+v"(sa) : : "memory");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                c0 = __uint_as_float((unsigned)ca); c1 = __uint_as_float((unsigned)(ca >> 32));
-                s0 = __uint_as_float((unsigned)sa); s1 = __uint_as_float((unsigned)(sa >> 32));
-              }
-              if (j < 3) dbg_cs[j * 2 + u] = __float_as_uint(c0) ^ (__float_as_uint(s0) * 3u) ^ (__float_as_uint(c1) * 5u) ^ (__float_as_uint(s1) * 7u);
-#endif
+              const float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
               const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
               v.x = x0 * c0 - x1 * s0;
               v.y = x1 * c0 + x0 * s0;
@@ -270,23 +229,12 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
               v.w = x3 * c1 + x2 * s1;
             }
           }
-#ifdef RGM_ATTN_HAZARD_DBG
-          if (j >= 2) dbg_raw[(j - 2) * 2 + u] = __float_as_uint(v.x) ^ (__float_as_uint(v.y) * 3u) ^ (__float_as_uint(v.z) * 5u) ^ (__float_as_uint(v.w) * 7u);
-#endif
           v8[4 * u] = v.x * scale; v8[4 * u + 1] = v.y * scale; v8[4 * u + 2] = v.z * scale; v8[4 * u + 3] = v.w * scale;
         }
         split8(v8, qh[j], ql[j]);
       }
     }
     ATTN_STAMP(3)
-#ifdef RGM_ATTN_HAZARD_DBG
-    unsigned ck_q = 0;
-    float ck_s = 0.f, ck_p = 0.f;
-#pragma unroll
-    for (int j = 0; j < KS; ++j)
-#pragma unroll
-      for (int w = 0; w < 4; ++w) ck_q ^= (reinterpret_cast<const unsigned*>(&qh[j])[w] * 31u + (unsigned)(j * 8 + w)) ^ (reinterpret_cast<const unsigned*>(&ql[j])[w] * 17u);
-#endif
     // ---- S^T[key][query] = K . Q^T
     f32x16 sacc[NKT];
 #pragma unroll
@@ -304,12 +252,6 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       }
     }
     ATTN_STAMP(4)
-#ifdef RGM_ATTN_HAZARD_DBG
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ck_s += sacc[kt][e] * (float)(1 + ((kt * 16 + e) & 7));
-#endif
     // ---- softmax over keys: register e of tile kt is key kt*32 + (e&3) + 8*(e>>2) + 4*hh
     float mx = -INFINITY;
     const int ktr = T >> 5, tr = T & 31;   // ragged tile index / valid keys in it (wave-uniform)
@@ -326,23 +268,8 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 16; ++e) mx = fmaxf(mx, sacc[kt][e]);
     }
-    mx = fmaxf(mx, other_half(mx));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     float sum = 0.f;
-#ifdef RGM_ATTN_HAZARD_DBG
-    if (ATTN_DBG_MODE(4)) {   // every v_exp_f32 retired long before anything reads a probability
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sacc[kt][e] = __builtin_amdgcn_exp2f(sacc[kt][e] - mx);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) sum += sacc[kt][e];
-    } else
-#endif
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -351,16 +278,12 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
         sacc[kt][e] = pv;
         sum += pv;
       }
-    sum += other_half(sum);
+    sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
     // natural-log sum-exp of the scaled scores, saved for the backward (scores here are in the log2 domain)
     if (lse && hh == 0 && q < T) lse[((long long)n * heads + head) * T + q] = (mx + log2f(sum)) * 0.693147180559945309417f;
     ATTN_STAMP(5)
-#ifdef RGM_ATTN_HAZARD_DBG
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) ck_p += sacc[kt][e] * (float)(1 + ((kt * 16 + e) & 7));
+#ifdef RGM_ATTN_HAZARD_DUMP
     const float dbg_mx = mx, dbg_sum = sum;
 #endif
     // ---- O^T[d][query] = V^T . P^T ; A operand = V^T rows (d = lane&31), B operand = the probability registers, split
@@ -390,20 +313,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[dt], 0, 0, 0);
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[dt], 0, 0, 0);
         }
-#ifdef RGM_ATTN_HAZARD_DBG
-        if (ATTN_DBG_MODE(5)) {   // nothing may overwrite ph / pl (B operands written by VALU) until the MFMAs that read them are long under way
-          __builtin_amdgcn_sched_barrier(0);
-          asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-          __builtin_amdgcn_sched_barrier(0);
-        }
-#endif
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the V^T reads of later key tiles from being hoisted (spills)
     }
     ATTN_STAMP(6)
-#ifdef RGM_ATTN_HAZARD_DBG
-    if (ATTN_DBG_MODE(2)) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
-#endif
     // ---- store: lane = query (row), registers 4g..4g+3 = 4 consecutive channels
     if (q < T) {
       float* op = o + ((long long)n * T + q) * D + head * HD;
@@ -429,26 +342,19 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
           }
         }
     }
-#ifdef RGM_ATTN_HAZARD_DBG
-    ATTN_DUMP(0, __uint_as_float(ck_q))
-    ATTN_DUMP(1, dbg_mx)
-    ATTN_DUMP(2, dbg_sum)
-    ATTN_DUMP(3, ck_s)
-    ATTN_DUMP(4, ck_p)
-#pragma unroll
-    for (int i2 = 0; i2 < 6; ++i2) {
-      ATTN_DUMP(5 + i2, __uint_as_float(dbg_raw[i2]))
-      ATTN_DUMP(11 + i2, __uint_as_float(dbg_cs[i2]))
-    }
+#ifdef RGM_ATTN_HAZARD_DUMP   // the Q fragments as the S^T MFMAs saw them (stored here, behind the output: stores in the prologue hide the failure;
+                              // the 40 extra live registers shift the schedule too -- the run that named the element was made at commit 7be1b0c)
     if constexpr (KS <= 5) {
 #pragma unroll
       for (int j = 0; j < KS; ++j)
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-          ATTN_DUMP(17 + j * 8 + w, __uint_as_float(reinterpret_cast<const unsigned*>(&qh[j])[w]))
-          ATTN_DUMP(17 + j * 8 + 4 + w, __uint_as_float(reinterpret_cast<const unsigned*>(&ql[j])[w]))
+          ATTN_DUMP(j * 8 + w, __uint_as_float(reinterpret_cast<const unsigned*>(&qh[j])[w]))
+          ATTN_DUMP(j * 8 + 4 + w, __uint_as_float(reinterpret_cast<const unsigned*>(&ql[j])[w]))
         }
     }
+    ATTN_DUMP(40, dbg_mx)
+    ATTN_DUMP(41, dbg_sum)
 #endif
     ATTN_STAMP(7)
   }

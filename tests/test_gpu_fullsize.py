@@ -526,6 +526,49 @@ def test_short_sequence_attention_is_right_in_every_launch(N, T, heads, hd, prec
     assert err < (3e-6 if precision == "fp32" else 3e-5), err
 
 
+@pytest.mark.parametrize("N,T,heads,hd,rot", [(40, 160, 6, 64, 4), (24, 256, 6, 64, 8), (24, 130, 16, 72, 4), (3, 257, 6, 64, 32)])
+def test_every_attention_launcher_keeps_one_workgroup_per_cu(N, T, heads, hd, rot, precision):
+    """two workgroups of an attention kernel on one CU are a correctness hazard, so every launcher goes through
+    attn_prepare_kernel (common.h), which pads the LDS request past half of the 160 KiB and REQUIRES an occupancy of one from the
+    runtime -- a launch that could co-reside returns an error instead of running.  The key-blocked kernel's request shrinks with the rotary
+    table (head_dim 64 with 4 rotary channels at T = 160 would fit twice without the padding: the advisor's case); the backward kernels
+    take the same helper.  Here: those shapes run, repeat bit for bit, and are right against the fp64 product."""
+    from gpu_util import dev
+    from rgm import native as R
+    from rgm.synth import rotary_freqs
+    from oracle import dit_np as odit
+    rng = np.random.RandomState(N * 1000 + T)
+    D = heads * hd
+    qkv = (rng.randn(N * T, 3 * D) * 1.2).astype(F32)
+    cos, sin = odit.rotary_tables(rotary_freqs(rot), T)
+    qd, cd, sd_ = dev(qkv), dev(cos), dev(sin)
+    outs = []
+    for _ in range(8):
+        od = torch.full((N * T, D), float("nan"), device="cuda")
+        R.check(R.lib.rgm_rotary_attention(R.ptr(qd), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, rot // 2, R.current_stream()))
+        outs.append(od)
+    torch.cuda.synchronize()
+    assert max(float((o - outs[0]).abs().max()) for o in outs) == 0.0
+    r = qkv.reshape(N, T, 3, heads, hd)
+    q, k, v = (r[:, :, i].transpose(0, 2, 1, 3) for i in range(3))
+    q = odit.apply_rotary(q.astype(F32), cos, sin).astype(np.float64)
+    k = odit.apply_rotary(k.astype(F32), cos, sin).astype(np.float64)
+    s = q @ k.transpose(0, 1, 3, 2) * hd ** -0.5
+    p = np.exp(s - s.max(-1, keepdims=True))
+    p /= p.sum(-1, keepdims=True)
+    ref = (p @ v.astype(np.float64)).transpose(0, 2, 1, 3).reshape(N * T, D)
+    err = np.abs(outs[0].cpu().numpy() - ref).max() / np.abs(ref).max()
+    assert err < (3e-6 if precision == "fp32" else 3e-5), err
+    # the backward launchers (fp32 MFMA kernels) on the same shape: the helper's occupancy requirement must hold for them too
+    lse = torch.zeros(N * heads * T, device="cuda")
+    do = dev(rng.randn(N * T, D).astype(F32))
+    dq = torch.empty(N * T, 3 * D, device="cuda")
+    R.check(R.lib.rgm_rotary_attention_bwd(R.ptr(qd), R.ptr(outs[0]), R.ptr(do), R.ptr(lse), R.ptr(dq), R.ptr(cd), R.ptr(sd_), N, T, heads, hd,
+                                           rot // 2, R.current_stream()))
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dq).all())
+
+
 def test_half_window_batches_through_the_xl_model_are_deterministic(precision):
     """The same hazard at the model level: 48 half windows (H = 64 -> 128 tokens) through XL depth 4, twelve times: identical outputs,
     equal to the batches-of-2 evaluation."""

@@ -1,0 +1,7 @@
+#!/bin/bash
+# builds the three flavours of the short-sequence attention hazard probe (see attn_hazard.hip) next to this script
+cd "$(dirname "$0")"
+F="--offload-arch=gfx950 -O3 -std=c++17 -DRGM_ATTN_HAZARD_DBG -I../../rule-guided-music_amd/csrc"
+/opt/rocm/bin/hipcc $F -o attn_hazard attn_hazard.hip
+/opt/rocm/bin/hipcc $F -DRGM_ATTN_HAZARD_TWO_PHASE -o attn_hazard_two_phase attn_hazard.hip
+/opt/rocm/bin/hipcc $F -DRGM_ATTN_HAZARD_DUMP -o attn_hazard_dump attn_hazard.hip
