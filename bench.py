@@ -46,7 +46,9 @@ import torch  # noqa: E402
 
 XL = dict(depth=28, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4)
 DIT_GFLOP_PER_SAMPLE = 237.4          # DiTRotary_XL_8 forward, T=256
+DIT_GFLOP_PER_HALF_WINDOW = 116.8     # the same forward at T=128 (DiffCollage half window)
 VAE_GFLOP_PER_TILE = 114.48
+CLS_VAG_GFLOP_PER_SAMPLE = 25.4       # DiTRotary-S/8-cls forward + dgrad
 F32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH: v_mfma_f32_32x32x2_f32, dense
 BF16X3_EQUIV_PEAK_TFLOPS = 2500.0 / 3  # dense bf16 MFMA peak, 3 MFMAs per useful (algorithmic) product
 
@@ -101,14 +103,20 @@ class C2Workload:
 
 
 class SCGWorkload:
-    """One guided SCG step (config[3] shape): B=4, n=16 candidates, DiT-XL + VAE decode + 2 rules, DDPM chain."""
-    name = "C4 SCG guided DDPM step, DiTRotary_XL_8 + KL-VAE decode + pitch_hist/note_density, B=4, n=16 (sharded over GPUs)"
+    """One guided step of BASELINE config[3] = cond_table/all/scg_classifier_all.yml as the reference defines it (:6-35), minus the
+    music21 chord rule: classifier guidance with the pitch-histogram and note-density DiTRotary-S/8-cls (scales 400 / 10) AND SCG with
+    n = 16 candidates over B = 4 -- DiT-XL on 4 + 64 rows, KL-VAE decode of 512 squares, 2 rules, DDPM chain.  SURVEY 8d prices it
+    (1 + 16) * 237.4 + 16 * 915.8 + 2 * 25.4 GFLOP per sample."""
+    name = ("C4 classifier-guided (pitch_hist + note_density DiTRotary-S/8-cls) + SCG DDPM step, DiTRotary_XL_8 + KL-VAE decode + "
+            "pitch_hist/note_density rules, B=4, n=16 (sharded over GPUs)")
+    classifiers = True
 
     def __init__(self, device, batch):
         from functools import partial
         from types import SimpleNamespace
         from rgm import synth
-        from guided_diffusion.condition_functions import model_fn
+        from guided_diffusion.dit import DiT_models
+        from guided_diffusion.condition_functions import model_fn, composite_nn_zt
         from taming.models.klvae_pedal import AutoencoderKL
         self.B = batch
         self.device = device
@@ -124,17 +132,30 @@ class SCGWorkload:
         ph = torch.tensor([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], device=device).repeat(batch, 1)
         nd = torch.tensor([3.] * 8 + [3.] * 8, device=device).repeat(batch, 1)
         self.kw = {"y": torch.ones(batch, dtype=torch.int64, device=device), "rule": {"pitch_hist": ph, "note_density": nd}}
-        self.guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+        self.cond = None
+        cls_gflop = 0.0
+        if self.classifiers:
+            self.clfs = []
+            for k, seed in ((12, 5), (16, 3)):
+                clf = DiT_models["DiTRotary-S/8-cls"](input_size=[128, 16], in_channels=4, num_classes=k)
+                arch = dict(depth=12, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=k)
+                clf.load_state_dict(synth.dit_state_dict(seed, device=device, **arch))
+                self.clfs.append(clf.to(device).eval())
+            self.cond = partial(composite_nn_zt, fns=["grad_nn_zt_mse", "grad_nn_zt_mse"], classifier_scales=[400., 10.],
+                                classifiers=self.clfs, rule_names=["pitch_hist", "note_density"])
+            cls_gflop = 2 * CLS_VAG_GFLOP_PER_SAMPLE
+        self.guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1,
+                                    method="classifier_guidance" if self.classifiers else "no_guidance")
         self.scg = {"num_samples": 16, "pitch_hist": 40., "note_density": 1.}
         self.k = 0
-        self.flop_per_step = batch * ((1 + 16) * DIT_GFLOP_PER_SAMPLE + 16 * 8 * VAE_GFLOP_PER_TILE) * 1e9
+        self.flop_per_step = batch * ((1 + 16) * DIT_GFLOP_PER_SAMPLE + 16 * 8 * VAE_GFLOP_PER_TILE + cls_gflop) * 1e9
 
     def step(self):
         i = 700 - (self.k % 600)
         self.k += 1
         t = torch.full((self.B,), i, dtype=torch.int64, device=self.device)
         self.d._t_host = i
-        out = self.d.p_sample(self.fn, self.x, t, clip_denoised=False, model_kwargs=self.kw, embed_model=self.vae,
+        out = self.d.p_sample(self.fn, self.x, t, clip_denoised=False, cond_fn=self.cond, model_kwargs=self.kw, embed_model=self.vae,
                               scale_factor=1.2465, guidance_kwargs=self.guid, scg_kwargs=self.scg)
         self.d._t_host = None
         self.x = out["sample"]
@@ -145,6 +166,7 @@ class LongWorkload(SCGWorkload):
     (latent 4 x 512 x 16) -- with SCG (n = 16) scoring rule(decode(x0)) on the 4096-frame roll."""
     name = ("C5 DiffCollage (linear, 7 windows, overlap 64) + SCG guided DDPM step, DiTRotary_XL_8 + KL-VAE decode of 32 squares "
             "per candidate + pitch_hist/note_density, n=16 (sharded over GPUs)")
+    classifiers = False     # BASELINE config[4] is collage + SCG; the 128-row classifiers do not apply to a 512-row latent
 
     def __init__(self, device, batch):
         from functools import partial
@@ -163,8 +185,8 @@ class LongWorkload(SCGWorkload):
         ph = torch.tensor([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], device=device).repeat(batch, 1)
         nd = torch.tensor([3.] * nw + [3.] * nw, device=device).repeat(batch, 1)
         self.kw = {"y": torch.ones(batch, dtype=torch.int64, device=device), "rule": {"pitch_hist": ph, "note_density": nd}}
-        windows = 7 + 6                       # 7 full windows + 6 overlap halves evaluated by the collage
-        self.flop_per_step = batch * ((1 + 16) * windows * DIT_GFLOP_PER_SAMPLE + 16 * (H // 16) * VAE_GFLOP_PER_TILE) * 1e9
+        per_forward = 7 * DIT_GFLOP_PER_SAMPLE + 6 * DIT_GFLOP_PER_HALF_WINDOW   # 7 full windows + the 6 overlap halves (T = 128) of the collage
+        self.flop_per_step = batch * ((1 + 16) * per_forward + 16 * (H // 16) * VAE_GFLOP_PER_TILE) * 1e9
 
 
 class C3Workload:
@@ -209,6 +231,7 @@ class C3Workload:
 class DPSRuleWorkload(SCGWorkload):
     """One DPS step through the rule itself (cond_table/single/dps_rule/pitch.yml): eps-network forward with saves,
     x0 -> VAE decode with saves -> pitch_hist log p and roll gradient -> decoder input-gradient pass -> eps-network VJP."""
+    classifiers = False
     name = ("dps_rule guided DDPM step ('250' chain), DiTRotary_XL_8 forward+VJP + KL-VAE decode+input-gradient + pitch_hist "
             "value-and-grad, batch 16")
 

@@ -127,6 +127,11 @@ int rgm_set_big_tiles(int mode, int min_tiles);
  * tests/test_gpu_fullsize.py), 0 = separate launches.  rgm_fused_reduce_ln_launches: how many launches took the fused route so far. */
 int rgm_set_fuse_reduce_ln(int on);
 long long rgm_fused_reduce_ln_launches(void);
+/* adaLN conditioning of a forward (ref guided_diffusion/dit.py:332, 372: every block's adaLN_modulation(c), 0.9 GB of weights for N rows):
+ * 1 = block 0's slice in front of block 0, the rest on a side stream owned by the handle, forked from and joined to the caller's
+ * stream by events (still stream-ordered for the caller; capturable) while block 0 computes; 0 (default; measured equal or better) = one
+ * GEMM in front of block 0. */
+int rgm_set_adaln_overlap(int on);
 /* Workspace-backed decompositions of the pre-split GEMM (csrc/gemm4.hip stream-K, csrc/gemm2.hip deterministic split-K): the
  * scratch is caller memory like every other workspace.  rgm_gemm_streamk_workspace_bytes() bytes, 16-byte aligned; tile 0 lets
  * the heuristic choose, 47 forces the persistent stream-K kernel.  The entry zeroes the scratch's flag words on `stream`. */

@@ -403,7 +403,7 @@ template <int HD>
 __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                           const float* __restrict__ cos_tab,
                                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half,
-                                                                          float* __restrict__ lse, int out_split) {
+                                                                          float* __restrict__ lse, int out_split, int stagger) {
   constexpr int KP = (HD + 15) / 16 * 16;
   constexpr int KS = KP / 16;
   constexpr int DT = (HD + 31) / 32;
@@ -425,6 +425,12 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
   typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int nb = (T + KB - 1) / KB;
+#ifdef RGM_EXPERIMENTS   // staggered starts: workgroup classes (blockIdx % groups) begin `delay` x 1024 cycles (~0.5 us) apart (RGM_ATTN_STAGGER=groups*100+delay)
+  if (stagger) {
+    const int groups = stagger / 100, delay = stagger % 100;
+    for (int i = 0; i < (int)(blockIdx.x % groups) * delay; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
 
   // ---- staging registers of one block: SLOTS chunks of K (+ their rotary factors) and VSLOTS chunks of V per thread.
   // K chunks are indexed key-major (consecutive lanes = consecutive 16-byte chunks of a row: coalesced reads, row-major LDS writes).
@@ -721,7 +727,8 @@ static int launch_attn_x3_blocked(const float* qkv, float* o, const float* ct, c
   static size_t prepared_lds = 0;      // the occupancy check is per LDS size class: the request grows with T
   if (prepared_lds != lds) RGM_TRY(attn_prepare_kernel(kern, 512, lds, "rotary_attention_x3_blocked_kernel"));
   prepared_lds = lds;
-  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
+  static const int stagger = RGM_EXP_ENV("RGM_ATTN_STAGGER");
+  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split, stagger);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -136,7 +136,8 @@ struct GemmParams {
   int aload = 0;
   int H = 0, W = 0, Cin = 0, logH = 0, logW = 0, ups = 0;
   // K order of the implicit conv: 0 = (tap, cin) as the weights are repacked [cout][9][cin]; 1 = (cin / 32, tap, cin % 32) -- the nine
-  // taps of a 32-channel block are consecutive K-tiles (gemm2.hip PIPE 5 only, ups == 0; weights [cout][cin/32][9][32])
+  // taps of a 32-channel block are consecutive K-tiles (gemm2.hip PIPE 5 only; weights [cout][cin/32][9][32]).  The three nearest-x2 upsampling
+  // convs keep order 0 (measured better); the ALOAD 2 loader also implements order 1 for them, behind RGM_CONV_KMAJOR_UPS (experiments)
   int conv_kmajor = 0;
   // tile override for experiments: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
   int tile = 0;

@@ -45,6 +45,8 @@ struct Slot {
   bool in_t = false;                      // lives in arena_t (the W^T copies an eps-network gets from rgm_dit_enable_grad)
 };
 
+static int g_adaln_overlap = getenv("RGM_ADALN_OVERLAP") ? atoi(getenv("RGM_ADALN_OVERLAP")) : 0;   // measured: no gain
+
 struct rgm_dit {
   rgm_dit_cfg cfg{};
   int device = 0;
@@ -62,6 +64,10 @@ struct rgm_dit {
   void* sk_ws = nullptr;     // scratch of the call in progress (points into the caller's workspace; see GemmParams::sk_ws)
   size_t sk_ws_bytes = 0;
   unsigned* sk_err_host = nullptr;   // pinned: the stream-K error word of the LAST forward, copied out asynchronously behind it
+  // adaLN conditioning of blocks 1.. (0.9 GB of weights for N rows: HBM-bound, 0.27 ms of a C2 step) on a side stream, forked from and
+  // joined to the caller's stream by events, while block 0 runs (rgm_set_adaln_overlap)
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
   float* sp(const Slot& sl) const { return (sl.in_t ? arena_t : arena) + sl.off; }
@@ -225,6 +231,9 @@ extern "C" void rgm_dit_destroy(rgm_dit* h) {
   if (h->cos_tab) (void)hipFree(h->cos_tab);
   if (h->sin_tab) (void)hipFree(h->sin_tab);
   if (h->sk_err_host) (void)hipHostFree(h->sk_err_host);
+  if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+  if (h->ev_join) (void)hipEventDestroy(h->ev_join);
   delete h;
 }
 
@@ -443,7 +452,32 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
   RGM_TRY(lin(p.c1, D, h->p("t_embedder.mlp.2.weight"), h->p("t_embedder.mlp.2.bias"), p.c, D, p.N, D, D, 0, s));
   const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
   RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, p.N, D, s));
-  RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, p.N, L, D, 0, s));
+  // adaLN conditioning of the whole forward: mod[N, L] = cs . W_ada^T + b (all blocks' projections are contiguous in the arena).  Block 0
+  // needs only its own 6 D columns up front; the other 0.9 GB of weights stream on the handle's side stream while block 0 computes
+  // (the matrix pipes are the limit there and HBM idles) and are joined back before block 0's fc2, whose reduce writes block 1's LayerNorm.
+  bool joined = true;
+  if (g_adaln_overlap && c.depth > 1 && L > 6 * D) {
+    if (!h->side) {
+      RGM_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+      RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+      RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+    }
+    const float* W = h->p("blocks.0.adaLN_modulation.1.weight");
+    const float* bv = h->p("blocks.0.adaLN_modulation.1.bias");
+    RGM_TRY(lin(p.cs, D, W, bv, p.mod, L, p.N, 6 * D, D, 0, s));
+    RGM_CHECK_HIP(hipEventRecord(h->ev_fork, s));
+    RGM_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+    RGM_TRY(lin(p.cs, D, W + (size_t)6 * D * D, bv + 6 * D, p.mod + 6 * D, L, p.N, L - 6 * D, D, 0, h->side));
+    RGM_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
+    joined = false;
+  } else {
+    RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, p.N, L, D, 0, s));
+  }
+  auto join = [&]() -> int {
+    if (!joined) RGM_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    joined = true;
+    return RGM_OK;
+  };
   const bool v2 = rgm_get_gemm_precision() == 2;   // bf16x3 with pre-split operands: producers emit split rows, gemm2 consumes
   // next_mod (fc2 only): shift of the NEXT block's first adaLN-LayerNorm (its scale is D further).  A K-sliced fc2 then writes that
   // LayerNorm from its reduce kernel (GemmParams::ln_out) and *ln_done tells the loop to skip the separate launch.
@@ -478,10 +512,12 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
       RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr,
                    RGM_EXP_ENV("RGM_FC1_TILE")));
+      RGM_TRY(join());          // block i + 1's shift / scale feed the fused reduce + LayerNorm of this fc2
       RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, RGM_EXP_ENV("RGM_FC2_TILE"),
                    i + 1 < c.depth ? m + 6 * D : nullptr, &xm_ready));
       continue;
     }
+    if (i > 0) RGM_TRY(join());
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, p.M, 3 * D, D, 0, s));
     RGM_TRY(rotary_attention_fwd(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s));
@@ -490,6 +526,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     RGM_TRY(lin(p.xm, D, h->p(b + "mlp.fc1.weight"), h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, p.M, 4 * D, D, 2, s));
     RGM_TRY(lin_gated(p.hid, 4 * D, h->p(b + "mlp.fc2.weight"), h->p(b + "mlp.fc2.bias"), p.x, p.M, D, 4 * D, m + 5 * D, L, T, s));
   }
+  RGM_TRY(join());              // depth 1: nothing above waited
   if (v2) RGM_TRY(sk_end(h, p.sk, s));
   return RGM_OK;
 }
@@ -911,5 +948,14 @@ extern "C" int rgm_dit_status(rgm_dit* h) {
     set_error("dit: a stream-K GEMM timed out waiting for a partial tile in an earlier forward (its output is invalid)");
     return RGM_ERR_STATE;
   }
+  return RGM_OK;
+}
+
+// 1: the adaLN conditioning of blocks 1.. runs on the handle's side stream under block 0 (fork / join by events on the caller's stream:
+// still stream-ordered for the caller, capturable); 0 (default): one GEMM in front of block 0.  Same-box A/B at C2: 12.67 ms (0) vs
+// 12.72 ms (1) -- the one-wave-per-SIMD GEMMs own every register of their CUs, the side launch only runs in their gaps
+extern "C" int rgm_set_adaln_overlap(int on) {
+  RGM_REQUIRE(on == 0 || on == 1, "set_adaln_overlap: %d (0 / 1)", on);
+  g_adaln_overlap = on;
   return RGM_OK;
 }

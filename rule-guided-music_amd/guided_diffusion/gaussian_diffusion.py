@@ -21,8 +21,9 @@ What is different underneath (design, not a translation):
   * every other step (unguided, classifier-guided, DPS) is batch-parallel: rank r computes rows [r*B/R, (r+1)*B/R) and ONE
     all-gather of the new latents per step gives every rank the full batch again -- see batch_shard / SURVEY 8e.
 
-Not implemented here: PREVIOUS_X models, SCG / DPS steps with LEARNED variances (learn_sigma=True; plain, classifier-guided
-and DDIM steps with them are provided) and the training losses.  They raise NotImplementedError instead of silently degrading.
+All three mean types (EPSILON, START_X, PREVIOUS_X) and fixed / learned variances run through the fused step kernels (PREVIOUS_X swaps
+the mean afterwards, _prevx_fix); SCG on a learn_sigma=True network uses the per-element noise scale.  Not implemented: DPS on a
+learn_sigma=True network (raises -- the reference asserts there too, :421) and the training losses.
 SCG / DPS score candidates with an eps-predicting network (as every shipped configuration does).
 """
 import ctypes as C
@@ -427,6 +428,7 @@ class GaussianDiffusion:
                     _rgm.check(_rgm.lib.rgm_ddpm_step_learned(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(vv), lo, hi, _rgm.ptr(grad), _rgm.ptr(noise),
                                                               _rgm.ptr(tt), tab.ptrs, int(bool(clip_denoised)), int(self.t_end),
                                                               _rgm.ptr(sample), _rgm.ptr(x0), N, E, _rgm.current_stream()))
+            sample, x0 = self._prevx_fix(kind, sample, x0, x, t, clip_denoised)
             return sample, x0, g_elem
         with th.cuda.device(x.device):
             if kind == "ddpm":
@@ -437,14 +439,22 @@ class GaussianDiffusion:
                 _rgm.check(_rgm.lib.rgm_ddim_step(_rgm.ptr(x), _rgm.ptr(eps), _rgm.ptr(grad), _rgm.ptr(noise), _rgm.ptr(tt),
                                                   tab.ptrs, int(bool(clip_denoised)), int(self.t_end), float(eta),
                                                   _rgm.ptr(sample), _rgm.ptr(x0), _rgm.ptr(g), N, E, _rgm.current_stream()))
-        prevx = getattr(self, "_prevx", None)
-        if kind == "ddpm" and prevx is not None and prevx.shape == x.shape:
-            # ModelMeanType.PREVIOUS_X: model_mean = model_output (:338), not the posterior mean of the processed x0 the kernel formed
-            sample = sample + (prevx - (self._per_sample(self.posterior_mean_coef1, t, x) * x0
-                                        + self._per_sample(self.posterior_mean_coef2, t, x) * x))
-            # pred_xstart straight from _predict_xstart_from_xprev (1 / coef1 is large: the eps round trip of the kernel would cost digits)
-            x0 = self._prevx_x0.clamp(-1, 1) if clip_denoised else self._prevx_x0
+        sample, x0 = self._prevx_fix(kind, sample, x0, x, t, clip_denoised)
         return sample, x0, g
+
+    def _prevx_fix(self, kind, sample, x0, x, t, clip_denoised):
+        """ModelMeanType.PREVIOUS_X (reference :331-338): model_mean = the network's output, whatever clip_denoised / denoised_fn do to
+        x0, and with fixed or learned variances alike; the fused kernels formed the posterior mean of the processed x0 -- swap the means.
+        pred_xstart comes straight from _predict_xstart_from_xprev (1 / coef1 is large: the kernel's eps round trip would cost digits)."""
+        prevx = getattr(self, "_prevx", None)
+        if kind != "ddpm" or prevx is None:
+            return sample, x0
+        assert prevx.shape == x.shape, (f"PREVIOUS_X: the network output kept by _model_eps {tuple(prevx.shape)} does not belong to this "
+                                        f"step's x {tuple(x.shape)} (a row-sharded forward followed by a full-batch step?)")
+        sample = sample + (prevx - (self._per_sample(self.posterior_mean_coef1, t, x) * x0
+                                    + self._per_sample(self.posterior_mean_coef2, t, x) * x))
+        x0 = self._prevx_x0.clamp(-1, 1) if clip_denoised else self._prevx_x0
+        return sample, x0
 
     @staticmethod
     def _reject_unsupported(denoised_fn, edit_kwargs, guidance_kwargs=None):

@@ -80,6 +80,7 @@ def _load():
         "rgm_set_streamk": (C.c_int, [i32]),
         "rgm_set_big_tiles": (C.c_int, [i32, i32]),
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
+        "rgm_set_adaln_overlap": (C.c_int, [i32]),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),
         "rgm_gemm_streamk_status": (C.c_int, [vp, vp]),
         "rgm_dit_status": (C.c_int, [vp]),

@@ -420,6 +420,7 @@ FIXTURE_SEEDS = {
     "learned": {"seed": 21},
     "next2": {"dpsscg.noise_seed": 1910, "dpsscg_off.noise_seed": 2410},
     "round3": {"lsig.seed": 21},
+    "round4": {"c4.noise_seed": 4102, "c4.x_seed": 4101, "c5.w_seed": 4201, "prevx_lr.seed": 21, "xl28_b32.x_seed": 4001},
     "seg": {"noise_seed": 1451},
     "steps2": {"circ.noise_seed": 1415, "dcg.noise_seed": 1411, "dscg.noise_seed": 1412, "dscgc.noise_seed": 1413},
     "vae_decoder": {"seed": 2},
@@ -972,6 +973,134 @@ def g_round3(vae):
     save("round3", **out)
 
 
+def g_round4(vae):
+    """Round-4 pins (ADVICE): values the REFERENCE computes at the sizes the configs run, not chained through this
+    implementation's own small batches.
+    (a) ModelMeanType.PREVIOUS_X together with LEARNED_RANGE variances, clip_denoised / denoised_fn on (:299-313 + :331-338): the mean is
+        the raw network output, the variance the interpolated one;
+    (b) DiTRotary_XL_8 (depth 28) forward at B = 32 (C3's batch): the output only, inputs regenerated from the stored seed;
+    (c) ONE guided step of cond_table/all/scg_classifier_all.yml as the reference defines it (minus the music21 chord rule): classifier
+        guidance with the pitch and note-density DiTRotary-S/8-cls (depth 12, scales 400 / 10) AND SCG n = 16 over B = 4 through XL-28 and
+        the real decoder (512 squares) -- the winners, the selected sample and the reference's own (16, 4) log-probability table
+        (captured at its argmax, :540);
+    (d) condind_long's 13-window collage eps (7 full + 6 half windows, XL-28) for one 4 x 16 x 512 latent."""
+    print("[round4: PREVIOUS_X + learned range, XL-28 B=32, C4-size classifier+SCG step, C5 collage eps at XL-28]")
+    from functools import partial
+    from types import SimpleNamespace
+    out = {}
+    # ---- (a)
+    arch = dict(SM, out_ch=8)
+    sd8 = synth.dit_state_dict(21, **arch)
+    m8 = rdit.DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=2, num_heads=6, num_classes=3, learn_sigma=True)
+    m8.load_state_dict(tsd(sd8), strict=True)
+    m8.eval()
+    mf8 = ref_model_fn(m8, 3, True)
+    rng = np.random.RandomState(4300)
+    B = 2
+    x = rng.randn(B, 4, 128, 16).astype(F32)
+    y = np.array([1, 2], dtype=np.int64)
+    out.update({"prevx_lr.seed": np.array(21), "prevx_lr.x": x, "prevx_lr.y": y})
+
+    def dfn(v):
+        return v.clamp(-0.5, 0.5) * 0.9
+    betas = rgd.get_named_beta_schedule("linear", 1000)
+    for tag, ti, clip, use_dfn in (("prevx_lr_clip", 300, True, False), ("prevx_lr_dfn", 77, False, True)):
+        d = rrs.SpacedDiffusion(use_timesteps=rrs.space_timesteps(1000, [1000]), betas=betas, model_mean_type=rgd.ModelMeanType.PREVIOUS_X,
+                                model_var_type=rgd.ModelVarType.LEARNED_RANGE, loss_type=rgd.LossType.MSE, rescale_timesteps=False)
+        d.t_end = 0
+        t = np.full((B,), ti, dtype=np.int64)
+        nz = rng.randn(B, 4, 128, 16).astype(F32)
+        NQ.push(nz)
+        r = d.p_sample(mf8, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=clip, denoised_fn=dfn if use_dfn else None,
+                       model_kwargs={"y": torch.from_numpy(y)})
+        out.update({f"{tag}.t": t, f"{tag}.noise": nz, f"{tag}.sample": r["sample"].numpy(), f"{tag}.pred_xstart": r["pred_xstart"].numpy()})
+        print(f"    {tag}: sample range {r['sample'].min().item():.3f} .. {r['sample'].max().item():.3f}, x0 range "
+              f"{r['pred_xstart'].min().item():.3f} .. {r['pred_xstart'].max().item():.3f}")
+        NQ.q.clear()
+
+    # ---- (b) XL-28 at B = 32
+    t0 = time.time()
+    m, sd = ref_dit(XL28, 1, final_std=0.3 / 1152 ** 0.5)
+    rb = np.random.RandomState(FIXTURE_SEEDS["round4"]["xl28_b32.x_seed"])
+    xb = rb.randn(32, 4, 128, 16).astype(F32)
+    tb = rb.randint(0, 1000, size=32).astype(np.int64)
+    yb = rb.randint(0, 4, size=32).astype(np.int64)
+    ob = m(torch.from_numpy(xb), torch.from_numpy(tb), torch.from_numpy(yb)).numpy()
+    print(f"    XL-28 B=32 forward: {time.time() - t0:.0f} s, |out| max {np.abs(ob).max():.3f}")
+    out.update({"xl28_b32.x_seed": np.array(FIXTURE_SEEDS["round4"]["xl28_b32.x_seed"]), "xl28_b32.out": ob})
+
+    # ---- (d) C5's 13 windows at XL-28 (before (c): small)
+    def eps_fn(xx, tt, y=None):
+        return m(xx.permute(0, 1, 3, 2), tt, y=y).permute(0, 1, 3, 2)
+    rw = np.random.RandomState(FIXTURE_SEEDS["round4"]["c5.w_seed"])
+    w = rw.randn(1, 4, 16, 512).astype(F32)
+    tw = np.array([640], dtype=np.int64)
+    yw = np.array([1], dtype=np.int64)
+    lin = rdc.CondIndSimple((4, 16, 128), eps_fn, 7, overlap_size=64)
+    ew = lin.eps_scalar_t_fn(torch.from_numpy(w), torch.from_numpy(tw), y=torch.from_numpy(yw)).numpy()
+    print(f"    C5 collage eps at XL-28: |eps| max {np.abs(ew).max():.3f}")
+    out.update({"c5.w_seed": np.array(FIXTURE_SEEDS["round4"]["c5.w_seed"]), "c5.t": tw, "c5.y": yw, "c5.eps": ew})
+
+    # ---- (c) C4: classifier guidance (pitch + nd) + SCG n = 16, B = 4, XL-28, real decoder
+    t0 = time.time()
+    PCLS = dict(CLS, cls_classes=12)
+    cm_p, _ = ref_cls(PCLS, 5)
+    cm_n, _ = ref_cls(CLS, 3)
+    Bc, n = 4, 16
+    rc = np.random.RandomState(FIXTURE_SEEDS["round4"]["c4.x_seed"])
+    xc = rc.randn(Bc, 4, 128, 16).astype(F32)
+    yc = np.ones((Bc,), dtype=np.int64)
+    tgt = {"pitch_hist": np.tile(np.array([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], dtype=F32), (Bc, 1)),
+           "note_density": np.tile(np.array([3.] * 8 + [3.] * 8, dtype=F32), (Bc, 1))}
+    ttgt = {k: torch.from_numpy(v) for k, v in tgt.items()}
+    cond = partial(rcf.composite_nn_zt, fns=["grad_nn_zt_mse", "grad_nn_zt_mse"], classifier_scales=[400., 10.], classifiers=[cm_p, cm_n],
+                   rule_names=["pitch_hist", "note_density"])
+    scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
+    gk = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="classifier_guidance")
+    mf = ref_model_fn(m, 3, True)
+    d = make_diffusion("")
+    d.t_end = 0
+    tc = np.full((Bc,), 500, dtype=np.int64)
+    nz = np.random.RandomState(FIXTURE_SEEDS["round4"]["c4.noise_seed"]).randn(n, Bc, 4, 128, 16).astype(F32)
+    NQ.push(nz)
+
+    class ChunkedVAE:                      # the reference's _decode hands all 512 squares over at once: same values, 32 at a time
+        def decode(self, z):
+            return torch.cat([vae.decode(z[i:i + 32]) for i in range(0, z.shape[0], 32)])
+    seen = []
+    orig_argmax = torch.Tensor.argmax
+
+    def spy(self, *a, **k):
+        if self.dim() == 2 and self.shape == (n, Bc):
+            seen.append(self.detach().clone().numpy())
+        return orig_argmax(self, *a, **k)
+    torch.Tensor.argmax = spy              # (grad stays globally off: grad_nn_zt_mse enables it around the classifier itself, :58-64)
+    try:
+        r = d.p_sample(mf, torch.from_numpy(xc), torch.from_numpy(tc), clip_denoised=False, cond_fn=cond,
+                       model_kwargs={"y": torch.from_numpy(yc), "rule": ttgt}, embed_model=ChunkedVAE(), scale_factor=1.2465,
+                       guidance_kwargs=gk, scg_kwargs=scg)
+    finally:
+        torch.Tensor.argmax = orig_argmax
+    assert len(seen) == 1, len(seen)
+    table = seen[0]
+    samp = r["sample"].detach().numpy()
+    # the winners, recovered from the sample: candidate k of row b is mean[b] + g[b] * nz[k, b]; differences of two candidates of a row
+    # are g * (nz[k] - nz[k']) -- the winner is the k whose difference to the sample is proportional to no noise difference at all
+    mi = np.argmax(table, axis=0)
+    S = odf.Schedule(1000, "linear", "")
+    gco = np.exp(F32(0.5) * S.ex(S.model_log_variance, tc)).reshape(Bc, 1, 1, 1)
+    for b in range(Bc):
+        mean_b = samp[b] - gco[b] * nz[mi[b], b]
+        others = [float(np.abs(samp[b] - (mean_b + gco[b] * nz[k, b])).max()) for k in range(n) if k != mi[b]]
+        assert min(others) > 1e-2
+    srt = np.sort(table, axis=0)
+    print(f"    C4 step: {time.time() - t0:.0f} s; winners {mi}; gap best - second per row {srt[-1] - srt[-2]}")
+    out.update({"c4.x_seed": np.array(FIXTURE_SEEDS["round4"]["c4.x_seed"]), "c4.noise_seed": np.array(FIXTURE_SEEDS["round4"]["c4.noise_seed"]),
+                "c4.t": tc, "c4.sample": samp, "c4.pred_xstart": r["pred_xstart"].detach().numpy(), "c4.max_ind": mi.astype(np.int64),
+                "c4.total_log_prob": table.astype(F32), "c4.target.pitch_hist": tgt["pitch_hist"], "c4.target.note_density": tgt["note_density"]})
+    save("round4", **out)
+
+
 def g_configs():
     """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
     checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
@@ -1405,7 +1534,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1416,7 +1545,7 @@ if __name__ == "__main__":
         g_dit("xl_d28", XL28, 1)
     if "cls" in which:
         g_cls()
-    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e", "round3"}:
+    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e", "round3", "round4"}:
         vae = g_vae() if "vae" in which else RefVAE(2)
     if "rules" in which:
         g_rules()
@@ -1438,6 +1567,8 @@ if __name__ == "__main__":
         g_round3(vae)
     if "learned" in which:
         g_learned()
+    if "round4" in which:
+        g_round4(vae)
     if "configs" in which:
         g_configs()
     if "collage" in which:

@@ -284,11 +284,29 @@ def _targets(B, nw):
     return {"pitch_hist": ph, "note_density": nd}
 
 
+def _c4_classifiers():
+    """the pitch-histogram (12 outputs) and note-density (16) DiTRotary-S/8-cls of scg_classifier_all.yml, synthetic weights (seeds 5 / 3
+    as in tests/golden/make_golden.py g_round4 and bench.py), scales 400 / 10"""
+    from functools import partial
+    from gpu_util import load_module
+    from rgm import synth
+    from guided_diffusion.dit import DiTRotaryClassifier
+    from guided_diffusion.condition_functions import composite_nn_zt
+    clfs = []
+    for k, seed in ((12, 5), (16, 3)):
+        arch = dict(depth=12, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=k)
+        clfs.append(load_module(DiTRotaryClassifier(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=12, num_heads=6,
+                                                    num_classes=k), synth.dit_state_dict(seed, **arch)))
+    return partial(composite_nn_zt, fns=["grad_nn_zt_mse", "grad_nn_zt_mse"], classifier_scales=[400., 10.], classifiers=clfs,
+                   rule_names=["pitch_hist", "note_density"])
+
+
 def test_scg_search_step_at_c4_size_matches_its_two_rank_replay(monkeypatch, precision):
-    """BASELINE config 4 at its real candidate batch: B = 4, n = 16 -> the eps-network scores 64 rows (M = 16384), the decoder 512
+    """BASELINE config 4 as scg_classifier_all.yml defines it (minus the chord rule) at its real candidate batch: classifier guidance
+    with the pitch and note-density classifiers AND SCG, B = 4, n = 16 -> the eps-network scores 64 rows (M = 16384), the decoder 512
     squares.  The step is run unsharded and replayed as 'rank r of 2' (32 candidates each, other half of the log-prob table from a
     stand-in all-gather): same per-sample winners, log-probs equal up to the batch-size dependence of the GEMM tiles, and the
-    rebuilt winner bit-identical."""
+    rebuilt winner bit-identical.  (The same step against the REFERENCE's values: tests/test_gpu_round4.py.)"""
     from functools import partial
     from types import SimpleNamespace
     from gpu_util import rel
@@ -299,7 +317,8 @@ def test_scg_search_step_at_c4_size_matches_its_two_rank_replay(monkeypatch, pre
     m, vae = _dit(XL2, 1), _vae(2)
     fn = partial(model_fn, model=m, num_classes=3, class_cond=True, cfg=False, w=0.)
     kw = {"y": torch.ones(B, dtype=torch.int64, device="cuda"), "rule": _targets(B, 8)}
-    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="classifier_guidance")
+    cond = _c4_classifiers()
     scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
     x = torch.randn(B, 4, 128, 16, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
     t = torch.full((B,), 600, dtype=torch.int64, device="cuda")
@@ -308,7 +327,7 @@ def test_scg_search_step_at_c4_size_matches_its_two_rank_replay(monkeypatch, pre
         d = _diffusion("")
         d.t_end = 0
         d.noise = PhiloxNoise(seed=99)
-        out = d.p_sample(fn, x, t, clip_denoised=False, model_kwargs=kw, embed_model=vae, scale_factor=1.2465,
+        out = d.p_sample(fn, x, t, clip_denoised=False, cond_fn=cond, model_kwargs=kw, embed_model=vae, scale_factor=1.2465,
                          guidance_kwargs=guid, scg_kwargs=scg)
         return out["sample"], d.last_scg["total_log_prob"].clone(), d.last_scg["max_ind"].clone()
 
@@ -472,6 +491,23 @@ def test_two_rank_scg_bench_control_flow_on_one_device():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "PLUMBING" in line["data"]
+    assert line["config"]["same_winners_on_every_rank"] is True, line
+
+
+def test_eight_rank_scg_bench_control_flow_on_one_device():
+    """The north star's topology -- n = 16 candidates over EIGHT ranks (2 each), B = 4 < R: the x_t forward and the two classifiers'
+    gradients shared out one row per rank (`R % B == 0` rule of batch_shard.partition_rows), one all-gather of eps + gradient rows, one
+    of the (2, 4) log-prob tables -- run as eight processes on this one device over gloo (plumbing, never a measurement).  The step is
+    C4 as the reference's scg_classifier_all.yml defines it (classifier guidance AND SCG); every rank must pick the same winners."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGM_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-extras", "--workload", "scg", "--steps", "2",
+                          "--warmup", "1", "--repeats", "1"], capture_output=True, text=True, timeout=2400, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and "PLUMBING" in line["data"]
+    assert "classifier-guided" in line["config"]["workload"]
     assert line["config"]["same_winners_on_every_rank"] is True, line
 
 
