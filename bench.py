@@ -282,8 +282,6 @@ def roofline_pass(work, steps=2):
           53: (2, 6, 4), 54: (1, 4, 4), 55: (1, 5, 4), 56: (2, 4, 4), 57: (3, 6, 4), 58: (3, 3, 4), 71: (7, 2, 5), 72: (8, 2, 5)}
 
     def kname(k):
-        if k == 47:
-            return "gemm4_kernel"                                  # persistent stream-K 128x128 (csrc/gemm4.hip)
         if k < 40:
             return f"gemm_kernel<{tiles[k % 10]},{(k // 10) % 2},{k // 20}>"
         t = k - 40
@@ -626,8 +624,6 @@ def main():
 
     from rgm import native as R
     R.set_gemm_precision(args.precision)
-    if os.environ.get("RGM_STREAMK") is not None:               # experiments: 0 off, 1 heuristic (default), 2 always
-        R.check(R.lib.rgm_set_streamk(int(os.environ["RGM_STREAMK"])))
     torch.manual_seed(0)
     batch = args.batch or {"c2": 16, "c3": 32, "scg": 4, "long": 1, "dps_rule": 16}[args.workload]
     work = {"c2": C2Workload, "c3": C3Workload, "scg": SCGWorkload, "long": LongWorkload,

@@ -69,9 +69,6 @@ int rgm_dit_forward(rgm_dit* h, const float* x, const int64_t* t, const int32_t*
                     int N, int H, void* ws, size_t ws_bytes, void* stream);
 /* DiTRotaryClassifier.forward dit.py:803-831.  logits (N,n_out) [kind 1]  or  key (N,25) + chord
  * (N,H/width,n_out) [kind 2; key_out may be NULL]. */
-/* RGM_ERR_STATE once if a persistent stream-K GEMM of an earlier forward of this handle ran out of its bounded spin (its output
- * is invalid); no device synchronisation -- call after one.  Every forward also checks its predecessor. */
-int rgm_dit_status(rgm_dit* h);
 int rgm_dit_classify(rgm_dit* h, const float* x, const int64_t* t, float* logits, float* key_out,
                      int N, int H, void* ws, size_t ws_bytes, void* stream);
 
@@ -132,19 +129,16 @@ long long rgm_fused_reduce_ln_launches(void);
  * stream by events (still stream-ordered for the caller; capturable) while block 0 computes; 0 (default; measured equal or better) = one
  * GEMM in front of block 0. */
 int rgm_set_adaln_overlap(int on);
-/* Workspace-backed decompositions of the pre-split GEMM (csrc/gemm4.hip stream-K, csrc/gemm2.hip deterministic split-K): the
- * scratch is caller memory like every other workspace.  rgm_gemm_streamk_workspace_bytes() bytes, 16-byte aligned; tile 0 lets
- * the heuristic choose, 47 forces the persistent stream-K kernel.  The entry zeroes the scratch's flag words on `stream`. */
-size_t rgm_gemm_streamk_workspace_bytes(void);
-/* process-wide: 0 never use the persistent kernel, 1 heuristic (default), 2 whenever the operands allow it */
-int rgm_set_streamk(int mode);
-/* reads the scratch's error word back (synchronises `stream`): RGM_ERR_STATE if a stream-K spin ran out since the flags were zeroed */
-int rgm_gemm_streamk_status(void* ws, void* stream);
+/* Deterministic split-K of the pre-split GEMM (csrc/gemm2.hip: K slices as a batch + one fixed-order reduce kernel, which for the fc2
+ * of a DiT block also writes the next adaLN-LayerNorm): the scratch is caller memory like every other workspace,
+ * rgm_gemm_scratch_bytes(M, N) bytes for GEMMs of up to M rows and N columns, 16-byte aligned, no initialisation.  tile 0 lets the
+ * heuristic choose. */
+size_t rgm_gemm_scratch_bytes(int M, int N);
 int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias, int act,
                       int tile, int out_split, void* ws, size_t ws_bytes, void* stream);
 /* The general pre-split entry: C = (act(alpha * A . B^T + bias)) * gate + res with explicit row strides (elements), the per-sample
  * adaLN gate gate[(row / rows_per_gate) * gate_ld + col] and a residual that may alias C (the proj / fc2 epilogue of a DiT block,
- * guided_diffusion/dit.py:332-336), explicit tile as in rgm_gemm_split (47 = persistent stream-K, 71.. = 256x256 tiles) and the
+ * guided_diffusion/dit.py:332-336), explicit tile as in rgm_gemm_split (71.. = the one-wave-per-SIMD tiles) and the
  * caller's scratch (NULL: no workspace-backed decomposition).  The tiles above 128x128 (5, 45, 71, 72, 73) take a gate only with
  * rows_per_gate >= 32 (RGM_ERR_INVALID otherwise); tile 0 keeps finer gates on the 128-row kernels. */
 int rgm_gemm_split_epi(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,

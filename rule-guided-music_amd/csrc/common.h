@@ -163,23 +163,16 @@ struct GemmParams {
   // whatever tile shape the heuristic picked: results stay independent of the batch size); vae.hip group_norm consumes them
   double* stats = nullptr;
   int stats_gw = 0;
-  // caller-provided scratch of the workspace-backed decompositions (gemm2_scratch_bytes): the first 4096 bytes are the
-  // stream-K flag words (zeroed once by the owner, handed back by the kernels), the rest holds stream-K accumulator slots
-  // or the deterministic split-K partial sums.  nullptr: neither decomposition is used.
+  // caller-provided scratch of the deterministic split-K (gemm2_scratch_bytes): the first 4096 bytes are reserved, the rest holds the
+  // K slices' partial sums.  nullptr: no K slicing.
   void* sk_ws = nullptr;
   size_t sk_ws_bytes = 0;
 };
 int gemm_launch(const GemmParams& p, hipStream_t stream);
 // gemm2.hip: the same contraction on operands already in split-row format (K bf16 hi | K bf16 lo per row)
 int gemm2_launch(const GemmParams& p, hipStream_t stream);
-int gemm3_launch(const GemmParams& p, hipStream_t stream, int tile);   // persistent loader/consumer kernel (gemm3.hip)
-// gemm4.hip: persistent stream-K 128x128 kernel (needs GemmParams::sk_ws)
-int gemm4_launch(const GemmParams& p, hipStream_t stream);
-bool gemm4_eligible(const GemmParams& p);
-size_t gemm4_workspace_bytes();
-constexpr size_t GEMM_SK_FLAG_BYTES = 4096;
-constexpr size_t GEMM_SK_ERR_OFFSET = GEMM_SK_FLAG_BYTES - 4;   // error word of the flag block (a stream-K spin ran out: gemm4.hip)
-// scratch a caller must provide for GEMMs of up to M rows and N columns to use stream-K / split-K
+constexpr size_t GEMM_SK_FLAG_BYTES = 4096;   // reserved head of the scratch (the split-K partial sums start behind it)
+// scratch a caller must provide for GEMMs of up to M rows and N columns to use the deterministic split-K
 size_t gemm2_scratch_bytes(int M, int N);
 int gemm2_prof_begin(int id, double flops, hipStream_t s);
 void gemm2_prof_end(int idx, hipStream_t s);

@@ -63,7 +63,6 @@ struct rgm_dit {
   size_t arena_t_floats = 0;
   void* sk_ws = nullptr;     // scratch of the call in progress (points into the caller's workspace; see GemmParams::sk_ws)
   size_t sk_ws_bytes = 0;
-  unsigned* sk_err_host = nullptr;   // pinned: the stream-K error word of the LAST forward, copied out asynchronously behind it
   // adaLN conditioning of blocks 1.. (0.9 GB of weights for N rows: HBM-bound, 0.27 ms of a C2 step) on a side stream, forked from and
   // joined to the caller's stream by events, while block 0 runs (rgm_set_adaln_overlap)
   hipStream_t side = nullptr;
@@ -230,7 +229,6 @@ extern "C" void rgm_dit_destroy(rgm_dit* h) {
   if (h->tfreqs) (void)hipFree(h->tfreqs);
   if (h->cos_tab) (void)hipFree(h->cos_tab);
   if (h->sin_tab) (void)hipFree(h->sin_tab);
-  if (h->sk_err_host) (void)hipHostFree(h->sk_err_host);
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
@@ -353,7 +351,7 @@ struct Plan {
   int N, H, T0, T, M0, M;
   size_t L;
   float *tok_in, *h1, *x, *xm, *qkv, *ao, *hid, *temb, *c1, *c, *cs, *mod, *tok_out, *pool, *pooln, *z1;
-  char* sk;          // stream-K / split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
+  char* sk;          // split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
   size_t sk_bytes;
   size_t bytes;
 };
@@ -409,24 +407,6 @@ int lin_gated(const float* A, int lda, const float* W, const float* bias, float*
   g.gate = gate; g.gate_ld = gate_ld; g.rows_per_gate = rows_per_gate;
   g.res = X; g.ldres = N;
   return gemm_launch(g, s);
-}
-
-// A stream-K finisher whose bounded spin ran out raises the scratch's error word and finishes with wrong data (gemm4.hip).  The word
-// is copied to pinned memory behind every forward / backward (sk_end: no sync) and looked at when the NEXT call begins -- by then that
-// copy has long landed -- and by rgm_dit_status at the caller's sync points.  sk_begin also zeroes the flag words: once per call, the
-// kernels hand them back.
-int sk_begin(rgm_dit* h, char* sk, hipStream_t s) {
-  if (!h->sk_err_host) {
-    RGM_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&h->sk_err_host), sizeof(unsigned), hipHostMallocDefault));
-    *h->sk_err_host = 0;
-  }
-  RGM_TRY(rgm_dit_status(h));
-  RGM_CHECK_HIP(hipMemsetAsync(sk, 0, GEMM_SK_FLAG_BYTES, s));
-  return RGM_OK;
-}
-int sk_end(rgm_dit* h, const char* sk, hipStream_t s) {
-  RGM_CHECK_HIP(hipMemcpyAsync(h->sk_err_host, sk + GEMM_SK_ERR_OFFSET, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-  return RGM_OK;
 }
 
 // embedders + blocks; leaves the residual stream in plan.x and SiLU(c) modulation in plan.mod
@@ -495,7 +475,6 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     }
     return gemm2_launch(g, s);
   };
-  if (v2) RGM_TRY(sk_begin(h, p.sk, s));
   static const int dit_exp = RGM_EXP_ENV("RGM_DIT_EXP");   // timing experiments (common.h): 1 = fc1 without GELU/split, 2 = block-0 weights everywhere
   int xm_ready = 0;   // the previous block's fc2 has already written this block's first LayerNorm to plan.xm
   for (int i = 0; i < c.depth; ++i) {
@@ -527,7 +506,6 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     RGM_TRY(lin_gated(p.hid, 4 * D, h->p(b + "mlp.fc2.weight"), h->p(b + "mlp.fc2.bias"), p.x, p.M, D, 4 * D, m + 5 * D, L, T, s));
   }
   RGM_TRY(join());              // depth 1: nothing above waited
-  if (v2) RGM_TRY(sk_end(h, p.sk, s));
   return RGM_OK;
 }
 
@@ -628,7 +606,7 @@ struct GPlan {
   float *xs, *x1s, *qkvs, *aos, *pres, *lses;   // per-block saves (xs has depth+1 entries)
   float *xm, *hid, *dx, *dx1, *t1, *dbig, *dqkv, *dsmall;
   float *pool, *pooln, *z1pre, *z1, *logits, *dl, *dz1, *dpooln, *dpool, *dz, *dtin;
-  char* sk;          // stream-K / split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
+  char* sk;          // split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
   size_t sk_bytes;
   size_t bytes;
 };
@@ -749,7 +727,6 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
   const bool v2 = rgm_get_gemm_precision() == 2;
   h->sk_ws = p.sk;
   h->sk_ws_bytes = p.sk_bytes;
-  if (v2) RGM_TRY(sk_begin(h, p.sk, s));   // stream-K flag words + the previous call's error word (see run_backbone)
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string(i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
@@ -852,7 +829,6 @@ static int grad_embed_backward(rgm_dit* h, const GPlan& p, float* grad_x, hipStr
   }
   RGM_TRY(dgrad(h, "x_embedder.MLP.0.weight", p.dz, 256, p.dtin, pc, p.M0, nullptr, 0, 0, s));
   RGM_TRY(unpatchify_launch(p.dtin, grad_x, N, c.in_ch, H, c.width, s));
-  if (rgm_get_gemm_precision() == 2 && h->sk_err_host) RGM_TRY(sk_end(h, p.sk, s));
   return RGM_OK;
 }
 
@@ -938,18 +914,6 @@ extern "C" int rgm_dit_vjp(rgm_dit* h, const float* x, const int64_t* t, const i
 }
 
 
-
-// RGM_ERR_STATE (once) if a stream-K GEMM of an earlier forward of this handle timed out waiting for a partial tile -- that
-// forward's output is invalid.  No device synchronisation: call it after one (the samplers do, at the end of a loop).
-extern "C" int rgm_dit_status(rgm_dit* h) {
-  RGM_REQUIRE(h, "dit_status: null handle");
-  if (h->sk_err_host && *h->sk_err_host) {
-    *h->sk_err_host = 0;
-    set_error("dit: a stream-K GEMM timed out waiting for a partial tile in an earlier forward (its output is invalid)");
-    return RGM_ERR_STATE;
-  }
-  return RGM_OK;
-}
 
 // 1: the adaLN conditioning of blocks 1.. runs on the handle's side stream under block 0 (fork / join by events on the caller's stream:
 // still stream-ordered for the caller, capturable); 0 (default): one GEMM in front of block 0.  Same-box A/B at C2: 12.67 ms (0) vs

@@ -1693,7 +1693,6 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     RGM_REQUIRE(nb_cols > 0, "gemm2: tile %d (big + small tiles) does not apply to M=%d N=%d", tile, p.M, p.N);
     return tile == 49 ? launch_dual<64, 64>(p, nb_cols, s) : launch_dual<128, 64>(p, nb_cols, s);
   }
-  if (tile == 0 && gemm4_eligible(p)) tile = 47;   // >= 1.5 CU-rounds of 128x128 tiles: equal K-tile ranges per workgroup (gemm4.hip)
   if (tile == 0) {
     // tools/gemm_sweep.py on MI355X: cross-iteration pipeline (PIPE 3) at 128x128 (2 workgroups per CU) once the grid
     // fills at least one round of the chip, at 128x64 (3 per CU) below that; grids that do not even fill the CUs
@@ -1731,7 +1730,6 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 45: return launch2<256, 128, 4, 2, 2, 3>(p, s, 45);   // 96 KB, 8 waves
     case 46: return launch2<64, 64, 2, 2, 3, 3>(p, s, 46);     // 48 KB: 3 per CU
     // loader/consumer split (PIPE == 4): NW MFMA waves + NW DMA waves, 3-stage ring
-    case 47: return gemm4_launch(p, s);                        // persistent stream-K 128x128 (gemm4.hip)
     case 51: return launch2<128, 128, 2, 2, 3, 4>(p, s, 51);   // 96 KB: 1 per CU
     case 52: return launch2<128, 64, 2, 2, 3, 4>(p, s, 52);    // 72 KB: 2 per CU
     // deep rings for grids of at most one workgroup per CU
@@ -1745,10 +1743,6 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 71: return launch2<256, 256, 2, 2, 2, 5>(p, s, 71);   // 128 KB: 1 per CU, 512 registers
     case 73: return launch2<128, 256, 1, 4, 2, 5>(p, s, 73);   // 96 KB: 128x64 wave tiles, for M of a few thousand rows (B = 8: the shapes B = 16 has at 256 rows)
     case 72: return launch2<512, 128, 4, 1, 2, 5>(p, s, 72);   // 160 KB (all of the LDS): the same 128x128 wave tiles for N = 128 (VAE convs at 128 channels)
-    // persistent loader/consumer kernel (gemm3.hip)
-    case 61:
-    case 62:
-    case 63: return gemm3_launch(p, s, tile);
     default: break;
   }
   set_error("gemm2: unknown tile %d", tile);
@@ -1782,15 +1776,16 @@ int split_rows_launch(const float* x, float* out, long long rows, int K, int ld_
 }
 
 size_t gemm2_scratch_bytes(int M, int N) {
-  // split-K: up to 8 slices of a grid below 384 128x64 tiles (splitk_factor); stream-K: one slot per resident workgroup
+  // deterministic split-K: up to 8 slices of a grid below 384 128x64 tiles (splitk_factor), never less than the 32 MiB the K-sliced
+  // fc2 of a batch of 16 takes with room to spare.  The first GEMM_SK_FLAG_BYTES are reserved (the partial sums start behind them).
   const long long rows = (long long)cdiv(384, cdiv(N, 64)) * 128;
   const size_t splitk = (size_t)8 * (size_t)(M < rows ? M : rows) * N * sizeof(float);
-  const size_t streamk = gemm4_workspace_bytes() - GEMM_SK_FLAG_BYTES;
-  return GEMM_SK_FLAG_BYTES + (splitk > streamk ? splitk : streamk);
+  const size_t floor_ = (size_t)32 << 20;
+  return GEMM_SK_FLAG_BYTES + (splitk > floor_ ? splitk : floor_);
 }
 
 void gemm2_prof(bool on) { g2_prof_on = on; }
-// shared with gemm3.hip: bracket one launch with two events on its stream (no-ops while profiling is off)
+// bracket one launch with two events on its stream (no-ops while profiling is off)
 int gemm2_prof_begin(int id, double flops, hipStream_t s) {
   if (!g2_prof_on) return -1;
   Prof2 rec{};
@@ -1927,5 +1922,37 @@ extern "C" int rgm_gemm_split_ld(const float* A_split, int lda, const float* B_s
   rgm::GemmParams g;
   g.A = A_split; g.lda = lda; g.B = B_split; g.ldb = ldb; g.C = C; g.ldc = ldc;
   g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.tile = tile; g.out_split = out_split;
+  return rgm::gemm2_launch(g, (hipStream_t)stream);
+}
+
+// Bytes of scratch a caller should provide for pre-split GEMMs of up to M rows and N columns so that the heuristic may K-slice them
+// (deterministic split-K: S partial results + one fixed-order reduce kernel).  16-byte aligned caller memory, no initialisation needed.
+extern "C" size_t rgm_gemm_scratch_bytes(int M, int N) { return rgm::gemm2_scratch_bytes(M, N); }
+
+// rgm_gemm_split with caller-provided split-K scratch: tile 0 lets the heuristic pick (K slices when they pay).
+extern "C" int rgm_gemm_split_ws(const float* A_split, const float* B_split, float* C, int M, int N, int K, const float* bias, int act,
+                                 int tile, int out_split, void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(A_split && B_split && C && ws, "gemm_split_ws: null operand");
+  rgm::GemmParams g;
+  g.A = A_split; g.lda = K; g.B = B_split; g.ldb = K; g.C = C; g.ldc = N;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.tile = tile; g.out_split = out_split;
+  g.sk_ws = ws; g.sk_ws_bytes = ws_bytes;
+  return rgm::gemm2_launch(g, (hipStream_t)stream);
+}
+
+// The general entry of the pre-split GEMM family: every fused epilogue the DiT block uses (alpha, bias, activation, per-sample
+// adaLN gate, residual that may alias C, split-row output), explicit row strides, explicit tile (0 = heuristic, 7x = the
+// one-wave-per-SIMD kernels) and the caller's split-K scratch (may be NULL: decompositions that need it are then not chosen; forced
+// ones fail).  What guided_diffusion/dit.py:332-336 computes per block, in one launch.
+extern "C" int rgm_gemm_split_epi(const float* A_split, int lda, const float* B_split, int ldb, float* C, int ldc, int M, int N, int K,
+                                  const float* bias, int act, float alpha, const float* gate, int gate_ld, int rows_per_gate,
+                                  const float* res, int ldres, int tile, int out_split, void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(A_split && B_split && C, "gemm_split_epi: null operand");
+  rgm::GemmParams g;
+  g.A = A_split; g.lda = lda; g.B = B_split; g.ldb = ldb; g.C = C; g.ldc = ldc;
+  g.M = M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.alpha = alpha; g.tile = tile; g.out_split = out_split;
+  g.gate = gate; g.gate_ld = gate_ld; g.rows_per_gate = rows_per_gate > 0 ? rows_per_gate : 1;
+  g.res = res; g.ldres = ldres;
+  g.sk_ws = ws; g.sk_ws_bytes = ws ? ws_bytes : 0;
   return rgm::gemm2_launch(g, (hipStream_t)stream);
 }

@@ -36,16 +36,6 @@ def _attach(root, dotted, param):
     mod.register_parameter(leaf, param)
 
 
-import weakref as _weakref
-_LIVE = _weakref.WeakSet()      # every native DiT module alive in this process (check_native_status)
-
-
-def check_native_status():
-    """check_status() of every live native DiT module (eps-networks and classifiers): called by the samplers at the end of a loop."""
-    for m in list(_LIVE):
-        m.check_status()
-
-
 class _NativeDiT(nn.Module):
     """Parameter container + native handle shared by the eps-network and the classifiers."""
 
@@ -74,7 +64,6 @@ class _NativeDiT(nn.Module):
         self._dirty = True
         self._ws = None
         self._gws = None      # workspace of the input-gradient calls (saved activations)
-        _LIVE.add(self)
         self.register_load_state_dict_post_hook(lambda m, _: setattr(m, "_dirty", True))
         self.reset_parameters()
 
@@ -148,13 +137,6 @@ class _NativeDiT(nn.Module):
                 raise NotImplementedError("fractional timesteps (rescale_timesteps with T != 1000) are not supported")
             t = t.round()
         return t.to(dtype).contiguous()
-
-    def check_status(self):
-        """Raise RgmError if a persistent stream-K GEMM of an earlier forward of this module timed out waiting for a partial tile
-        (rgm_dit_status: that forward's output is invalid).  No device sync: every forward checks its predecessor; the samplers
-        call this once more when a loop ends."""
-        if self._handle is not None:
-            _rgm.check(_rgm.lib.rgm_dit_status(self._handle))
 
     def __del__(self):
         try:

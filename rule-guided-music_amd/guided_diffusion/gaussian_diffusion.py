@@ -919,8 +919,6 @@ class GaussianDiffusion:
                 self._t_host = None
             yield out
             img = out["sample"]
-        from .dit import check_native_status        # a stream-K GEMM that timed out inside the chain invalidates it: raise (no device sync)
-        check_native_status()
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, t_end=0,
                                   cond_fn=None, model_kwargs=None, device=None, progress=False, embed_model=None,

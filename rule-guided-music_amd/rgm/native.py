@@ -76,14 +76,11 @@ def _load():
         "rgm_rotary_attention_bwd": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_split_rows": (C.c_int, [vp, vp, C.c_int64, i32, vp]),
         "rgm_gemm_split": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp]),
-        "rgm_gemm_streamk_workspace_bytes": (sz, []),
-        "rgm_set_streamk": (C.c_int, [i32]),
+        "rgm_gemm_scratch_bytes": (sz, [i32, i32]),
         "rgm_set_big_tiles": (C.c_int, [i32, i32]),
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),
-        "rgm_gemm_streamk_status": (C.c_int, [vp, vp]),
-        "rgm_dit_status": (C.c_int, [vp]),
         "rgm_gemm_split_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_gemm_split_epi": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_split_rows_ld": (C.c_int, [vp, i32, vp, i32, C.c_int64, i32, vp]),

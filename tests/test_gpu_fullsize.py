@@ -1,8 +1,8 @@
 """-m gpu: parity at the sizes BASELINE configs 3-5 really run (round-2 review, "what's weak" 1 and 2).
 
 The goldens pin batches of 2; the kernels that carry C3 (B = 32), C4 (n.B = 64) and C5 (14-window batches at XL width) are chosen by
-M: the persistent stream-K kernel (gemm4.hip, profiler id 47) and the 256x256 one-wave-per-SIMD kernel (gemm5.hip, ids 71..) only
-run at M >= 4096 / 8192.  Covered here: their fused gate / residual epilogues against an fp64 product, the XL model at B = 32 / 64
+M: the one-wave-per-SIMD kernels (gemm2.hip PIPE 5: 256x256 / 512x128 / 128x256 tiles, profiler ids 111..113 and 121 / 122 for the
+implicit convs) only run at M >= 2048.  Covered here: their fused gate / residual epilogues against an fp64 product, the XL model at B = 32 / 64
 against batches of 2 (with proof, from the library's own launch records, that those kernels ran), one SCG search step at
 n.B = 64 against its 'rank r of 2' replay, and one guided DiffCollage step of config 5 at XL width."""
 import ctypes as C
@@ -62,20 +62,20 @@ class _Recorded:
         from rgm import native as R
         torch.cuda.synchronize()
         R.check(R.lib.rgm_prof_enable(0))
-        self.n = _launches([83, 84, 47, 111, 112, 113, 121, 122])
-        self.big = self.n[47] + self.n[111] + self.n[112] + self.n[113]
+        self.n = _launches([83, 84, 111, 112, 113, 121, 122])
+        self.big = self.n[111] + self.n[112] + self.n[113]
         R.check(R.lib.rgm_prof_reset())
 
 
-BIG_TILES = [47, 71, 72, 73]
+BIG_TILES = [71, 72, 73]
 
 
 @pytest.mark.parametrize("tile", BIG_TILES)
 @pytest.mark.parametrize("M,N,K,T", [(8192, 1152, 4608, 256), (16384, 1152, 1152, 256), (8192 + 200, 1152, 1152, 128), (4096, 1152, 4608, 256)])
 def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
     """proj / fc2 of a DiT block (dit.py:332-336: x = x + gate_b * (h W^T + bias), per-sample adaLN gate, residual read from and
-    written to C) through the persistent stream-K kernel (47) and the 256x256 kernel (71) on C3 / C4's shapes and one ragged M,
-    against the fp64 product; run twice on the same scratch (flags handed back), bit-identical, no spin timed out."""
+    written to C) through the one-wave-per-SIMD kernels (71 / 72 / 73) on C3 / C4's shapes and one ragged M, against the fp64
+    product; run twice on the same (uninitialised) scratch, bit-identical."""
     from gpu_util import dev, rel
     from rgm import native as R
     rng = np.random.RandomState(M + N + K + tile)
@@ -83,7 +83,7 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
     bias, res = rng.randn(N).astype(F32), rng.randn(M, N).astype(F32)
     gate = rng.randn((M + T - 1) // T, N + 64).astype(F32)          # gate rows are strided like the modulation buffer's
     As, Bs, bd, gd = _split(A), _split(B), dev(bias), dev(gate)
-    need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 4 * M * N * 4)
+    need = max(int(R.lib.rgm_gemm_scratch_bytes(M, N)), 4096 + 4 * M * N * 4)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     ws.fill_(0xAB)
     st = R.current_stream()
@@ -93,7 +93,6 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
         R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 0.7, R.ptr(gd), N + 64, T,
                                          R.ptr(x), N, tile, 0, R.ptr(ws), need, st))
         torch.cuda.synchronize()
-        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0, "a flag was left raised or a spin timed out"
         outs.append(x.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     assert rel(outs[0], _ref(A, B, bias, 0, 0.7, gate[:, :N], T, res)) < 3e-5
@@ -124,7 +123,7 @@ def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
     bias, res = rng.randn(N).astype(F32), rng.randn(M, N).astype(F32)
     gate = rng.randn((M + T - 1) // T, N + 64).astype(F32)
     As, Bs, bd, gd = _split(A), _split(B), dev(bias), dev(gate)
-    need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 8 * M * N * 4)
+    need = max(int(R.lib.rgm_gemm_scratch_bytes(M, N)), 4096 + 8 * M * N * 4)
     ws = torch.empty(need, dtype=torch.uint8, device="cuda")
     st = R.current_stream()
     outs = []
@@ -191,7 +190,7 @@ def test_fine_grained_gate_stays_off_the_big_tiles():
     res = rng.randn(M, N).astype(F32)
     As, Bs = _split(A), _split(B)
     bd, gd = dev(bias), dev(gate)
-    need = int(R.lib.rgm_gemm_streamk_workspace_bytes())
+    need = int(R.lib.rgm_gemm_scratch_bytes(M, N))
     ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
     st = R.current_stream()
     x = dev(res)
@@ -440,8 +439,16 @@ def test_long_sequence_guided_step_at_xl_width(monkeypatch, prec_depth):
         clear = (top2[0] - top2[1]) > 2e-4 * ref_total.abs().max()
         assert torch.equal(idx[clear], ref_idx[clear]), f"rank {rank}: other per-segment winners"
         assert int(clear.sum()) >= clear.numel() // 2
-        if torch.equal(idx, ref_idx):
-            assert torch.equal(s, ref_sample), f"rank {rank}: rebuilt segment winners differ"
+        # the rebuilt sample, segment by segment (128 latent rows each): bit-identical wherever the winners agree -- also when some OTHER
+        # segment flipped on a tie; a flipped segment must hold exactly the other candidate (not a mixture): it differs there
+        same = (idx == ref_idx)
+        for seg in range(S):
+            for b in range(B):
+                a, r_ = s[b, :, seg * 128:(seg + 1) * 128], ref_sample[b, :, seg * 128:(seg + 1) * 128]
+                if bool(same[seg, b]):
+                    assert torch.equal(a, r_), f"rank {rank}: segment {seg} of sample {b} has the same winner but other values"
+                else:
+                    assert not bool(clear[seg, b]) and not torch.equal(a, r_)
 
 
 _DECODE_SNIPPET = """
@@ -492,6 +499,27 @@ def test_two_rank_scg_bench_control_flow_on_one_device():
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and "PLUMBING" in line["data"]
     assert line["config"]["same_winners_on_every_rank"] is True, line
+
+
+def test_forward_time_has_no_cliff_between_neighbouring_batch_sizes():
+    """gemm2_launch's tile choice is a hand-tuned ladder fitted to B = 16 / 32 / 64 and C5's window batches: the
+    XL-28 forward is timed over the batch sizes in between and the cost PER SAMPLE may not rise by more than 10 % from one batch size to
+    the next larger one (tools/batch_sweep.py prints the table; round 4: the worst step is B = 24 -> 28 at +9 %).  A pair over the bar is
+    measured once more before it counts (boxes drift by a few percent within a run)."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import batch_sweep
+    Bs = [2, 3, 4, 6, 8, 10, 12, 14, 16, 20, 24, 28, 32, 40, 48, 56, 64]
+    rows = dict(batch_sweep.sweep(Bs))
+    per = {B: rows[B] / B for B in Bs}
+    for a, b in zip(Bs[:-1], Bs[1:]):
+        ratio = per[b] / per[a]
+        if ratio > 1.10:
+            again = dict(batch_sweep.sweep([a, b], reps=15))
+            ratio = (again[b] / b) / (again[a] / a)
+        assert ratio <= 1.10, f"per-sample cost rises x{ratio:.3f} from B = {a} to B = {b}: {rows}"
+    assert per[64] < per[16] < per[4] < per[2]
 
 
 def test_eight_rank_scg_bench_control_flow_on_one_device():

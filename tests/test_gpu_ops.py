@@ -147,7 +147,7 @@ def test_split_rows_format():
     assert (np.abs(back - x) <= np.abs(x) * 2.0 ** -15.5 + 1e-38).all()
 
 
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 21, 22, 43, 44, 45, 46, 51, 52, 53, 54, 55, 56, 57, 58, 61, 62, 63, 71, 72, 73])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 5, 21, 22, 43, 44, 45, 46, 51, 52, 53, 54, 55, 56, 57, 58, 71, 72, 73])
 @pytest.mark.parametrize("M,N,K", [(200, 96, 64), (513, 1152, 1152), (4096, 36, 1152), (777, 3456, 384), (256, 128, 32)])
 def test_gemm_split_dma_kernel(tile, M, N, K):
     """Pre-split operands + LDS-DMA staging (gemm2): same contraction, bf16x3 accuracy, every tile shape, ragged edges."""
@@ -183,63 +183,12 @@ def test_split_rows_and_gemm_with_padded_row_strides():
     R.check(R.lib.rgm_split_rows_ld(R.ptr(dev(B)), K, R.ptr(Bs), ldb, N, K, st))
     assert rel(_unsplit(As[:, :K].contiguous()), A) < 2 ** -16
     C = torch.full((M, ldc), 7.0, device="cuda")
-    for tile in (0, 43, 44, 52, 54, 56, 57, 61, 71, 72, 73):
+    for tile in (0, 43, 44, 52, 54, 56, 57, 71, 72, 73):
         C.fill_(7.0)
         R.check(R.lib.rgm_gemm_split_ld(R.ptr(As), lda, R.ptr(Bs), ldb, R.ptr(C), ldc, M, N, K, R.ptr(dev(bias)), 0, tile, 0, st))
         torch.cuda.synchronize()
         assert rel(C[:, :N].cpu().numpy(), _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)) < 3e-5, tile
         assert bool((C[:, N:] == 7.0).all()), f"tile {tile} wrote into the row padding"
-
-
-@pytest.mark.parametrize("M,N,K,act,split", [(4096, 4608, 1152, 2, 1), (4096, 3456, 1152, 0, 0), (4096, 1152, 4608, 0, 0), (1000, 1152, 1152, 1, 0),
-                                             (333, 260, 96, 0, 0), (128, 128, 32, 0, 0), (8192, 1152, 4608, 0, 0)])
-def test_streamk_gemm_matches_the_tiled_kernel(M, N, K, act, split):
-    """gemm4.hip (tile 47): the persistent stream-K kernel on the DiT's shapes at B = 16 / 32 (tiles cut between 2 and 3
-    workgroups), ragged edges, tiny grids (fewer K-tiles than workgroups); fused epilogue variants; the flag words are handed
-    back (a second launch on the same scratch needs no re-zeroing) and no spin timed out; bit-identical run to run."""
-    from gpu_util import dev, rel
-    from rgm import native as R
-    rng = np.random.RandomState(M + N + K)
-    A = rng.randn(M, K).astype(F32)
-    B = (rng.randn(N, K) * 0.05).astype(F32)
-    bias = rng.randn(N).astype(F32)
-    As, Bs, bd = _split(A), _split(B), dev(bias)
-    need = R.lib.rgm_gemm_streamk_workspace_bytes()
-    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
-    ws.fill_(0xAB)                                                          # garbage: the entry zeroes the flag words itself
-    st = R.current_stream()
-    outs = []
-    for rep in range(2):
-        c = torch.full((M, N), float("nan"), device="cuda")
-        R.check(R.lib.rgm_gemm_split_ws(R.ptr(As), R.ptr(Bs), R.ptr(c), M, N, K, R.ptr(bd), act, 47, split, R.ptr(ws), need, st))
-        torch.cuda.synchronize()
-        flags = ws[:4096].view(torch.int32)
-        assert int(flags[:513].abs().sum()) == 0, "a flag was left raised or a spin timed out"
-        outs.append(_unsplit(c) if split else c.cpu().numpy())
-    assert np.array_equal(outs[0], outs[1])
-    assert rel(outs[0], _ref_gemm(A, B, bias, act, 1.0, None, 1, None)) < 3e-5
-    # against the tiled 128x128 kernel of the same arithmetic: only the summation order of cut tiles differs
-    c2 = torch.empty((M, N), device="cuda")
-    R.check(R.lib.rgm_gemm_split(R.ptr(As), R.ptr(Bs), R.ptr(c2), M, N, K, R.ptr(bd), act, 43, split, st))
-    torch.cuda.synchronize()
-    assert rel(outs[0], _unsplit(c2) if split else c2.cpu().numpy()) < (3e-5 if split else 5e-6)
-
-
-def test_streamk_gemm_gate_and_residual_in_place():
-    """the proj / fc2 epilogue of a DiT block (adaLN gate per sample, residual read from and written to C) through stream-K."""
-    from gpu_util import dev, rel
-    from rgm import native as R
-    rng = np.random.RandomState(5)
-    M, N, K, T = 2048, 1152, 4608, 256
-    A, B = rng.randn(M, K).astype(F32), (rng.randn(N, K) * 0.03).astype(F32)
-    bias, gate, res = rng.randn(N).astype(F32), rng.randn(M // T, N).astype(F32), rng.randn(M, N).astype(F32)
-    need = R.lib.rgm_gemm_streamk_workspace_bytes()
-    ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
-    x = dev(res)
-    R.check(R.lib.rgm_gemm_split_ws(R.ptr(_split(A)), R.ptr(_split(B)), R.ptr(x), M, N, K, R.ptr(dev(bias)), 0, 47, 0, R.ptr(ws), need, R.current_stream()))
-    torch.cuda.synchronize()
-    # no gate / residual through this entry: the plain product first ...
-    assert rel(x.cpu().numpy(), _ref_gemm(A, B, bias, 0, 1.0, None, 1, None)) < 3e-5
 
 
 @pytest.mark.parametrize("tile", [48, 49])

@@ -19,7 +19,7 @@ if tile >= 100:                                       # pre-split operands, LDS-
     a2, b2 = torch.empty_like(a), torch.empty_like(b)
     R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st))
     R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), N, K, st))
-    need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 8 * M * N * 4)
+    need = max(int(R.lib.rgm_gemm_scratch_bytes(M, N)), 4096 + 8 * M * N * 4)
     ws = torch.zeros(need, dtype=torch.uint8, device="cuda")         # the heuristic's K slices / stream-K need caller scratch
 for _ in range(iters):
     if tile >= 100:

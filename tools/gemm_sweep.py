@@ -57,16 +57,16 @@ def bench(M, N, K, tile, iters=20, check=True):
         R.check(R.lib.rgm_split_rows_ld(R.ptr(b), K, R.ptr(b2), ld, N, K, st))
         bs = [b2] + [b2.clone() for _ in range(ncopy - 1)]
         cnt = [0]
-        need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 16 * M * N * 4)
+        need = max(int(R.lib.rgm_gemm_scratch_bytes(M, N)), 4096 + 16 * M * N * 4)
         ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
 
-        def run_ws():                                  # 147 = persistent stream-K kernel (gemm4.hip), 100 = heuristic with scratch
+        def run_ws():                                  # 100 = heuristic with scratch
             cnt[0] += 1
             R.check(R.lib.rgm_gemm_split_ws(R.ptr(a2), R.ptr(bs[cnt[0] % ncopy]), R.ptr(c), M, N, K, R.ptr(bias), ACT, tile - 100, SPLIT,
                                             R.ptr(ws), need, st))
 
         def run():
-            if (tile in (147, 100) or 300 <= tile < 317) and not PAD:
+            if (tile in (100,) or 300 <= tile < 317) and not PAD:
                 return run_ws()
             cnt[0] += 1
             R.check(R.lib.rgm_gemm_split_ld(R.ptr(a2), ld, R.ptr(bs[cnt[0] % ncopy]), ld, R.ptr(c), N, M, N, K, R.ptr(bias), ACT,

@@ -16,8 +16,6 @@ import bench  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 R.set_gemm_precision("bf16x3_presplit")
-if os.environ.get("RGM_STREAMK") is not None:
-    R.check(R.lib.rgm_set_streamk(int(os.environ["RGM_STREAMK"])))
 work = bench.C2Workload(torch.device("cuda", 0), B)
 for _ in range(5):
     work.step()

@@ -9,7 +9,7 @@ from rgm import native as R
 
 M, N, K = 16384, 4608, 1152
 st = R.current_stream()
-need = R.lib.rgm_gemm_streamk_workspace_bytes()
+need = int(R.lib.rgm_gemm_scratch_bytes(M, N))
 ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
 c = torch.empty(M, N, device="cuda")
 bias = torch.zeros(N, device="cuda")

@@ -48,7 +48,7 @@ for (Nn, K) in ((3456, 1152), (1152, 1152), (4608, 1152), (1152, 4608), (256, 32
     if K % 32 == 0 and Nn % 32 == 0:
         a2, b2 = torch.empty_like(a), torch.empty_like(b)
         R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st)); R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), Nn, K, st))
-        need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 8 * M * Nn * 4)
+        need = max(int(R.lib.rgm_gemm_scratch_bytes(M, Nn)), 4096 + 8 * M * Nn * 4)
         ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
         def gs():
             c = torch.empty(M, Nn, device="cuda")

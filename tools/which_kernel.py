@@ -19,7 +19,7 @@ for M, N, K in zip(args[0::3], args[1::3], args[2::3]):
     st = R.current_stream()
     R.check(R.lib.rgm_split_rows(R.ptr(a), R.ptr(a2), M, K, st))
     R.check(R.lib.rgm_split_rows(R.ptr(b), R.ptr(b2), N, K, st))
-    need = max(R.lib.rgm_gemm_streamk_workspace_bytes(), 4096 + 8 * M * N * 4)
+    need = max(int(R.lib.rgm_gemm_scratch_bytes(M, N)), 4096 + 8 * M * N * 4)
     ws = torch.zeros(need, dtype=torch.uint8, device="cuda")
     tile = int(os.environ.get("TILE", "0"))
     for it in range(12):
