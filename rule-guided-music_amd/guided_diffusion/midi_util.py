@@ -78,7 +78,7 @@ def register_midi_reader(fn):
 
 def read_midi_piano_roll(path, fs=100):
     """MIDI file -> (3,128,T) [velocity | onset | pedal] roll.  Default: the built-in SMF reader + get_full_piano_roll's logic
-    (music_rule_guidance.piano_roll_to_chord; its onset channel is an assumption about the reference's pretty_midi fork);
+    (music_rule_guidance.piano_roll_to_chord; all three channels pinned to the reference's pretty_midi fork, tests/golden/midi_rolls.npz);
     register_midi_reader replaces it, e.g. with the fork itself."""
     if _MIDI_READER is not None:
         return np.asarray(_MIDI_READER(path, fs), dtype=np.float32)

@@ -258,30 +258,42 @@ def quantize_pedal(value, num_bins=8):
 
 
 def midi_to_full_piano_roll(pm, fs=100):
-    """SimpleMIDI -> (3,128,T) [velocity | onset | pedal] float32 roll (reference midi_util.py:267-291 get_full_piano_roll over
-    its pretty_midi fork's get_piano_roll(fs, pedal_threshold=None, onset=True)).  The fork is not part of the reference
-    repository; velocity follows pretty_midi's documented get_piano_roll (velocity held over [int(start*fs), int(end*fs)),
-    summed over instruments, clipped to 127), the onset channel is ASSUMED to be the note's velocity at its first column
-    -- parity unpinned for that channel.  The pedal channel is the reference's own code."""
-    T = int(math.ceil(pm.get_end_time() * fs))
-    roll = np.zeros((3, 128, max(T, 1)), dtype=np.float32)
+    """SimpleMIDI (or anything with .instruments of notes / control_changes) -> (3,128,T) [velocity | onset | pedal] float32 roll:
+    the reference's get_full_piano_roll (midi_util.py:267-291) over its vendored pretty_midi FORK's
+    get_piano_roll(fs, pedal_threshold=None, onset=True) (/root/reference/pretty_midi/instrument.py:70-205, pretty_midi.py:797-852),
+    restated and pinned to both (tests/golden/midi_rolls.npz):
+      * per instrument: no notes -> nothing (the fork's onset=True path cannot unpack such an instrument and raises); int(fs * end_time) columns, end_time = last note end / control change of THAT instrument;
+        drums -> zeros; velocity += over [int(start*fs), int(end*fs)) (overlaps add up, nothing is clipped; a note shorter than a
+        column leaves no velocity); onset = 127 (a binary mark, not the velocity) at min(int(start*fs), columns - 1);
+      * instruments are summed into max-columns rolls, the onset roll clipped to 127;
+      * pedal: the reference's own loop (quantised CC 64 values on the piano rows, a 0 -> 127 jump in one column shifted by two)."""
+    rolls = []
     for ins in pm.instruments:
-        if ins.is_drum:
+        if not ins.notes:
             continue
-        for n in ins.notes:
-            a, b = int(n.start * fs), int(n.end * fs)
-            if a < roll.shape[2]:
-                roll[0, n.pitch, a:max(b, a + 1)] += n.velocity
-                roll[1, n.pitch, a] = n.velocity
-    np.clip(roll[0], 0, 127, out=roll[0])
+        ends = [n.end for n in ins.notes] + [c.time for c in ins.control_changes] + [b.time for b in getattr(ins, "pitch_bends", [])]
+        cols = int(fs * max(ends))
+        vel, on = np.zeros((128, cols)), np.zeros((128, cols))
+        if not ins.is_drum:
+            for n in ins.notes:
+                vel[n.pitch, int(n.start * fs):int(n.end * fs)] += n.velocity
+                if cols > 0:
+                    on[n.pitch, min(int(n.start * fs), cols - 1)] = 127
+        rolls.append((vel, on))
+    T = max([v.shape[1] for v, _ in rolls], default=0)
+    roll = np.zeros((3, 128, T), dtype=np.float64)
+    for v, o in rolls:
+        roll[0, :, :v.shape[1]] += v
+        roll[1, :, :o.shape[1]] += o
+    np.clip(roll[1], 0, 127, out=roll[1])
     for ins in pm.instruments:
         for cc in ins.control_changes:
             if cc.number != 64:
                 continue
             t = int(cc.time * fs)
-            if t < roll.shape[2]:
+            if t < T:
                 if roll[2, MIN_PIANO, t] != 0.0 and abs(roll[2, MIN_PIANO, t] - cc.value) > 64:
-                    roll[2, MIN_PIANO:MAX_PIANO + 1, min(t + 2, roll.shape[2] - 1)] = quantize_pedal(cc.value)
+                    roll[2, MIN_PIANO:MAX_PIANO + 1, min(t + 2, T - 1)] = quantize_pedal(cc.value)
                 else:
                     roll[2, MIN_PIANO:MAX_PIANO + 1, t] = quantize_pedal(cc.value)
-    return roll
+    return roll.astype(np.float32)

@@ -1395,6 +1395,80 @@ def g_midi():
     save("midi_events", **out)
 
 
+def _ref_pretty_midi():
+    """the reference's vendored pretty_midi fork (/root/reference/pretty_midi) under an alias -- ref_shims registers an inert
+    `pretty_midi` for the sampling path; the fork itself imports with `mido` stubbed (only file I/O needs mido)"""
+    import importlib.util
+    if "ref_pretty_midi" not in sys.modules:
+        spec = importlib.util.spec_from_file_location("ref_pretty_midi", "/root/reference/pretty_midi/__init__.py",
+                                                      submodule_search_locations=["/root/reference/pretty_midi"])
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["ref_pretty_midi"] = mod
+        spec.loader.exec_module(mod)
+    return sys.modules["ref_pretty_midi"]
+
+
+def g_midi_rolls():
+    """(3,128,T) rolls the REFERENCE builds from note / pedal events: get_full_piano_roll (midi_util.py:267-291) over its vendored
+    pretty_midi fork's get_piano_roll(onset=True) (instrument.py:70-205, pretty_midi.py:797-852) -- (a) random events on two instruments
+    (overlapping notes, sub-column notes, a note starting in the last column, a drum track, pedal jumps inside one column), (b) the
+    round trip of midi_events' r3 roll: piano_roll_to_pretty_midi with the fork's real classes, then get_full_piano_roll."""
+    print("[midi rolls: the reference's pretty_midi fork]")
+    rpm = _ref_pretty_midi()
+    from music_rule_guidance import piano_roll_to_chord as rp2c
+    out = {}
+    rng = np.random.RandomState(520)
+    pm = rpm.PrettyMIDI()
+    ev = {}
+    for k, (n_notes, drum) in enumerate(((70, False), (25, False), (10, True))):
+        ins = rpm.Instrument(program=0, is_drum=drum)
+        notes, ccs = [], []
+        for _ in range(n_notes):
+            p, a = int(rng.randint(21, 109)), float(rng.rand() * 5.5)
+            d = float(rng.choice([0.004, 0.03, 0.2, 0.9, 2.5]) * (0.5 + rng.rand()))
+            notes.append((int(rng.randint(1, 128)), p, a, a + d))
+        notes.append((99, 60, 6.0 - 0.004, 6.0))                          # starts in the last column
+        notes.append((50, 60, 1.0, 2.0))
+        notes.append((60, 60, 1.5, 2.5))                                  # overlaps the previous one on the same pitch
+        if k == 0:
+            t = 0.0
+            for j in range(30):
+                t += float(rng.rand() * 0.3)
+                ccs.append((64, int(rng.choice([0, 10, 40, 100, 127])), t))
+                if j % 7 == 3:
+                    ccs.append((64, 127 - ccs[-1][1], t + 0.001))          # the 0 <-> 127 jump inside one column (:280-283)
+            ccs.append((64, 0, 6.3))                                       # a control change behind the last note end
+            ccs.append((7, 100, 0.5))                                      # not a pedal
+        for v, p, a, b in notes:
+            ins.notes.append(rpm.Note(velocity=v, pitch=p, start=a, end=b))
+        for nmb, v, tt in ccs:
+            ins.control_changes.append(rpm.ControlChange(number=nmb, value=v, time=tt))
+        pm.instruments.append(ins)
+        ev[f"ev.notes{k}"] = np.array(notes, dtype=np.float64).reshape(-1, 4)
+        ev[f"ev.ccs{k}"] = np.array(ccs, dtype=np.float64).reshape(-1, 3)
+        ev[f"ev.drum{k}"] = np.array(int(drum))
+    # As shipped, get_full_piano_roll dies with NameError: CC_SUSTAIN_PEDAL is never defined in midi_util.py (:274).  The fork's own
+    # get_piano_roll defines the same name locally as 64 (instrument.py:129): injected here so that the function's logic can be pinned.
+    assert not hasattr(rmu, "CC_SUSTAIN_PEDAL")
+    rmu.CC_SUSTAIN_PEDAL = 64
+    full = rmu.get_full_piano_roll(pm, fs=100)
+    assert full.shape[0] == 3 and full.max() > 127 and np.array_equal(full, np.round(full))
+    out.update(ev)
+    out["ev.full"] = full.astype(np.int16)
+    print(f"    events: roll {full.shape}, velocity max {full[0].max():.0f} (overlaps add up), onset values {np.unique(full[1])}")
+    g = np.load(os.path.join(HERE, "midi_events.npz"))
+    old = rp2c.pretty_midi
+    rp2c.pretty_midi = rpm
+    try:
+        pm2 = rp2c.piano_roll_to_pretty_midi(g["r3.roll"].astype(F32), fs=100)
+    finally:
+        rp2c.pretty_midi = old
+    back = rmu.get_full_piano_roll(pm2, fs=100)
+    out["r3.reroll"] = back.astype(np.int16)
+    print(f"    r3 round trip: {g['r3.roll'].shape} -> {back.shape}; velocity equal on {np.mean(back[0][:, :g['r3.roll'].shape[2]] == g['r3.roll'][0][:, :back.shape[2]]):.4f} of the cells")
+    save("midi_rolls", **out)
+
+
 def chord_test_roll(seed):
     """(3,3,128,256) roll with values on both sides of the -0.95 snap, outside [-1,1] and in the non-piano rows (the tests
     rebuild it from the seed: tests/conftest.py chord_test_roll is this function)."""
@@ -1534,7 +1608,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "midi_rolls"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1581,6 +1655,8 @@ if __name__ == "__main__":
         g_dpsrule()
     if "midi" in which:
         g_midi()
+    if "midi_rolls" in which:
+        g_midi_rolls()
     if "chordq" in which:
         g_chordq()
     if "cli" in which:

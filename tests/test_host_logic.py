@@ -267,6 +267,30 @@ def test_piano_roll_note_events_match_reference(tag):
     assert np.array_equal(notes, g[f"{tag}.notes"]) and np.array_equal(ccs, g[f"{tag}.ccs"])
 
 
+def test_full_piano_roll_matches_the_references_pretty_midi_fork():
+    """midi_to_full_piano_roll against the reference's get_full_piano_roll (midi_util.py:267-291) run over its vendored pretty_midi
+    fork (pretty_midi/instrument.py:70-205: onset = 127 at the note's first column, velocities of overlapping notes add up unclipped,
+    int(fs * end_time) columns per instrument, drums silent) -- fixture midi_rolls.npz, made by importing both: (a) random events on three
+    instruments, (b) the round trip roll -> events -> roll of the r3 test roll."""
+    from music_rule_guidance.piano_roll_to_chord import Instrument, Note, ControlChange, SimpleMIDI, midi_to_full_piano_roll, piano_roll_to_pretty_midi
+    g = load_golden("midi_rolls")
+    pm = SimpleMIDI()
+    for k in range(3):
+        ins = Instrument(program=0, is_drum=bool(int(g[f"ev.drum{k}"])))
+        for v, p_, a, b in g[f"ev.notes{k}"]:
+            ins.notes.append(Note(velocity=int(v), pitch=int(p_), start=float(a), end=float(b)))
+        for nmb, v, t in g[f"ev.ccs{k}"]:
+            ins.control_changes.append(ControlChange(number=int(nmb), value=int(v), time=float(t)))
+        pm.instruments.append(ins)
+    full = midi_to_full_piano_roll(pm, fs=100)
+    assert full.shape == g["ev.full"].shape and full.dtype == np.float32
+    assert np.array_equal(full, g["ev.full"].astype(np.float32))
+    assert full[0].max() > 127 and set(np.unique(full[1])) == {0.0, 127.0}
+    ev = load_golden("midi_events")
+    back = midi_to_full_piano_roll(piano_roll_to_pretty_midi(ev["r3.roll"].astype(np.float32), fs=100), fs=100)
+    assert np.array_equal(back, g["r3.reroll"].astype(np.float32))
+
+
 def test_midi_file_round_trip_and_default_io(tmp_path):
     """The built-in SMF writer / reader (no pretty_midi): events survive write -> read to the tick (1/440 s), the default
     save_piano_roll_midi writes .midi + .npy under the reference's names, read_midi_piano_roll returns a (3,128,T) roll whose
@@ -292,10 +316,10 @@ def test_midi_file_round_trip_and_default_io(tmp_path):
     midi_util.save_piano_roll_midi(roll[None], str(tmp_path), fs=100, y=np.array([2]), save_ind=5)
     assert sorted(os.listdir(tmp_path)) == ["a.midi", "sample_5_y_2.midi", "sample_5_y_2.npy"]
     full = midi_util.read_midi_piano_roll(str(tmp_path / "sample_5_y_2.midi"), fs=100)
-    assert full.shape[:2] == (3, 128) and full.dtype == np.float32 and full.max() <= 127
+    assert full.shape[:2] == (3, 128) and full.dtype == np.float32
     n0 = back.instruments[0].notes[0]
     s, e = int(n0.start * 100), int(n0.end * 100)
-    assert (full[0, n0.pitch, s:e] > 0).all() and full[1, n0.pitch, s] > 0
+    assert (full[0, n0.pitch, s:e] > 0).all() and full[1, n0.pitch, s] == 127
     assert set(np.unique(full[2])) <= {0.0} | {float(v) for v in range(8, 128, 16)}      # quantised pedal bins
     # a registered writer / reader replaces the defaults
     seen = []
