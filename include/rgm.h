@@ -100,6 +100,9 @@ int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const
  * Process-wide default used by all handles; results stay within the 1e-3 latent tolerance in every mode (tests). */
 int rgm_set_gemm_precision(int prec);
 int rgm_get_gemm_precision(void);
+/* Element type of the hi / lo halves the bf16x3 modes split fp32 operands into -- a build constant of the library: 0 = bf16 (default
+ * build), 1 = fp16 (make F16=1 -> librgm_hip_f16.so: 2^-22 instead of 2^-16 per product at the same MFMA rate, fp16's exponent range). */
+int rgm_split_dtype(void);
 /* Split-row format of the pre-split bf16x3 path (precision 2, "bf16x3_presplit"): a logical fp32 row of K values
  * keeps its K*4 bytes; every block of 32 values is one 128-byte line [32 bf16 hi | 32 bf16 lo] (x ~= hi + lo, both
  * round-to-nearest; K % 32 == 0).  rgm_split_rows converts (rows,K) fp32 -> split (out-of-place); rgm_gemm_split is

@@ -180,12 +180,12 @@ __global__ __launch_bounds__(512) void rotary_attention_kernel(const float* __re
           if (d < HD) {
             const float4 ov = make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
             if (out_split) {   // split-row format (common.h split_idx): A operand of the pre-split proj GEMM
-              typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+              typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
               bf16x4 hi, lo;
-              hi[0] = (__bf16)ov.x; hi[1] = (__bf16)ov.y; hi[2] = (__bf16)ov.z; hi[3] = (__bf16)ov.w;
-              lo[0] = (__bf16)(ov.x - (float)hi[0]); lo[1] = (__bf16)(ov.y - (float)hi[1]);
-              lo[2] = (__bf16)(ov.z - (float)hi[2]); lo[3] = (__bf16)(ov.w - (float)hi[3]);
-              __bf16* rp = reinterpret_cast<__bf16*>(o + ((long long)n * T + q) * D);
+              hi[0] = (split_t)ov.x; hi[1] = (split_t)ov.y; hi[2] = (split_t)ov.z; hi[3] = (split_t)ov.w;
+              lo[0] = (split_t)(ov.x - (float)hi[0]); lo[1] = (split_t)(ov.y - (float)hi[1]);
+              lo[2] = (split_t)(ov.z - (float)hi[2]); lo[3] = (split_t)(ov.w - (float)hi[3]);
+              split_t* rp = reinterpret_cast<split_t*>(o + ((long long)n * T + q) * D);
               const int si = split_idx(head * HD + d);      // d % 4 == 0: the 4 elements share a 32-block
               *reinterpret_cast<bf16x4*>(rp + si) = hi;
               *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;

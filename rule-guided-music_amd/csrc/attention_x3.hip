@@ -18,13 +18,13 @@
 
 namespace rgm {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef split_t bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split8(const float* v, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    hi[i] = (__bf16)v[i];
-    lo[i] = (__bf16)(v[i] - (float)hi[i]);
+    hi[i] = (split_t)v[i];
+    lo[i] = (split_t)(v[i] - (float)hi[i]);
   }
 }
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
   const int R = 2 * rot_half;
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
 
 #ifdef RGM_ATTN_STAMPS
   if (threadIdx.x == 0 && blockIdx.x < 1024) g_attn_real[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -115,9 +115,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
     }
     {
       bf16x4 hi, lo;
-      hi[0] = (__bf16)kv.x; hi[1] = (__bf16)kv.y; hi[2] = (__bf16)kv.z; hi[3] = (__bf16)kv.w;
-      lo[0] = (__bf16)(kv.x - (float)hi[0]); lo[1] = (__bf16)(kv.y - (float)hi[1]);
-      lo[2] = (__bf16)(kv.z - (float)hi[2]); lo[3] = (__bf16)(kv.w - (float)hi[3]);
+      hi[0] = (split_t)kv.x; hi[1] = (split_t)kv.y; hi[2] = (split_t)kv.z; hi[3] = (split_t)kv.w;
+      lo[0] = (split_t)(kv.x - (float)hi[0]); lo[1] = (split_t)(kv.y - (float)hi[1]);
+      lo[2] = (split_t)(kv.z - (float)hi[2]); lo[3] = (split_t)(kv.w - (float)hi[3]);
       char* kr = Ks + key * KROW + d0 * 2;
       *reinterpret_cast<bf16x4*>(kr) = hi;
       *reinterpret_cast<bf16x4*>(kr + KP * 2) = lo;
@@ -130,10 +130,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const __bf16 hi = (__bf16)vs[i];
+        const split_t hi = (split_t)vs[i];
         char* vr = Vt + (d0 + i) * VROW + pos * 2;
-        *reinterpret_cast<__bf16*>(vr) = hi;
-        *reinterpret_cast<__bf16*>(vr + TP * 2) = (__bf16)(vs[i] - (float)hi);
+        *reinterpret_cast<split_t*>(vr) = hi;
+        *reinterpret_cast<split_t*>(vr + TP * 2) = (split_t)(vs[i] - (float)hi);
       }
     }
   }
@@ -246,9 +246,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
       for (int j = 0; j < KS; ++j) {
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 32 * j);
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + 32 * j + KP * 2);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[j], sacc[kt], 0, 0, 0);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[j], sacc[kt], 0, 0, 0);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = RGM_MFMA_SPLIT_32x32x16(kl, qh[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = RGM_MFMA_SPLIT_32x32x16(kh, ql[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = RGM_MFMA_SPLIT_32x32x16(kh, qh[j], sacc[kt], 0, 0, 0);
       }
     }
     ATTN_STAMP(4)
@@ -309,9 +309,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
         for (int dt = 0; dt < DT; ++dt) {
           const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vt + vrow[dt] + koff);
           const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vt + vrow[dt] + koff + TP * 2);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[dt], 0, 0, 0);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[dt], 0, 0, 0);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[dt], 0, 0, 0);
+          oacc[dt] = RGM_MFMA_SPLIT_32x32x16(vl, ph, oacc[dt], 0, 0, 0);
+          oacc[dt] = RGM_MFMA_SPLIT_32x32x16(vh, pl, oacc[dt], 0, 0, 0);
+          oacc[dt] = RGM_MFMA_SPLIT_32x32x16(vh, ph, oacc[dt], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the V^T reads of later key tiles from being hoisted (spills)
@@ -329,10 +329,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
             const float4 ov = make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
             if (out_split) {   // split-row format (common.h split_idx): A operand of the pre-split proj GEMM
               bf16x4 hi, lo;
-              hi[0] = (__bf16)ov.x; hi[1] = (__bf16)ov.y; hi[2] = (__bf16)ov.z; hi[3] = (__bf16)ov.w;
-              lo[0] = (__bf16)(ov.x - (float)hi[0]); lo[1] = (__bf16)(ov.y - (float)hi[1]);
-              lo[2] = (__bf16)(ov.z - (float)hi[2]); lo[3] = (__bf16)(ov.w - (float)hi[3]);
-              __bf16* rp = reinterpret_cast<__bf16*>(o + ((long long)n * T + q) * D);
+              hi[0] = (split_t)ov.x; hi[1] = (split_t)ov.y; hi[2] = (split_t)ov.z; hi[3] = (split_t)ov.w;
+              lo[0] = (split_t)(ov.x - (float)hi[0]); lo[1] = (split_t)(ov.y - (float)hi[1]);
+              lo[2] = (split_t)(ov.z - (float)hi[2]); lo[3] = (split_t)(ov.w - (float)hi[3]);
+              split_t* rp = reinterpret_cast<split_t*>(o + ((long long)n * T + q) * D);
               const int si = split_idx(head * HD + d);      // d % 4 == 0: the 4 elements share a 32-block
               *reinterpret_cast<bf16x4*>(rp + si) = hi;
               *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
   const int R = 2 * rot_half;
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int nb = (T + KB - 1) / KB;
 #ifdef RGM_EXPERIMENTS   // staggered starts: workgroup classes (blockIdx % groups) begin `delay` x 1024 cycles (~0.5 us) apart (RGM_ATTN_STAGGER=groups*100+delay)
@@ -487,8 +487,8 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
       bf16x4 hi, lo;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        hi[i] = (__bf16)kr[i];
-        lo[i] = (__bf16)(kr[i] - (float)hi[i]);
+        hi[i] = (split_t)kr[i];
+        lo[i] = (split_t)(kr[i] - (float)hi[i]);
       }
       char* krp = Ks + key * KROW + d0 * 2;
       *reinterpret_cast<bf16x4*>(krp) = hi;
@@ -504,10 +504,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
       const float vs[4] = {vq[sl].x, vq[sl].y, vq[sl].z, vq[sl].w};
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const __bf16 vh = (__bf16)vs[i];
+        const split_t vh = (split_t)vs[i];
         char* vr = Vt + (d0 + i) * VROW + pos * 2;
-        *reinterpret_cast<__bf16*>(vr) = vh;
-        *reinterpret_cast<__bf16*>(vr + KB * 2) = (__bf16)(vs[i] - (float)vh);
+        *reinterpret_cast<split_t*>(vr) = vh;
+        *reinterpret_cast<split_t*>(vr + KB * 2) = (split_t)(vs[i] - (float)vh);
       }
     }
   };
@@ -609,9 +609,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
       for (int j = 0; j < KS; ++j) {
         const bf16x8 kh = *reinterpret_cast<const bf16x8*>(kp + 32 * j);
         const bf16x8 kl = *reinterpret_cast<const bf16x8*>(kp + 32 * j + KP * 2);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl, qh[j], sacc[kt], 0, 0, 0);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, ql[j], sacc[kt], 0, 0, 0);
-        sacc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh, qh[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = RGM_MFMA_SPLIT_32x32x16(kl, qh[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = RGM_MFMA_SPLIT_32x32x16(kh, ql[j], sacc[kt], 0, 0, 0);
+        sacc[kt] = RGM_MFMA_SPLIT_32x32x16(kh, qh[j], sacc[kt], 0, 0, 0);
       }
     }
     if (b < 4) { ATTN_STAMP(4 + 3 * b) }
@@ -664,9 +664,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
         for (int dt = 0; dt < DT; ++dt) {
           const bf16x8 vh = *reinterpret_cast<const bf16x8*>(Vt + vrow[dt] + koff);
           const bf16x8 vl = *reinterpret_cast<const bf16x8*>(Vt + vrow[dt] + koff + KB * 2);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl, ph, oacc[dt], 0, 0, 0);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, pl, oacc[dt], 0, 0, 0);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh, ph, oacc[dt], 0, 0, 0);
+          oacc[dt] = RGM_MFMA_SPLIT_32x32x16(vl, ph, oacc[dt], 0, 0, 0);
+          oacc[dt] = RGM_MFMA_SPLIT_32x32x16(vh, pl, oacc[dt], 0, 0, 0);
+          oacc[dt] = RGM_MFMA_SPLIT_32x32x16(vh, ph, oacc[dt], 0, 0, 0);
         }
       }
     }
@@ -696,10 +696,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
           const float4 ov = make_float4(oacc[dt][4 * g] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
           if (out_split) {
             bf16x4 hi, lo;
-            hi[0] = (__bf16)ov.x; hi[1] = (__bf16)ov.y; hi[2] = (__bf16)ov.z; hi[3] = (__bf16)ov.w;
-            lo[0] = (__bf16)(ov.x - (float)hi[0]); lo[1] = (__bf16)(ov.y - (float)hi[1]);
-            lo[2] = (__bf16)(ov.z - (float)hi[2]); lo[3] = (__bf16)(ov.w - (float)hi[3]);
-            __bf16* rp = reinterpret_cast<__bf16*>(o + ((long long)n * T + q) * D);
+            hi[0] = (split_t)ov.x; hi[1] = (split_t)ov.y; hi[2] = (split_t)ov.z; hi[3] = (split_t)ov.w;
+            lo[0] = (split_t)(ov.x - (float)hi[0]); lo[1] = (split_t)(ov.y - (float)hi[1]);
+            lo[2] = (split_t)(ov.z - (float)hi[2]); lo[3] = (split_t)(ov.w - (float)hi[3]);
+            split_t* rp = reinterpret_cast<split_t*>(o + ((long long)n * T + q) * D);
             const int si = split_idx(head * HD + d);
             *reinterpret_cast<bf16x4*>(rp + si) = hi;
             *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;

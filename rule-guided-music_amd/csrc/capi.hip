@@ -51,3 +51,12 @@ extern "C" int rgm_rotary_attention(const float* qkv, float* o, const float* cos
   RGM_REQUIRE(qkv && o && cos_tab && sin_tab, "attention: null tensor");
   return rotary_attention_fwd(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream);
 }
+
+// 0: the x3 modes split into bf16 halves (default build), 1: into fp16 halves (-DRGM_SPLIT_F16 build: librgm_hip_f16.so)
+extern "C" int rgm_split_dtype(void) {
+#ifdef RGM_SPLIT_F16
+  return 1;
+#else
+  return 0;
+#endif
+}

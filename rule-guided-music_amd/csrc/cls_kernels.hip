@@ -97,12 +97,12 @@ int ln_mod_bwd_launch(const float* dy, const float* x, const float* res, float* 
 // write 4 consecutive values of a row either as fp32 or in the split-row format of the pre-split GEMMs (common.h split_idx)
 __device__ __forceinline__ void store4(float* __restrict__ out, long long row, int D, int c, float4 v, int out_split) {
   if (out_split) {
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
     bf16x4 hi, lo;
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-    __bf16* rp = reinterpret_cast<__bf16*>(out + row * D);
+    hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+    lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
+    lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
+    split_t* rp = reinterpret_cast<split_t*>(out + row * D);
     *reinterpret_cast<bf16x4*>(rp + split_idx(c)) = hi;
     *reinterpret_cast<bf16x4*>(rp + split_idx(c) + 32) = lo;
   } else {

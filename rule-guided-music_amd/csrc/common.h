@@ -47,6 +47,19 @@ void set_error(const char* fmt, ...);
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// Element type of the hi / lo halves of the "x3" arithmetic (x ~= hi + lo, three MFMAs per product, fp32 accumulate) -- a BUILD constant:
+//   default        __bf16   : 8 significand bits each, 2^-16 per product, fp32's exponent range (rounds 1-3; modes "bf16x3", "bf16x3_presplit")
+//   -DRGM_SPLIT_F16 _Float16 : 11 significand bits each, 2^-22 per product at the same MFMA rate (v_mfma_f32_32x32x16_f16), but fp16's
+//                              range: |x| > 65504 overflows, lo halves of |x| < 0.125 are subnormal (still <= 3e-8 absolute).  Evaluated in
+//                              round 4 as librgm_hip_f16.so (make F16=1); rgm_split_dtype() tells which build is loaded.
+#ifdef RGM_SPLIT_F16
+typedef _Float16 split_t;
+#define RGM_MFMA_SPLIT_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef __bf16 split_t;
+#define RGM_MFMA_SPLIT_32x32x16 __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+
 // "Split row" format (pre-split bf16x3 operands, gemm2.hip): a logical fp32 row of K elements keeps its K*4 bytes;
 // every block of 32 elements becomes one 128-byte line [32 bf16 hi | 32 bf16 lo] (x ~= hi + lo, round-to-nearest each).
 // Returns the bf16 index of element `col`'s hi part within the row; its lo part is 32 further.

@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
       y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
     }
     if (out_split) {   // split-row format (common.h split_idx) for the pre-split GEMM path
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 hi, lo;
-      hi[0] = (__bf16)y.x; hi[1] = (__bf16)y.y; hi[2] = (__bf16)y.z; hi[3] = (__bf16)y.w;
-      lo[0] = (__bf16)(y.x - (float)hi[0]); lo[1] = (__bf16)(y.y - (float)hi[1]);
-      lo[2] = (__bf16)(y.z - (float)hi[2]); lo[3] = (__bf16)(y.w - (float)hi[3]);
-      __bf16* rp = reinterpret_cast<__bf16*>(out + (long long)row * D);
+      hi[0] = (split_t)y.x; hi[1] = (split_t)y.y; hi[2] = (split_t)y.z; hi[3] = (split_t)y.w;
+      lo[0] = (split_t)(y.x - (float)hi[0]); lo[1] = (split_t)(y.y - (float)hi[1]);
+      lo[2] = (split_t)(y.z - (float)hi[2]); lo[3] = (split_t)(y.w - (float)hi[3]);
+      split_t* rp = reinterpret_cast<split_t*>(out + (long long)row * D);
       const int si = split_idx(c * 4);
       *reinterpret_cast<bf16x4*>(rp + si) = hi;
       *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;

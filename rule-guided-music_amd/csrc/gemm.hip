@@ -29,8 +29,8 @@
 
 namespace rgm {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef split_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
 
 // fp32 -> (hi, lo) bf16 pair with x ~= hi + lo to ~2^-17 relative (both round-to-nearest-even, v_cvt_pk_bf16_f32)
 __device__ __forceinline__ void split_bf16(const float4& v, bf16x4& hi, bf16x4& lo) {
@@ -41,11 +41,11 @@ __device__ __forceinline__ void split_bf16(const float4& v, bf16x4& hi, bf16x4& 
   lo = hi;
   return;
 #endif
-  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-  lo[0] = (__bf16)(v.x - (float)hi[0]);
-  lo[1] = (__bf16)(v.y - (float)hi[1]);
-  lo[2] = (__bf16)(v.z - (float)hi[2]);
-  lo[3] = (__bf16)(v.w - (float)hi[3]);
+  hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+  lo[0] = (split_t)(v.x - (float)hi[0]);
+  lo[1] = (split_t)(v.y - (float)hi[1]);
+  lo[2] = (split_t)(v.z - (float)hi[2]);
+  lo[3] = (split_t)(v.w - (float)hi[3]);
 }
 
 // PREC 0: exact fp32 products on v_mfma_f32_32x32x2_f32 (157 TF peak).
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
         for (int im = 0; im < TM; ++im)
 #pragma unroll
           for (int in = 0; in < TN; ++in) {
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[im], bh[in], acc[im][in], 0, 0, 0);
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bl[in], acc[im][in], 0, 0, 0);
-            acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bh[in], acc[im][in], 0, 0, 0);
+            acc[im][in] = RGM_MFMA_SPLIT_32x32x16(al[im], bh[in], acc[im][in], 0, 0, 0);
+            acc[im][in] = RGM_MFMA_SPLIT_32x32x16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+            acc[im][in] = RGM_MFMA_SPLIT_32x32x16(ah[im], bh[in], acc[im][in], 0, 0, 0);
           }
       }
     }
@@ -289,10 +289,10 @@ __global__ __launch_bounds__(WM* WN * 64) void gemm_kernel(GemmParams p, int til
         if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
         if (resb) v += resb[(long long)row * p.ldres + col];
         if (p.out_split) {   // split-row output (common.h split_idx) feeding a pre-split consumer (gemm2.hip)
-          __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-          const __bf16 hi = (__bf16)v;
+          split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
+          const split_t hi = (split_t)v;
           rowp[split_idx(col)] = hi;
-          rowp[split_idx(col) + 32] = (__bf16)(v - (float)hi);
+          rowp[split_idx(col) + 32] = (split_t)(v - (float)hi);
         } else {
           Cb[(long long)row * p.ldc + col] = v;
         }

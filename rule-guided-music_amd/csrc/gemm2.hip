@@ -26,7 +26,7 @@
 
 namespace rgm {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef split_t bf16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
   // 16 B per lane, LDS destination = wave-uniform base + lane*16
@@ -289,7 +289,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       static_for<0, NM>([&](auto mc) {
         constexpr int m = decltype(mc)::value;
         constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
-        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.a[st][im][t == 0 ? 1 : 0], f.b[st][in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
+        acc[im][in] = RGM_MFMA_SPLIT_32x32x16(f.a[st][im][t == 0 ? 1 : 0], f.b[st][in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
         if constexpr (st == 1) {
           if (prefetch) {
             static_for<0, RPM>([&](auto rc) {
@@ -406,7 +406,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         constexpr int m = decltype(mc)::value;
         constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
-        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
+        acc[im][in] = RGM_MFMA_SPLIT_32x32x16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
         if constexpr (READ && m % EV == 0 && m / EV < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / EV>{});
         if constexpr (AIM && m % EV == 1 && m / EV < APIECES) aim_piece(std::integral_constant<int, m / EV>{}, aim);
         if constexpr (DMA && m % EV == 1 && m / EV < SPW) {
@@ -551,7 +551,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         constexpr int m = decltype(mc)::value;
         constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
-        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? f.al[st][im] : f.ah[st][im], t == 1 ? f.bl[st][in] : f.bh[st][in],
+        acc[im][in] = RGM_MFMA_SPLIT_32x32x16(t == 0 ? f.al[st][im] : f.ah[st][im], t == 1 ? f.bl[st][in] : f.bh[st][in],
                                                               acc[im][in], 0, 0, 0);
         if constexpr ((m % EVERY) == EVERY - 1 && (m / EVERY) < PN) {
           constexpr int i = PB + m / EVERY;
@@ -673,7 +673,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         constexpr int m = decltype(mc)::value;
         constexpr int st = m / NM, t = (m % NM) / (TM * TN), im = ((m % NM) % (TM * TN)) / TN, in = (m % NM) % TN;
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
-        acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t == 0 ? al[st][im] : ah[st][im], t == 1 ? bl[st][in] : bh[st][in],
+        acc[im][in] = RGM_MFMA_SPLIT_32x32x16(t == 0 ? al[st][im] : ah[st][im], t == 1 ? bl[st][in] : bh[st][in],
                                                               acc[im][in], 0, 0, 0);
         if constexpr ((m & 1) == 1 && (m >> 1) < SPW) {
           constexpr int i = m >> 1;
@@ -752,9 +752,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       for (int im = 0; im < TM; ++im)
 #pragma unroll
         for (int in = 0; in < TN; ++in) {
-          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[im], bh[in], acc[im][in], 0, 0, 0);
-          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bl[in], acc[im][in], 0, 0, 0);
-          acc[im][in] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[im], bh[in], acc[im][in], 0, 0, 0);
+          acc[im][in] = RGM_MFMA_SPLIT_32x32x16(al[im], bh[in], acc[im][in], 0, 0, 0);
+          acc[im][in] = RGM_MFMA_SPLIT_32x32x16(ah[im], bl[in], acc[im][in], 0, 0, 0);
+          acc[im][in] = RGM_MFMA_SPLIT_32x32x16(ah[im], bh[in], acc[im][in], 0, 0, 0);
         }
       if (DBG) {
         if (st == 0) { RGM_STAMP(4) } else { RGM_STAMP(6) }
@@ -806,7 +806,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // Output stores.  The one-wave-per-SIMD kernels (PIPE 5) finish a whole round of 256 KB tiles at the same moment and their
     // epilogue runs at the chip's write rate: non-temporal stores (the 57-76 MB of a qkv / fc1 output pass through the 32 MB of L2
     // anyway) take 1.7-4.4 % off those launches (tools/which_kernel.py, same box: 86.9 -> 85.4 us at 224 tiles, 98.3 -> 94.0 at 256).
-    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    typedef split_t bf16x4_t __attribute__((ext_vector_type(4)));
     auto out16 = [&](float* dst, const float (&v)[4]) {
       if constexpr (PIPE == 5) {
         const f32x4 nv = {v[0], v[1], v[2], v[3]};
@@ -815,20 +815,20 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
     };
-    auto out8 = [&](__bf16* dst, const bf16x4_t& v) {
+    auto out8 = [&](split_t* dst, const bf16x4_t& v) {
       if constexpr (PIPE == 5) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4_t*>(dst));
       else *reinterpret_cast<bf16x4_t*>(dst) = v;
     };
     auto store_row = [&](int row, const float (&v)[4]) {
       if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
         bf16x4 hi, lo;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
-          hi[q4] = (__bf16)v[q4];
-          lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+          hi[q4] = (split_t)v[q4];
+          lo[q4] = (split_t)(v[q4] - (float)hi[q4]);
         }
-        __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+        split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
         out8(rowp + split_idx(col), hi);
         out8(rowp + split_idx(col) + 32, lo);
       } else if (exp != 4) {
@@ -872,14 +872,14 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) v[q4] = ACT == 1 ? silu_f(v[q4]) : (ACT == 2 ? gelu_tanh_fast_f(v[q4]) : v[q4]);
                 if constexpr (SPLIT) {
-                  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                  typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
                   bf16x4 hi, lo;
 #pragma unroll
                   for (int q4 = 0; q4 < 4; ++q4) {
-                    hi[q4] = (__bf16)v[q4];
-                    lo[q4] = (__bf16)(v[q4] - (float)hi[q4]);
+                    hi[q4] = (split_t)v[q4];
+                    lo[q4] = (split_t)(v[q4] - (float)hi[q4]);
                   }
-                  __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
+                  split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
                   out8(rowp + split_idx(col), hi);
                   out8(rowp + split_idx(col) + 32, lo);
                 } else {
@@ -1175,10 +1175,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
             if (p.gate) v *= p.gate[(long long)(row / p.rows_per_gate) * p.gate_ld + col];
             if (resb) v += resb[(long long)row * p.ldres + col];
             if (p.out_split) {   // split-row output (common.h split_idx)
-              __bf16* rowp = reinterpret_cast<__bf16*>(Cb + (long long)row * p.ldc);
-              const __bf16 hi = (__bf16)v;
+              split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
+              const split_t hi = (split_t)v;
               rowp[split_idx(col)] = hi;
-              rowp[split_idx(col) + 32] = (__bf16)(v - (float)hi);
+              rowp[split_idx(col) + 32] = (split_t)(v - (float)hi);
             } else {
               if (exp != 4) Cb[(long long)row * p.ldc + col] = v;
               else if (v == 123.456f) Cb[0] = v;   // timing experiment: keep the math, drop the stores
@@ -1406,14 +1406,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, GemmParams p, 
     v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
   }
   if (p.out_split) {
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
     bf16x4 hi, lo;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      hi[q] = (__bf16)v[q];
-      lo[q] = (__bf16)(v[q] - (float)hi[q]);
+      hi[q] = (split_t)v[q];
+      lo[q] = (split_t)(v[q] - (float)hi[q]);
     }
-    __bf16* rowp = reinterpret_cast<__bf16*>(p.C + (long long)row * p.ldc);
+    split_t* rowp = reinterpret_cast<split_t*>(p.C + (long long)row * p.ldc);
     *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
     *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
   } else {
@@ -1512,12 +1512,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_ln_kernel(const float* __re
     const float4 sc = reinterpret_cast<const float4*>(p.ln_scale + mo)[c], sh = reinterpret_cast<const float4*>(p.ln_shift + mo)[c];
     y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
     if (p.ln_out_split) {
-      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
       bf16x4 hi, lo;
-      hi[0] = (__bf16)y.x; hi[1] = (__bf16)y.y; hi[2] = (__bf16)y.z; hi[3] = (__bf16)y.w;
-      lo[0] = (__bf16)(y.x - (float)hi[0]); lo[1] = (__bf16)(y.y - (float)hi[1]);
-      lo[2] = (__bf16)(y.z - (float)hi[2]); lo[3] = (__bf16)(y.w - (float)hi[3]);
-      __bf16* rp = reinterpret_cast<__bf16*>(p.ln_out + (long long)row * p.N);
+      hi[0] = (split_t)y.x; hi[1] = (split_t)y.y; hi[2] = (split_t)y.z; hi[3] = (split_t)y.w;
+      lo[0] = (split_t)(y.x - (float)hi[0]); lo[1] = (split_t)(y.y - (float)hi[1]);
+      lo[2] = (split_t)(y.z - (float)hi[2]); lo[3] = (split_t)(y.w - (float)hi[3]);
+      split_t* rp = reinterpret_cast<split_t*>(p.ln_out + (long long)row * p.N);
       const int si = split_idx(c * 4);
       *reinterpret_cast<bf16x4*>(rp + si) = hi;
       *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
@@ -1757,12 +1757,12 @@ __global__ void split_rows_kernel(const float* __restrict__ x, float* __restrict
   const long long row = i / kq;
   const int c = (int)(i - row * kq) * 4;
   const float4 v = *reinterpret_cast<const float4*>(x + row * ld_in + c);
-  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
   bf16x4 hi, lo;
-  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-  lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-  lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-  __bf16* rowp = reinterpret_cast<__bf16*>(out + row * ld_out);
+  hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+  lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
+  lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
+  split_t* rowp = reinterpret_cast<split_t*>(out + row * ld_out);
   *reinterpret_cast<bf16x4*>(rowp + split_idx(c)) = hi;
   *reinterpret_cast<bf16x4*>(rowp + split_idx(c) + 32) = lo;
 }

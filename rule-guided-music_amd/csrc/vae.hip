@@ -176,12 +176,12 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
   const float4 v = reinterpret_cast<const float4*>(x)[i];
   const float4 ga = reinterpret_cast<const float4*>(gamma)[c4], be = reinterpret_cast<const float4*>(beta)[c4];
   if (raw_split) {   // the input itself as split rows, in the same pass (the 1x1 shortcut of a channel-changing ResnetBlock reads it)
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
     bf16x4 hi, lo;
-    hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-    lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-    lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-    __bf16* px = reinterpret_cast<__bf16*>(raw_split + (i / q) * C);
+    hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+    lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
+    lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
+    split_t* px = reinterpret_cast<split_t*>(raw_split + (i / q) * C);
     *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4)) = hi;
     *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4) + 32) = lo;
   }
@@ -194,12 +194,12 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
     o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
   }
   if (out_split) {   // split-row pixels (common.h split_idx) for the pre-split conv GEMM
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
     bf16x4 hi, lo;
-    hi[0] = (__bf16)o.x; hi[1] = (__bf16)o.y; hi[2] = (__bf16)o.z; hi[3] = (__bf16)o.w;
-    lo[0] = (__bf16)(o.x - (float)hi[0]); lo[1] = (__bf16)(o.y - (float)hi[1]);
-    lo[2] = (__bf16)(o.z - (float)hi[2]); lo[3] = (__bf16)(o.w - (float)hi[3]);
-    __bf16* px = reinterpret_cast<__bf16*>(y + (i / q) * C);
+    hi[0] = (split_t)o.x; hi[1] = (split_t)o.y; hi[2] = (split_t)o.z; hi[3] = (split_t)o.w;
+    lo[0] = (split_t)(o.x - (float)hi[0]); lo[1] = (split_t)(o.y - (float)hi[1]);
+    lo[2] = (split_t)(o.z - (float)hi[2]); lo[3] = (split_t)(o.w - (float)hi[3]);
+    split_t* px = reinterpret_cast<split_t*>(y + (i / q) * C);
     *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4)) = hi;
     *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4) + 32) = lo;
   } else {
@@ -425,14 +425,14 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, const float* dz
     o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w;
   }
   if (out_split) {   // split-row pixels for the pre-split input-gradient conv (out must not alias dz then)
-    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
     bf16x4 hi, lo;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      hi[k] = (__bf16)o[k];
-      lo[k] = (__bf16)(o[k] - (float)hi[k]);
+      hi[k] = (split_t)o[k];
+      lo[k] = (split_t)(o[k] - (float)hi[k]);
     }
-    __bf16* px = reinterpret_cast<__bf16*>(out + (i / q) * C);
+    split_t* px = reinterpret_cast<split_t*>(out + (i / q) * C);
     *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4)) = hi;
     *reinterpret_cast<bf16x4*>(px + split_idx(c4 * 4) + 32) = lo;
   } else {

@@ -80,6 +80,7 @@ def _load():
         "rgm_set_big_tiles": (C.c_int, [i32, i32]),
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
+        "rgm_split_dtype": (C.c_int, []),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),
         "rgm_gemm_split_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_gemm_split_epi": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, i32, i32, vp, sz, vp]),

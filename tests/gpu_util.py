@@ -85,3 +85,9 @@ def fake_chord_backend(pr, given_key=None, return_key=False, fs=100., window_siz
     if return_key:
         out.update(key=int(pr.sum()) % 24, correlationCoefficient=float(pr.mean()))
     return out
+
+
+def split_torch_dtype():
+    """torch dtype of the hi / lo halves of a split row: bfloat16 in the default build, float16 in the RGM_SPLIT_F16 build"""
+    from rgm import native as R
+    return torch.float16 if int(R.lib.rgm_split_dtype()) == 1 else torch.bfloat16

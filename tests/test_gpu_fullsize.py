@@ -104,7 +104,7 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
         R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(_split(W)), K, R.ptr(h), 2304, M, 2304, K, R.ptr(dev(b2)), 2, 1.0, None, 0, 1,
                                          None, 0, tile, 1, R.ptr(ws), need, st))
         torch.cuda.synchronize()
-        raw = h.view(torch.bfloat16).view(M, 2304 // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+        raw = h.view(__import__("gpu_util").split_torch_dtype()).view(M, 2304 // 32, 2, 32).float().cpu().numpy().astype(np.float64)
         assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, 2304), _ref(A, W, b2, 2, 1.0, None, 1, None)) < 3e-5
 
 
@@ -143,7 +143,7 @@ def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
     R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(h), N, M, N, K, R.ptr(bd), 2, 1.0, None, 0, 1, None, 0, 0, 1,
                                      R.ptr(ws), need, st))
     torch.cuda.synchronize()
-    raw = h.view(torch.bfloat16).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+    raw = h.view(__import__("gpu_util").split_torch_dtype()).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
     assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, N), _ref(A, B, bias, 2, 1.0, None, 1, None)) < 3e-5
 
 
@@ -169,7 +169,7 @@ def test_big_tile_epilogue_with_gate_rows_that_cut_through_slabs(tile, rpg, gate
     torch.cuda.synchronize()
     ref = _ref(A, B, bias, 0, 0.7, gate, rpg, res)
     if split_out:
-        raw = x.view(torch.bfloat16).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+        raw = x.view(__import__("gpu_util").split_torch_dtype()).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
         got = (raw[:, :, 0] + raw[:, :, 1]).reshape(M, N)
     else:
         got = x.cpu().numpy()

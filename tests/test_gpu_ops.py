@@ -135,7 +135,7 @@ def _split(x):
 def _unsplit(t):
     """split-row device tensor (R,K) -> numpy float64 hi+lo; a row is K/32 lines of [32 bf16 hi | 32 bf16 lo] (common.h)"""
     R_, K = t.shape
-    raw = t.contiguous().view(torch.bfloat16).view(R_, K // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+    raw = t.contiguous().view(__import__("gpu_util").split_torch_dtype()).view(R_, K // 32, 2, 32).float().cpu().numpy().astype(np.float64)
     return (raw[:, :, 0, :] + raw[:, :, 1, :]).reshape(R_, K)
 
 
