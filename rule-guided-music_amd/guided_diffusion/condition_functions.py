@@ -192,10 +192,41 @@ def composite_nn_zt_value_and_grad(x, t, y=None, rule=None, fns=None, classifier
     return lp, grad
 
 
+_SIDE_STREAMS = {}     # device -> side streams for classifiers 1.. of a composite cond_fn (composite_nn_zt)
+CONCURRENT_CLASSIFIERS = __import__("os").environ.get("RGM_CLS_STREAMS", "1") != "0"
+
+
 def composite_nn_zt(x, t, y=None, rule=None, fns=None, classifier_scales=None, classifiers=None, rule_names=None):
-    out = 0
-    for fn, scale, cls, name in zip(fns, classifier_scales, classifiers, rule_names):
-        out = out + function_map[fn](x, t, y=y, rule=rule[name], classifier_scale=scale, classifier=cls)
+    """sum of the classifiers' guidance gradients (reference condition_functions.py:161-167).  The classifiers are independent chains
+    of small launches (DiTRotary-S/8-cls at the sampler's batch: a few dozen workgroups per kernel on a 256-CU chip), each with its own
+    native handle and workspace: classifier i > 0 runs on a side stream forked from and joined to the caller's stream, so the chains
+    interleave on the device; the sum is formed on the caller's stream in the reference's order (RGM_CLS_STREAMS=0: one after the other)."""
+    items = list(zip(fns, classifier_scales, classifiers, rule_names))
+    if not (CONCURRENT_CLASSIFIERS and len(items) > 1 and th.is_tensor(x) and x.is_cuda):
+        out = 0
+        for fn, scale, cls, name in items:
+            out = out + function_map[fn](x, t, y=y, rule=rule[name], classifier_scale=scale, classifier=cls)
+        return out
+    main = th.cuda.current_stream(x.device)
+    pool = _SIDE_STREAMS.setdefault(x.device, [])
+    while len(pool) < len(items) - 1:
+        pool.append(th.cuda.Stream(device=x.device))
+    parts = []
+    for i, (fn, scale, cls, name) in enumerate(items):
+        if i == 0:
+            continue
+        side = pool[i - 1]
+        side.wait_stream(main)
+        with th.cuda.stream(side):
+            g = function_map[fn](x, t, y=y, rule=rule[name], classifier_scale=scale, classifier=cls)
+        parts.append((i, g, side))
+    fn, scale, cls, name = items[0]
+    out = function_map[fn](x, t, y=y, rule=rule[name], classifier_scale=scale, classifier=cls)
+    for i, g, side in parts:
+        main.wait_stream(side)
+        if th.is_tensor(g):
+            g.record_stream(main)
+        out = out + g
     return out
 
 
