@@ -90,6 +90,9 @@ int rgm_layernorm_modulate(const float* x, float* out, int M, int D, float eps, 
  * 2*rot_half channels of q,k with cos/sin tables (T, rot_half); softmax scale hd^-0.5. hd in {64,72}. */
 int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const float* sin_tab,
                          int N, int T, int heads, int hd, int rot_half, void* stream);
+/* the same forward, also writing lse (N*heads*T): log-sum-exp of the scaled scores of every query, the saved quantity of the backward */
+int rgm_rotary_attention_lse(const float* qkv, float* o, float* lse, const float* cos_tab, const float* sin_tab,
+                             int N, int T, int heads, int hd, int rot_half, void* stream);
 
 /* Arithmetic of the GEMM family (every nn.Linear / conv of the path):
  *   0  exact fp32 products on v_mfma_f32_32x32x2_f32 (default; 157 TFLOP/s peak);
@@ -303,6 +306,11 @@ int rgm_dit_enable_grad(rgm_dit* h);
 int rgm_dit_vjp(rgm_dit* h, const float* x, const int64_t* t, const int32_t* y, const float* g_eps, float* eps_out,
                 float* grad_x, int N, int H, void* ws, size_t ws_bytes, void* stream);
 /* d(qkv) of the RotaryAttention core from dO, the saved qkv, O and per-query log-sum-exp (N, heads, T); hd = 64. */
+/* Attention launches of the classifier path (DiTRotary-S/8-cls: 257 tokens = 9 tiles of 32 on 8 waves, 6 heads x the sampler's batch of
+ * (sample, head) pairs on 256 CUs; ref guided_diffusion/dit.py:803-831 + condition_functions.py:58-64): -1 (default) = per-tile workgroups
+ * (backward: one per query / key tile, partial sums through LDS in a fixed order; forward: two per (sample, head)) whenever the
+ * (sample, head) grid would leave CUs idle, 0 = never, 1 = always.  Same values to the last bit of the summation order. */
+int rgm_set_attn_split(int mode);
 int rgm_rotary_attention_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                              const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
                              int rot_half, void* stream);

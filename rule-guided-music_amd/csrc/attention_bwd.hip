@@ -36,7 +36,11 @@ __device__ __forceinline__ float4 rotate4(float4 v, const float* __restrict__ ct
 }
 
 // ------------------------------------------------------------------------------------------- dQ
-template <int HD, int NKT>
+// SPLIT: one workgroup per (sample, head, QUERY TILE) instead of per (sample, head): its eight waves share the tile's key loop (wave w takes
+// key tiles w, w + 8, ...), the partial dQ tiles meet in LDS (over the K / V images, behind a barrier) and are summed in wave order.  For
+// the grids that leave the chip empty -- the classifiers at the samplers' batches: 6 heads x B samples of 257 tokens = 9 query tiles on 8
+// waves, i.e. two tile-times on 24 .. 192 of 256 CUs -- this turns 2 x 9 serial key tiles into 2 and fills the CUs (launch_bwd).
+template <int HD, int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, const float* __restrict__ cos_tab,
@@ -46,7 +50,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Ks = smem;              // [TP][HDP] rotated keys
   float* Vs = smem + TP * HDP;   // [TP][HDP]
-  const int n = blockIdx.x / heads, head = blockIdx.x - n * heads;
+  const int nqt_all = (T + 31) >> 5;
+  const int bh = SPLIT ? blockIdx.x / nqt_all : blockIdx.x;
+  const int n = bh / heads, head = bh - n * heads;
   const int D = heads * HD, D3 = 3 * D, R = 2 * rot_half;
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
@@ -67,7 +73,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const float scale = rsqrtf((float)HD);
   const int nqt = (T + 31) >> 5, ktr = T >> 5, tr = T & 31;
-  for (int qt = wave; qt < nqt; qt += 8) {
+  const int qt0 = SPLIT ? blockIdx.x - bh * nqt_all : wave;
+  for (int qt = qt0; qt < nqt; qt += SPLIT ? nqt : 8) {
     const int q = qt * 32 + l31, qc = min(q, T - 1);
     const long long orow = ((long long)n * T + qc) * D + head * HD;
     f32x4 qf[KB], dof[KB];
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) dq[dt][e] = 0.f;
 #pragma unroll 1
-    for (int kt = 0; kt < NKT; ++kt) {
+    for (int kt = SPLIT ? wave : 0; kt < NKT; kt += SPLIT ? 8 : 1) {
       if (kt * 32 >= T) break;
       f32x16 s, dp;
 #pragma unroll
@@ -126,6 +133,31 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
         if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (SPLIT) {   // partial dQ of this wave's key tiles -> LDS [wave][query][HDP] over the K image; fixed-order sum; scale, un-rotate, store
+      __syncthreads();       // every wave is done with K / V
+      float* part = smem + (size_t)wave * 32 * HDP;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * hh;
+          if (d < HD) *reinterpret_cast<float4*>(part + l31 * HDP + d) = make_float4(dq[dt][4 * g], dq[dt][4 * g + 1], dq[dt][4 * g + 2], dq[dt][4 * g + 3]);
+        }
+      __syncthreads();
+      for (int e = tid; e < 32 * (HD / 4); e += 512) {
+        const int qi = e / (HD / 4), d = (e - qi * (HD / 4)) * 4, qq = qt * 32 + qi;
+        if (qq >= T) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          const float4 b = *reinterpret_cast<const float4*>(smem + (size_t)w * 32 * HDP + qi * HDP + d);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        float4 v = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
+        if (d < R) v = rotate4(v, cos_tab, sin_tab, qq * rot_half + (d >> 1), true);
+        *reinterpret_cast<float4*>(dqkv + ((long long)n * T + qq) * D3 + head * HD + d) = v;
+      }
+    } else
     if (q < T) {   // dQ^T[d][query]: lane = query row, registers 4g..4g+3 = channels dt*32 + 8g + 4hh ..+3
       float* op = dqkv + ((long long)n * T + q) * D3 + head * HD;
 #pragma unroll
@@ -143,7 +175,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------- dK, dV
-template <int HD, int NKT>
+// SPLIT: one workgroup per (sample, head, KEY TILE); wave w takes query tiles w, w + 8, ...; partial dK / dV tiles summed through LDS
+template <int HD, int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, const float* __restrict__ cos_tab,
@@ -155,7 +188,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
   float* Gs = smem + TP * HDP;        // [TP][HDP] dO
   float* Ls = smem + 2 * TP * HDP;    // [TP] lse
   float* Ds = Ls + TP;                // [TP] D = rowsum(dO * O)
-  const int n = blockIdx.x / heads, head = blockIdx.x - n * heads;
+  const int nkt_all = (T + 31) >> 5;
+  const int bh = SPLIT ? blockIdx.x / nkt_all : blockIdx.x;
+  const int n = bh / heads, head = bh - n * heads;
   const int D = heads * HD, D3 = 3 * D, R = 2 * rot_half;
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
@@ -190,7 +225,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int nkt = (T + 31) >> 5, qtr = T >> 5, tr = T & 31;
-  for (int kt = wave; kt < nkt; kt += 8) {
+  const int kt0 = SPLIT ? blockIdx.x - bh * nkt_all : wave;
+  for (int kt = kt0; kt < nkt; kt += SPLIT ? nkt : 8) {
     const int key = kt * 32 + l31, kc = min(key, T - 1);
     f32x4 kf[KB], vf[KB];
     {
@@ -212,7 +248,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
 #pragma unroll 1
-    for (int qt = 0; qt < NKT; ++qt) {
+    for (int qt = SPLIT ? wave : 0; qt < NKT; qt += SPLIT ? 8 : 1) {
       if (qt * 32 >= T) break;
       f32x16 s, dp;
 #pragma unroll
@@ -251,6 +287,34 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if constexpr (SPLIT) {   // partial dK / dV -> LDS [wave][dK | dV][key][HDP] over the Q / dO images (launch_bwd sizes the request for it)
+      __syncthreads();
+      float* part = smem + (size_t)wave * 2 * 32 * HDP;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = dt * 32 + 8 * g + 4 * hh;
+          if (d < HD) {
+            *reinterpret_cast<float4*>(part + l31 * HDP + d) = make_float4(dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
+            *reinterpret_cast<float4*>(part + 32 * HDP + l31 * HDP + d) = make_float4(dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+          }
+        }
+      __syncthreads();
+      for (int e = tid; e < 2 * 32 * (HD / 4); e += 512) {
+        const int which = e / (32 * (HD / 4)), r = e - which * 32 * (HD / 4);
+        const int ki = r / (HD / 4), d = (r - ki * (HD / 4)) * 4, kk = kt * 32 + ki;
+        if (kk >= T) continue;
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          const float4 b = *reinterpret_cast<const float4*>(smem + (size_t)w * 2 * 32 * HDP + which * 32 * HDP + ki * HDP + d);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        if (which == 0 && d < R) a = rotate4(a, cos_tab, sin_tab, kk * rot_half + (d >> 1), true);
+        *reinterpret_cast<float4*>(dqkv + ((long long)n * T + kk) * D3 + head * HD + (which == 0 ? D : 2 * D) + d) = a;
+      }
+    } else
     if (key_ok) {
       float* op = dqkv + ((long long)n * T + key) * D3 + head * HD;
 #pragma unroll
@@ -268,15 +332,41 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
   }
 }
 
+static int g_attn_split = -1;   // rgm_set_attn_split: -1 auto, 0 never, 1 always
+
 template <int HD, int NKT>
 static int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const float* ct,
                       const float* st, int N, int T, int heads, int rot_half, hipStream_t s) {
   constexpr int TP = NKT * 32, HDP = HD + 4;
   // one workgroup per CU (common.h attn_prepare_kernel): the same single-pass structure as the forward kernels
-  const size_t lds_q = attn_lds_one_per_cu((size_t)2 * TP * HDP * sizeof(float));
-  const size_t lds_kv = attn_lds_one_per_cu((size_t)2 * TP * HDP * sizeof(float) + (size_t)2 * TP * sizeof(float));
-  auto kq = attn_bwd_dq_kernel<HD, NKT>;
-  auto kkv = attn_bwd_dkv_kernel<HD, NKT>;
+  const size_t images = (size_t)2 * TP * HDP * sizeof(float);
+  const int nt = (T + 31) / 32;
+  // per-tile workgroups when (sample, head) workgroups leave most CUs idle: the classifiers at C4's batch (24 pairs) or on one row of a
+  // sharded step (6).  Every per-tile workgroup stages the head's K / V (Q / dO) again, which costs more than it buys from ~120 pairs on
+  // (tools/cls_time.py, value-and-gradient of DiTRotary-S/8-cls: B = 1 4.58 -> 2.34 ms, B = 4 4.89 -> 2.61, B = 16 6.09 -> 5.69,
+  // B = 24 7.17 -> 8.09, B = 32 7.99 -> 9.65)
+  const bool split = g_attn_split < 0 ? (long long)N * heads <= ATTN_SPLIT_MAX_PAIRS && nt > 1 : g_attn_split == 1;
+  if (split) {
+    const size_t lds_q = attn_lds_one_per_cu(images > (size_t)8 * 32 * HDP * 4 ? images : (size_t)8 * 32 * HDP * 4);
+    const size_t lds_kv = attn_lds_one_per_cu((images > (size_t)16 * 32 * HDP * 4 ? images : (size_t)16 * 32 * HDP * 4) + (size_t)2 * TP * sizeof(float));
+    auto kq = attn_bwd_dq_kernel<HD, NKT, true>;
+    auto kkv = attn_bwd_dkv_kernel<HD, NKT, true>;
+    static bool prepared = false;
+    if (!prepared) {
+      RGM_TRY(attn_prepare_kernel(kq, 512, lds_q, "attn_bwd_dq_kernel (per query tile)"));
+      RGM_TRY(attn_prepare_kernel(kkv, 512, lds_kv, "attn_bwd_dkv_kernel (per key tile)"));
+      prepared = true;
+    }
+    hipLaunchKernelGGL(kq, dim3(N * heads * nt), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
+    RGM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kkv, dim3(N * heads * nt), dim3(512), lds_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
+    RGM_LAUNCH_CHECK();
+    return RGM_OK;
+  }
+  const size_t lds_q = attn_lds_one_per_cu(images);
+  const size_t lds_kv = attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float));
+  auto kq = attn_bwd_dq_kernel<HD, NKT, false>;
+  auto kkv = attn_bwd_dkv_kernel<HD, NKT, false>;
   static bool prepared = false;
   if (!prepared) {
     RGM_TRY(attn_prepare_kernel(kq, 512, lds_q, "attn_bwd_dq_kernel"));
@@ -307,7 +397,18 @@ int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d
   return launch_bwd<64, 9>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
 }
 
+int attn_split_mode() { return g_attn_split; }
+void attn_set_split(int mode) { g_attn_split = mode; }
+
 }  // namespace rgm
+
+// Attention kernels of the classifier path (T = 257: 9 tiles on 8 waves; a few dozen (sample, head) pairs on 256 CUs): -1 (default) = one
+// workgroup per (sample, head, tile) whenever (sample, head) workgroups would not fill the chip, 0 = never, 1 = always (A/B runs, tests)
+extern "C" int rgm_set_attn_split(int mode) {
+  RGM_REQUIRE(mode >= -1 && mode <= 1, "set_attn_split: %d (-1 auto, 0 never, 1 always)", mode);
+  rgm::attn_set_split(mode);
+  return RGM_OK;
+}
 
 extern "C" int rgm_rotary_attention_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                         const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,

@@ -60,7 +60,7 @@ template <int HD, int NKT>
 __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                   const float* __restrict__ cos_tab,
                                                                   const float* __restrict__ sin_tab, int T, int heads, int rot_half,
-                                                                  float* __restrict__ lse, int out_split) {
+                                                                  float* __restrict__ lse, int out_split, int qgroups) {
   constexpr int KP = (HD + 15) / 16 * 16;   // padded contraction length of QK^T
   constexpr int KS = KP / 16;               // k16 steps of QK^T
   constexpr int DT = (HD + 31) / 32;        // 32-wide output-channel tiles
@@ -72,7 +72,10 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   char* Ks = smem3;                         // [TP][KROW]
   char* Vt = smem3 + TP * KROW;             // [HD][VROW]
 
-  const int n = blockIdx.x / heads, head = blockIdx.x - n * heads;
+  // qgroups > 1: the query tiles of a (sample, head) are shared out over that many workgroups (each stages K and V itself) -- the
+  // classifiers' 257 tokens are 9 tiles on 8 waves, two tile-times in one workgroup, and their (sample, head) grids leave CUs idle
+  const int bh = blockIdx.x / qgroups, qgrp = blockIdx.x - bh * qgroups;
+  const int n = bh / heads, head = bh - n * heads;
   const int D = heads * HD, D3 = 3 * D;
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   const float scale = rsqrtf((float)HD) * 1.44269504088896340736f;
   const int nqt = (T + 31) >> 5;
 
-  for (int qt = wave; qt < nqt; qt += nwaves) {
+  const int per_grp = (nqt + qgroups - 1) / qgroups, qt_end = min(nqt, (qgrp + 1) * per_grp);
+  for (int qt = qgrp * per_grp + wave; qt < qt_end; qt += nwaves) {
     const int q = qt * 32 + l31;
     const int qc = min(q, T - 1);
     // ---- Q fragments: lane (query l31, half hh) holds Q[q][16j + 8hh .. +7], rotated, pre-scaled, split
@@ -386,7 +390,11 @@ static int launch_attn_x3(const float* qkv, float* o, const float* ct, const flo
     if (!prepared) RGM_TRY(attn_prepare_kernel(kern, 512, lds, "rotary_attention_x3_kernel"));
     prepared = true;
   }
-  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split);
+  // nine query tiles on eight waves (T = 257) in a grid that does not fill the chip: two workgroups per (sample, head), one tile per wave
+  const int nqt = (T + 31) / 32;
+  const int split = attn_split_mode();
+  const int qgroups = (nqt > 8 && (split < 0 ? (long long)N * heads <= ATTN_SPLIT_MAX_PAIRS : split == 1)) ? 2 : 1;
+  hipLaunchKernelGGL(kern, dim3(N * heads * qgroups), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split, qgroups);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -52,6 +52,13 @@ extern "C" int rgm_rotary_attention(const float* qkv, float* o, const float* cos
   return rotary_attention_fwd(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream);
 }
 
+// the same forward, also writing the per-query log-sum-exp (N * heads * T) the backward needs (what the classifiers' saved-activation pass calls)
+extern "C" int rgm_rotary_attention_lse(const float* qkv, float* o, float* lse, const float* cos_tab, const float* sin_tab, int N, int T,
+                                        int heads, int hd, int rot_half, void* stream) {
+  RGM_REQUIRE(qkv && o && lse && cos_tab && sin_tab, "attention: null tensor");
+  return rotary_attention_fwd(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream, 0, lse);
+}
+
 // 0: the x3 modes split into bf16 halves (default build), 1: into fp16 halves (-DRGM_SPLIT_F16 build: librgm_hip_f16.so)
 extern "C" int rgm_split_dtype(void) {
 #ifdef RGM_SPLIT_F16

@@ -35,6 +35,7 @@ def _load():
         "rgm_gemm_tile": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
         "rgm_layernorm_modulate": (C.c_int, [vp, vp, i32, i32, f32, vp, vp, vp, vp, i32, i32, vp]),
         "rgm_rotary_attention": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
+        "rgm_rotary_attention_lse": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_randn": (C.c_int, [vp, C.c_int64, C.c_uint64, C.c_uint64, vp]),
         "rgm_ddpm_step": (C.c_int, [vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, vp]),
         "rgm_ddpm_step_learned": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, vp, vp, i32, i32, vp]),
@@ -81,6 +82,7 @@ def _load():
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
         "rgm_split_dtype": (C.c_int, []),
+        "rgm_set_attn_split": (C.c_int, [i32]),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),
         "rgm_gemm_split_ws": (C.c_int, [vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, vp, sz, vp]),
         "rgm_gemm_split_epi": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, i32, i32, vp, sz, vp]),

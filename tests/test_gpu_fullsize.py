@@ -633,6 +633,45 @@ def test_every_attention_launcher_keeps_one_workgroup_per_cu(N, T, heads, hd, ro
     assert bool(torch.isfinite(dq).all())
 
 
+@pytest.mark.parametrize("N,T,heads,hd", [(4, 257, 6, 64), (32, 257, 6, 64), (3, 256, 16, 72), (5, 128, 16, 72), (2, 161, 6, 64)])
+def test_per_tile_attention_workgroups_match_the_per_head_ones(N, T, heads, hd, precision):
+    """rgm_set_attn_split: the classifier path's attention (257 tokens = 9 tiles on 8 waves, 6 x B (sample, head) pairs on 256 CUs) runs
+    one workgroup per (sample, head, tile) in the backward -- the eight waves share the tile's key / query loop, partial dQ / dK / dV tiles
+    meet in LDS and are summed in wave order -- and two workgroups per (sample, head) in the forward.  Same products, another summation
+    order of the eight partials: forward bit-identical, backward to 1e-6 of the gradient's scale; both repeat bit for bit."""
+    from gpu_util import dev
+    from rgm import native as R
+    from rgm.synth import rotary_freqs
+    from oracle import dit_np as odit
+    rng = np.random.RandomState(N + T)
+    D = heads * hd
+    rot = hd // 2
+    qkv = dev((rng.randn(N * T, 3 * D) * 1.2).astype(F32))
+    do = dev(rng.randn(N * T, D).astype(F32))
+    cos, sin = odit.rotary_tables(rotary_freqs(rot), T)
+    cd, sd_ = dev(cos), dev(sin)
+    st = R.current_stream()
+    res = {}
+    try:
+        for mode in (0, 1, 1):
+            R.check(R.lib.rgm_set_attn_split(mode))
+            o = torch.full((N * T, D), float("nan"), device="cuda")
+            lse = torch.full((N * heads * T,), float("nan"), device="cuda")
+            R.check(R.lib.rgm_rotary_attention_lse(R.ptr(qkv), R.ptr(o), R.ptr(lse), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, rot // 2, st))
+            dq = torch.full((N * T, 3 * D), float("nan"), device="cuda")
+            R.check(R.lib.rgm_rotary_attention_bwd(R.ptr(qkv), R.ptr(o), R.ptr(do), R.ptr(lse), R.ptr(dq), R.ptr(cd), R.ptr(sd_), N, T, heads, hd,
+                                                   rot // 2, st))
+            torch.cuda.synchronize()
+            res.setdefault(mode, []).append((o, lse, dq))
+    finally:
+        R.check(R.lib.rgm_set_attn_split(-1))
+    (o0, l0, g0), (o1, l1, g1), (o2, l2, g2) = res[0][0], res[1][0], res[1][1]
+    assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(g1, g2)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    assert bool(torch.isfinite(g1).all())
+    assert float((g0 - g1).abs().max()) <= 1e-6 * float(g0.abs().max())
+
+
 def test_half_window_batches_through_the_xl_model_are_deterministic(precision):
     """The same hazard at the model level: 48 half windows (H = 64 -> 128 tokens) through XL depth 4, twelve times: identical outputs,
     equal to the batches-of-2 evaluation."""

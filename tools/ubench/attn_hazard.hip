@@ -29,6 +29,7 @@ void set_error(const char* fmt, ...) {
   fputc('\n', stderr);
 }
 int rotary_attention_launch(const float*, float*, const float*, const float*, int, int, int, int, int, hipStream_t, float*, int) { return -1; }
+int attn_split_mode() { return 0; }
 }  // namespace rgm
 extern "C" int rgm_get_gemm_precision(void) { return 1; }
 
@@ -100,7 +101,7 @@ static unsigned cu_key(const rgm::AttnDbg& d) {   // (xcc, se, sh, cu)
 
 static void launch_attn(Setup& S, int threads, size_t lds, hipStream_t st, int out_split = 0) {
   auto kern = rgm::rotary_attention_x3_kernel<HD, NKT>;
-  hipLaunchKernelGGL(kern, dim3(N * HEADS), dim3(threads), lds, st, S.qkv, S.out, S.cosd, S.sind, T, HEADS, ROT_HALF, (float*)nullptr, out_split);
+  hipLaunchKernelGGL(kern, dim3(N * HEADS), dim3(threads), lds, st, S.qkv, S.out, S.cosd, S.sind, T, HEADS, ROT_HALF, (float*)nullptr, out_split, 1);
   CK(hipGetLastError());
 }
 
