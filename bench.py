@@ -636,6 +636,7 @@ def main():
         scg_shard.gather_totals = lambda local: local.repeat(Rn, 1)     # same table shape and selection work as the real all-gather
         from rgm import batch_shard                                     # the x_t forward of a search step: this rank's rows only
         batch_shard.partition_rows = lambda B, ws=None, r=None: ((0, B // Rn) if B % Rn == 0 else ((0, 1) if Rn % B == 0 else None))
+        batch_shard.partition_roles = lambda B, ws=None, r=None: batch_shard._orig_partition_roles(B, Rn, 0)   # rank 0: an eps row (the longer role)
         batch_shard.gather_rows = lambda ts: [t.repeat((Rn,) + (1,) * (t.dim() - 1)) for t in ts]   # stand-in: shapes, not values
     if args.workload in ("c2", "c3", "dps_rule"):
         work.d.batch_shard = False            # the headline runs one independent chain per GPU (weak scaling): nothing to shard

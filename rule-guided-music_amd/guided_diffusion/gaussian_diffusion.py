@@ -271,23 +271,36 @@ class GaussianDiffusion:
         follows needs them identical everywhere ("or shard that forward over batch and all-gather 32 KiB/sample")."""
         B = x.shape[0]
 
-        def run(xr, tr, kw, ekw):
-            eps = self._model_eps(xr, self._wrap_model(model)(xr, self._scale_timesteps(tr), **kw), tr, denoised_fn)
-            if ekw is not None:
-                eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw, denoised_fn)
-            grad = None
-            if cond_fn is not None:
+        def run(xr, tr, kw, ekw, want_eps=True, want_grad=True):
+            eps = grad = None
+            if want_eps:
+                eps = self._model_eps(xr, self._wrap_model(model)(xr, self._scale_timesteps(tr), **kw), tr, denoised_fn)
+                if ekw is not None:
+                    eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw, denoised_fn)
+            if cond_fn is not None and want_grad:
                 if ekw is None or not grad_on_edit_rows:      # (ddim_sample differentiates the whole latent, like the reference)
                     grad = self._wrap_model(cond_fn)(xr, self._scale_timesteps(tr), **kw)
                 else:
                     grad = self._edit_grad(self._wrap_model(cond_fn), xr, self._scale_timesteps(tr), kw, ekw)
             return eps, grad
 
-        part = None
+        part = roles = None
         if self.scg_shard and self.batch_shard and self._rows is None and not record and not self._learned():
             part = batch_shard.partition_rows(B)
+            if cond_fn is not None and self.model_mean_type != ModelMeanType.PREVIOUS_X:
+                roles = batch_shard.partition_roles(B)
         if part is None:
             return run(x, t, model_kwargs, edit_kwargs)
+        if roles is not None:
+            # R >= 2 B: eps of row b on rank b, its guidance gradient on rank B + b, at the same time; one all-gather of (eps | grad)
+            row, role = roles
+            eps, grad = run(x[row:row + 1].contiguous(), t[row:row + 1].contiguous(), batch_shard.slice_rows(model_kwargs, B, row, 1),
+                            batch_shard.slice_rows(edit_kwargs, B, row, 1) if edit_kwargs is not None else None,
+                            want_eps=role == 0, want_grad=role == 1)
+            mine = (eps if role == 0 else grad).float()
+            zero = th.zeros_like(mine)
+            full = batch_shard.gather_rows([mine if role == 0 else zero, mine if role == 1 else zero])
+            return full[0][:B].contiguous(), full[1][B:2 * B].contiguous()
         b0, nb = part
         eps, grad = run(x[b0:b0 + nb].contiguous(), t[b0:b0 + nb].contiguous(), batch_shard.slice_rows(model_kwargs, B, b0, nb),
                         batch_shard.slice_rows(edit_kwargs, B, b0, nb) if edit_kwargs is not None else None)

@@ -50,6 +50,22 @@ def partition_rows(B, world_size=None, rank=None):
 _orig_partition_rows = partition_rows        # (tests replace partition_rows with one rank's view and still need the rule itself)
 
 
+def partition_roles(B, world_size=None, rank=None):
+    """At least twice as many ranks as samples (B = 4 on 8 GPUs -- the north star's C4) AND a classifier gradient to compute: the two
+    per-sample forwards of a search step do not depend on each other (the guidance gradient is a function of x_t and t alone,
+    condition_functions.py:58-64), so they go to DIFFERENT ranks instead of one after the other on the same one.  Returns
+    (row, role) -- role 0: the eps-network forward of that row, role 1: its classifier gradient -- or None when the rule does not apply.
+    Ranks [0, B) take role 0, ranks [B, 2B) role 1, further ranks repeat the pattern (their results are not read)."""
+    if world_size is None:
+        world_size, rank = world()
+    if world_size <= 1 or B <= 0 or world_size % B != 0 or world_size < 2 * B:
+        return None
+    return rank % B, (rank // B) % 2
+
+
+_orig_partition_roles = partition_roles
+
+
 PER_SAMPLE_VECTORS = ("y", "t", "timesteps")      # the only 1-D tensors that carry one entry per sample
 
 

@@ -310,6 +310,71 @@ def test_search_step_forward_rows_are_shared_out_over_the_ranks(monkeypatch, wor
     assert calls == [(r, max(1, B // world)) for r in range(world)]
 
 
+def test_search_step_eps_and_gradient_rows_go_to_different_ranks_when_there_are_twice_as_many(monkeypatch):
+    """R >= 2 B with classifier guidance (C4 on 8 GPUs: B = 4): batch_shard.partition_roles gives rank b the eps-network forward of
+    row b and rank B + b its guidance gradient -- the two do not depend on each other (condition_functions.py:58-64) -- and ONE
+    all-gather of (eps | gradient) slots completes both.  Replayed as 'rank r of 4' for B = 2 on one GPU with a stand-in all-gather
+    that computes the other ranks' slots the way those ranks would: every rank ends on the unsharded winners and latent."""
+    from functools import partial
+    from types import SimpleNamespace
+    from gpu_util import dev, rel
+    from rgm import batch_shard
+    from guided_diffusion.condition_functions import composite_nn_zt
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    from test_gpu_pins2 import _cls
+    g = load_golden("steps")
+    m, vae, cm = _dit(SM, 11), _vae(2), _cls()
+    tgt = {"pitch_hist": dev(g["scg.target.pitch_hist"]), "note_density": dev(g["scg.target.note_density"])}
+    cond = partial(composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[cm], rule_names=["note_density"])
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="classifier_guidance")
+    scg = {"num_samples": 8, "pitch_hist": 40., "note_density": 1.}
+    x, t, y = dev(g["x"]), dev(g["scg.t"]), dev(g["y"])
+    B, world = x.shape[0], 4
+    assert B == 2
+    mf = _model_fn(m)
+
+    def run(d):
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=7)
+        out = d.p_sample(mf, x, t, clip_denoised=False, cond_fn=cond, model_kwargs={"y": y, "rule": tgt}, embed_model=vae,
+                         scale_factor=1.2465, guidance_kwargs=guid, scg_kwargs=scg)
+        return out["sample"], d.last_scg["max_ind"].clone()
+
+    assert [batch_shard.partition_roles(B, world, r) for r in range(world)] == [(0, 0), (1, 0), (0, 1), (1, 1)]
+    assert batch_shard.partition_roles(4, 8, 6) == (2, 1) and batch_shard.partition_roles(4, 4, 1) is None and batch_shard.partition_roles(3, 8, 0) is None
+    ref_sample, ref_idx = run(_diffusion(""))
+    dd = _diffusion("")
+    seen = []
+    for rank in range(world):
+        monkeypatch.setattr(batch_shard, "partition_rows", lambda b, ws=None, r=None, rank=rank: batch_shard._orig_partition_rows(b, world, rank))
+        monkeypatch.setattr(batch_shard, "partition_roles", lambda b, ws=None, r=None, rank=rank: batch_shard._orig_partition_roles(b, world, rank))
+
+        def fake_gather(tensors, rank=rank):
+            assert len(tensors) == 2 and tensors[0].shape[0] == 1
+            slots = [[], []]
+            for r in range(world):
+                row, role = batch_shard._orig_partition_roles(B, world, r)
+                if r == rank:
+                    mine = [tensors[0], tensors[1]]
+                else:
+                    xr, tr = x[row:row + 1].contiguous(), t[row:row + 1].contiguous()
+                    kw = {"y": y[row:row + 1], "rule": {k: v[row:row + 1] for k, v in tgt.items()}}
+                    with torch.no_grad():
+                        val = (dd._wrap_model(mf)(xr, dd._scale_timesteps(tr), **kw) if role == 0 else dd._wrap_model(cond)(xr, dd._scale_timesteps(tr), **kw)).float()
+                    mine = [val if role == 0 else torch.zeros_like(val), val if role == 1 else torch.zeros_like(val)]
+                slots[0].append(mine[0])
+                slots[1].append(mine[1])
+            my_row, my_role = batch_shard._orig_partition_roles(B, world, rank)
+            assert float(tensors[1 - my_role].abs().max()) == 0.0 and float(tensors[my_role].abs().max()) > 0.0
+            seen.append((rank, my_role))
+            return [torch.cat(slots[0], dim=0), torch.cat(slots[1], dim=0)]
+        monkeypatch.setattr(batch_shard, "gather_rows", fake_gather)
+        s, idx = run(_diffusion(""))
+        assert torch.equal(idx, ref_idx), f"rank {rank} of {world}: other winners"
+        assert rel(s.cpu().numpy(), ref_sample.cpu().numpy()) < 2e-5, rank
+    assert seen == [(0, 0), (1, 0), (2, 1), (3, 1)]
+
+
 def test_sharded_segmentwise_scg_matches_unsharded(monkeypatch):
     """dc.base > 0 (per-segment winners, reference :562-592) under candidate sharding: rank r scores its half of the
     candidates on every segment, the stand-in all-gather completes the (n, S, B) table, every rank picks the same

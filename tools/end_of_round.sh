@@ -1,0 +1,28 @@
+#!/bin/bash
+# End-of-round evidence in ONE gpurun call: the default bench line, rocprofv3 kernel stats of every BASELINE workload and the small batches.
+#   gpurun --timeout 3000 -- tools/end_of_round.sh r04
+set -u
+R=${1:-r04}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+cd $ROOT
+mkdir -p gpurun_out
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default_n1.json 2> gpurun_out/${R}_bench_default_n1.log
+tools/prof_bench.sh ${R}_c2 --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_c3 --no-extras --workload c3 --steps 20 --warmup 5 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_scg_b4_n16 --no-extras --workload scg --steps 5 --warmup 2 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_long --no-extras --workload long --steps 5 --warmup 2 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_scg_r8 --no-extras --workload scg --simulate-ranks 8 --steps 10 --warmup 3 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_long_r8 --no-extras --workload long --simulate-ranks 8 --steps 5 --warmup 2 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_c2_b4 --no-extras --batch 4 --steps 20 --warmup 5 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_c2_b8 --no-extras --batch 8 --steps 20 --warmup 5 > /dev/null 2>&1
+python tools/batch_sweep.py > gpurun_out/${R}_batch_sweep.txt 2>&1
+python tools/cls_time.py 1 4 8 16 32 > gpurun_out/${R}_cls_time.txt 2>&1
+for f in gpurun_out/${R}_*_bench_under_rocprof.json gpurun_out/${R}_bench_default_n1.json; do echo "== $f"; python - "$f" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print(d["ms_per_step"], d["value"], d["config"].get("workload", "")[:60], "frac", d["roofline"]["frac"], "tflops", d["config"].get("algorithmic_tflops"))
+except Exception as e:
+    print("unreadable:", e)
+PY
+done
