@@ -39,6 +39,9 @@ from rgm import batch_shard, scg_shard
 from music_rule_guidance.rule_maps import FUNC_DICT, LOSS_DICT
 
 
+_CONCURRENT_GRAD = __import__("os").environ.get("RGM_GRAD_STREAM", "1") != "0"   # 0: eps forward, then the guidance gradient (A/B runs)
+
+
 # --------------------------------------------------------------------------------- schedules
 def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
     """Named beta schedules of the reference (gaussian_diffusion.py:31-62)."""
@@ -162,6 +165,7 @@ class GaussianDiffusion:
         self._rows = None             # (b0, nb, B) while a rank computes its rows of a batch-sharded step
         self._tables = {}
         self._t_host = None
+        self._grad_streams = {}       # device -> side stream of the guidance gradient of a search step (_search_step_inputs)
 
     # ------------------------------------------------------------------ helpers
     def _check_supported(self):
@@ -273,15 +277,32 @@ class GaussianDiffusion:
 
         def run(xr, tr, kw, ekw, want_eps=True, want_grad=True):
             eps = grad = None
+
+            def the_grad():
+                if ekw is None or not grad_on_edit_rows:      # (ddim_sample differentiates the whole latent, like the reference)
+                    return self._wrap_model(cond_fn)(xr, self._scale_timesteps(tr), **kw)
+                return self._edit_grad(self._wrap_model(cond_fn), xr, self._scale_timesteps(tr), kw, ekw)
+            # the guidance gradient is a function of (x_t, t) alone: when this rank computes both, the classifiers' chains of small
+            # launches run on a side stream beside the eps-network's (both leave most CUs idle at the samplers' batches)
+            side = None
+            if cond_fn is not None and want_grad and want_eps and xr.is_cuda and _CONCURRENT_GRAD:
+                main = th.cuda.current_stream(xr.device)
+                if xr.device not in self._grad_streams:
+                    self._grad_streams[xr.device] = th.cuda.Stream(device=xr.device)
+                side = self._grad_streams[xr.device]
+                side.wait_stream(main)
+                with th.cuda.stream(side):
+                    grad = the_grad()
             if want_eps:
                 eps = self._model_eps(xr, self._wrap_model(model)(xr, self._scale_timesteps(tr), **kw), tr, denoised_fn)
                 if ekw is not None:
                     eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw, denoised_fn)
-            if cond_fn is not None and want_grad:
-                if ekw is None or not grad_on_edit_rows:      # (ddim_sample differentiates the whole latent, like the reference)
-                    grad = self._wrap_model(cond_fn)(xr, self._scale_timesteps(tr), **kw)
-                else:
-                    grad = self._edit_grad(self._wrap_model(cond_fn), xr, self._scale_timesteps(tr), kw, ekw)
+            if side is not None:
+                th.cuda.current_stream(xr.device).wait_stream(side)
+                if th.is_tensor(grad):
+                    grad.record_stream(th.cuda.current_stream(xr.device))
+            elif cond_fn is not None and want_grad:
+                grad = the_grad()
             return eps, grad
 
         part = roles = None
