@@ -831,9 +831,28 @@ class GaussianDiffusion:
                                      scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
                                      dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record)
             return {"sample": sample, "pred_xstart": x0}
+        def the_grad():
+            if edit_kwargs is None:
+                return self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
+            return self._edit_grad(self._wrap_model(cond_fn), x, self._scale_timesteps(t), model_kwargs, edit_kwargs)
+        # classifier guidance (condition_mean's non-DPS branch, :402-407): the gradient depends on (x_t, t) only -- it is enqueued on a
+        # side stream in front of the eps-network forward and joined before the fused step (RGM_GRAD_STREAM=0: one after the other)
+        grad, side = None, None
+        if guided and not dps and x.is_cuda and _CONCURRENT_GRAD:
+            main = th.cuda.current_stream(x.device)
+            if x.device not in self._grad_streams:
+                self._grad_streams[x.device] = th.cuda.Stream(device=x.device)
+            side = self._grad_streams[x.device]
+            side.wait_stream(main)
+            with th.cuda.stream(side):
+                grad = the_grad()
         eps = self._model_eps(x, self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
+        if side is not None:
+            th.cuda.current_stream(x.device).wait_stream(side)
+            if th.is_tensor(grad):
+                grad.record_stream(th.cuda.current_stream(x.device))
         if dps:
             if self._learned():
                 raise NotImplementedError("DPS guidance on a learn_sigma=True network: the reference's condition_mean feeds the 2C-channel "
@@ -858,12 +877,8 @@ class GaussianDiffusion:
             else:
                 sample = mean
             return {"sample": sample, "pred_xstart": x0}
-        grad = None
-        if guided:
-            if edit_kwargs is None:
-                grad = self._wrap_model(cond_fn)(x, self._scale_timesteps(t), **model_kwargs)
-            else:
-                grad = self._edit_grad(self._wrap_model(cond_fn), x, self._scale_timesteps(t), model_kwargs, edit_kwargs)
+        if guided and side is None:
+            grad = the_grad()
         if scg_kwargs is None or self._t0(t) > self.t_end:       # (the search steps of an SCG chain returned above)
             sample, x0, _ = self._step("ddpm", x, eps, grad, self._draw(x.shape, x.device), t, clip_denoised)
         else:
