@@ -118,6 +118,9 @@ def read_lightning_state_dict(path):
     return dict(sd)
 
 
+DECODE_CHUNK_SAMPLES = int(__import__("os").environ.get("RGM_VAE_CHUNK_SAMPLES", "0"))
+
+
 class AutoencoderKL(nn.Module):
     def __init__(self, ddconfig=None, lossconfig=None, embed_dim=4, ckpt_path=None, ignore_keys=(), image_key="image",
                  colorize_nlabels=None, monitor=None):
@@ -218,11 +221,17 @@ class AutoencoderKL(nn.Module):
         assert Cc == 4 and W == 16 and H % 16 == 0, f"latent must be (N,4,16k,16), got {tuple(latent.shape)}"
         roll = torch.empty((N, 3, 128, 8 * H), dtype=torch.float32, device=dev) if want_float else None
         u8 = torch.empty((N, 128, 8 * H, 3), dtype=torch.uint8, device=dev) if want_u8 else None
-        ws, need = self._workspace(N * (H // 16), dev)
+        # samples per native call (0 = all at once): a chunk whose largest activation fits the 256 MB Infinity Cache keeps the
+        # GroupNorm -> conv -> GroupNorm traffic of the decoder out of HBM (experiment: RGM_VAE_CHUNK_SAMPLES)
+        chunk = DECODE_CHUNK_SAMPLES if 0 < DECODE_CHUNK_SAMPLES < N else N
+        ws, need = self._workspace(chunk * (H // 16), dev)
         with torch.cuda.device(dev):
-            _rgm.check(_rgm.lib.rgm_vae_decode_latent(self._handle, _rgm.ptr(latent), 1.0 / float(scale_factor), _rgm.ptr(roll),
-                                                      _rgm.ptr(u8), float(threshold), N, H, _rgm.ptr(ws), need,
-                                                      _rgm.current_stream()))
+            for n0 in range(0, N, chunk):
+                nn_ = min(chunk, N - n0)
+                _rgm.check(_rgm.lib.rgm_vae_decode_latent(self._handle, _rgm.ptr(latent[n0:n0 + nn_]), 1.0 / float(scale_factor),
+                                                          _rgm.ptr(roll[n0:n0 + nn_]) if roll is not None else None,
+                                                          _rgm.ptr(u8[n0:n0 + nn_]) if u8 is not None else None, float(threshold), nn_, H,
+                                                          _rgm.ptr(ws), need, _rgm.current_stream()))
         if want_u8 and want_float:
             return roll, u8
         return u8 if want_u8 else roll
