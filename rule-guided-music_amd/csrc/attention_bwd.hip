@@ -44,7 +44,7 @@ template <int HD, int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, const float* __restrict__ cos_tab,
-                                                          const float* __restrict__ sin_tab, int T, int heads, int rot_half) {
+                                                          const float* __restrict__ sin_tab, int T, int heads, int rot_half, int lone) {
   constexpr int HDP = HD + 4, KB = HD / 8, DT = (HD + 31) / 32, TP = NKT * 32;   // hd = 72: the third channel tile is partial
   // (its operand reads run past a row into the next row / the following array: finite data feeding accumulator rows that are never stored)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -72,9 +72,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const float scale = rsqrtf((float)HD);
-  const int nqt = (T + 31) >> 5, ktr = T >> 5, tr = T & 31;
+  const int ktr = T >> 5, tr = T & 31;
+  // lone (T % 32 == 1, the classifiers' 257 tokens): the last query tile holds ONE query -- as a ninth MFMA tile it is a second round for
+  // wave 0, i.e. the whole kernel's second tile-time.  One wave computes that query's row with plain FMAs instead (below).
+  const int nqt = ((T + 31) >> 5) - (lone ? 1 : 0);
   const int qt0 = SPLIT ? blockIdx.x - bh * nqt_all : wave;
-  for (int qt = qt0; qt < nqt; qt += SPLIT ? nqt : 8) {
+  for (int qt = qt0; qt < nqt; qt += SPLIT ? nqt_all : 8) {
     const int q = qt * 32 + l31, qc = min(q, T - 1);
     const long long orow = ((long long)n * T + qc) * D + head * HD;
     f32x4 qf[KB], dof[KB];
@@ -172,6 +175,56 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
         }
     }
   }
+  if constexpr (!SPLIT) {
+    if (lone && wave == 7) {
+      // dQ of the lone last query q* = T - 1 without MFMA: phase A, lane = key: s = q* . K[key], dp = dO* . V[key], ds = p (dp - D*);
+      // phase B, lane = channel: dq*[d] = sum_key ds[key] K[key][d].  Scratch rows sit behind the K / V images (launch_bwd asks for them).
+      float* scr = smem + 2 * TP * HDP;          // qrow[HDP] | grow[HDP] | ds[TP] | out[HDP]
+      float* qrow = scr;
+      float* grow = scr + HDP;
+      float* dsr = scr + 2 * HDP;
+      float* outr = dsr + TP;
+      const int qs_ = T - 1;
+      const long long orow = ((long long)n * T + qs_) * D + head * HD;
+      float dpart = 0.f;
+      for (int d0 = lane * 4; d0 < HD; d0 += 256) {
+        float4 v = *reinterpret_cast<const float4*>(base + (long long)qs_ * D3 + d0);
+        if (d0 < R) v = rotate4(v, cos_tab, sin_tab, qs_ * rot_half + (d0 >> 1), false);
+        *reinterpret_cast<float4*>(qrow + d0) = make_float4(v.x * scale, v.y * scale, v.z * scale, v.w * scale);
+        const float4 g = *reinterpret_cast<const float4*>(d_o + orow + d0);
+        const float4 ov = *reinterpret_cast<const float4*>(o + orow + d0);
+        *reinterpret_cast<float4*>(grow + d0) = g;
+        dpart += (g.x * ov.x + g.y * ov.y) + (g.z * ov.z + g.w * ov.w);
+      }
+      const float dstar = wave_sum(dpart);
+      const float lq = lse[((long long)n * heads + head) * T + qs_];
+      for (int key = lane; key < TP; key += 64) {
+        float sacc = 0.f, dpa = 0.f;
+        if (key < T) {
+          const float* kr = Ks + key * HDP;
+          const float* vr = Vs + key * HDP;
+#pragma unroll 4
+          for (int d0 = 0; d0 < HD; d0 += 4) {
+            const float4 kq = *reinterpret_cast<const float4*>(kr + d0), vq = *reinterpret_cast<const float4*>(vr + d0);
+            const float4 qq = *reinterpret_cast<const float4*>(qrow + d0), gq = *reinterpret_cast<const float4*>(grow + d0);
+            sacc += (kq.x * qq.x + kq.y * qq.y) + (kq.z * qq.z + kq.w * qq.w);
+            dpa += (vq.x * gq.x + vq.y * gq.y) + (vq.z * gq.z + vq.w * gq.w);
+          }
+        }
+        dsr[key] = key < T ? exp_le0(sacc - lq) * (dpa - dstar) : 0.f;
+      }
+      for (int d = lane; d < HD; d += 64) {        // (same wave wrote dsr: LDS operations of a wave are in order)
+        float a = 0.f;
+        for (int key = 0; key < T; ++key) a = fmaf(dsr[key], Ks[key * HDP + d], a);
+        outr[d] = a * scale;
+      }
+      for (int d0 = lane * 4; d0 < HD; d0 += 256) {
+        float4 v = *reinterpret_cast<const float4*>(outr + d0);
+        if (d0 < R) v = rotate4(v, cos_tab, sin_tab, qs_ * rot_half + (d0 >> 1), true);
+        *reinterpret_cast<float4*>(dqkv + ((long long)n * T + qs_) * D3 + head * HD + d0) = v;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------- dK, dV
@@ -180,7 +233,7 @@ template <int HD, int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, const float* __restrict__ cos_tab,
-                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half) {
+                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half, int lone) {
   constexpr int HDP = HD + 4, KB = HD / 8, DT = (HD + 31) / 32, TP = NKT * 32;   // hd = 72: the third channel tile is partial
   // (its operand reads run past a row into the next row / the following array: finite data feeding accumulator rows that are never stored)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -224,9 +277,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int nkt = (T + 31) >> 5, qtr = T >> 5, tr = T & 31;
+  const int qtr = T >> 5, tr = T & 31;
+  // lone (T % 32 == 1): the last token is a tile of its own on both axes.  As a KEY it would be a second round for wave 0 -> one wave
+  // computes its dK / dV rows with plain FMAs (below); as a QUERY it would be a ninth MFMA iteration of every wave's loop -> a rank-1
+  // update of the accumulators instead.
+  const int nkt = ((T + 31) >> 5) - (lone ? 1 : 0);
   const int kt0 = SPLIT ? blockIdx.x - bh * nkt_all : wave;
-  for (int kt = kt0; kt < nkt; kt += SPLIT ? nkt : 8) {
+  for (int kt = kt0; kt < nkt; kt += SPLIT ? nkt_all : 8) {
     const int key = kt * 32 + l31, kc = min(key, T - 1);
     f32x4 kf[KB], vf[KB];
     {
@@ -249,7 +306,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
       for (int e = 0; e < 16; ++e) { dk[dt][e] = 0.f; dv[dt][e] = 0.f; }
 #pragma unroll 1
     for (int qt = SPLIT ? wave : 0; qt < NKT; qt += SPLIT ? 8 : 1) {
-      if (qt * 32 >= T) break;
+      if (qt * 32 >= T - (lone ? 1 : 0)) break;
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
@@ -285,6 +342,35 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
           dk[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(qr[dt * 32], ds[u], dk[dt], 0, 0, 0);   // dK_rot^T[d][key]
         }
         if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if constexpr (!SPLIT) {
+      if (lone) {   // the lone last query q* against this wave's 32 keys: s, dp from the K / V fragments the lanes hold, then
+        const int qs_ = T - 1;                    // dV^T[d][key] += dO[q*][d] p[key], dK^T[d][key] += Q[q*][d] ds[key]
+        const float* qr = Qs + qs_ * HDP;
+        const float* gr = Gs + qs_ * HDP;
+        float sp = 0.f, dpp = 0.f;
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const float4 qq = *reinterpret_cast<const float4*>(qr + 8 * j + 4 * hh), gq = *reinterpret_cast<const float4*>(gr + 8 * j + 4 * hh);
+          sp += (kf[j][0] * qq.x + kf[j][1] * qq.y) + (kf[j][2] * qq.z + kf[j][3] * qq.w);
+          dpp += (vf[j][0] * gq.x + vf[j][1] * gq.y) + (vf[j][2] * gq.z + vf[j][3] * gq.w);
+        }
+        sp += __shfl_xor(sp, 32, 64);
+        dpp += __shfl_xor(dpp, 32, 64);
+        const float pv = key_ok ? exp_le0(sp - Ls[qs_]) : 0.f;
+        const float dsv = pv * (dpp - Ds[qs_]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d = dt * 32 + 8 * g + 4 * hh;          // registers 4g..4g+3 of tile dt = channels d..d+3 (reads past hd: never stored)
+            const float4 gq = *reinterpret_cast<const float4*>(gr + d), qq = *reinterpret_cast<const float4*>(qr + d);
+            dv[dt][4 * g] = fmaf(gq.x, pv, dv[dt][4 * g]); dv[dt][4 * g + 1] = fmaf(gq.y, pv, dv[dt][4 * g + 1]);
+            dv[dt][4 * g + 2] = fmaf(gq.z, pv, dv[dt][4 * g + 2]); dv[dt][4 * g + 3] = fmaf(gq.w, pv, dv[dt][4 * g + 3]);
+            dk[dt][4 * g] = fmaf(qq.x, dsv, dk[dt][4 * g]); dk[dt][4 * g + 1] = fmaf(qq.y, dsv, dk[dt][4 * g + 1]);
+            dk[dt][4 * g + 2] = fmaf(qq.z, dsv, dk[dt][4 * g + 2]); dk[dt][4 * g + 3] = fmaf(qq.w, dsv, dk[dt][4 * g + 3]);
+          }
       }
     }
     if constexpr (SPLIT) {   // partial dK / dV -> LDS [wave][dK | dV][key][HDP] over the Q / dO images (launch_bwd sizes the request for it)
@@ -330,6 +416,58 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         }
     }
   }
+  if constexpr (!SPLIT) {
+    if (lone && wave == 7) {
+      // dK, dV of the lone last key k* = T - 1 without MFMA: phase A, lane = query: p = exp(Q[q] . K* - lse[q]), ds = p (dO[q] . V* - D[q]);
+      // phase B, lane = channel: dV*[d] = sum_q p[q] dO[q][d], dK*[d] = sum_q ds[q] Q[q][d].  Scratch rows behind lse / D.
+      float* scr = Ds + TP;                      // krow[HDP] | vrow[HDP] | p[TP] | ds[TP] | out[HDP]
+      float* krow = scr;
+      float* vrow = scr + HDP;
+      float* pr = scr + 2 * HDP;
+      float* dsr = pr + TP;
+      float* outr = dsr + TP;
+      const int ks_ = T - 1;
+      const float* rowp = base + (long long)ks_ * D3;
+      for (int d0 = lane * 4; d0 < HD; d0 += 256) {
+        float4 kv = *reinterpret_cast<const float4*>(rowp + D + d0);
+        if (d0 < R) kv = rotate4(kv, cos_tab, sin_tab, ks_ * rot_half + (d0 >> 1), false);
+        *reinterpret_cast<float4*>(krow + d0) = kv;
+        *reinterpret_cast<float4*>(vrow + d0) = *reinterpret_cast<const float4*>(rowp + 2 * D + d0);
+      }
+      for (int qi = lane; qi < TP; qi += 64) {
+        float sacc = 0.f, dpa = 0.f;
+        if (qi < T) {
+          const float* qr = Qs + qi * HDP;
+          const float* gr = Gs + qi * HDP;
+#pragma unroll 4
+          for (int d0 = 0; d0 < HD; d0 += 4) {
+            const float4 qq = *reinterpret_cast<const float4*>(qr + d0), gq = *reinterpret_cast<const float4*>(gr + d0);
+            const float4 kq = *reinterpret_cast<const float4*>(krow + d0), vq = *reinterpret_cast<const float4*>(vrow + d0);
+            sacc += (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
+            dpa += (gq.x * vq.x + gq.y * vq.y) + (gq.z * vq.z + gq.w * vq.w);
+          }
+        }
+        const float pv = qi < T ? exp_le0(sacc - Ls[qi]) : 0.f;
+        pr[qi] = pv;
+        dsr[qi] = pv * (dpa - Ds[qi < T ? qi : 0]);
+      }
+      float* op = dqkv + ((long long)n * T + ks_) * D3 + head * HD;
+      for (int d = lane; d < HD; d += 64) {
+        float av = 0.f, ak = 0.f;
+        for (int qi = 0; qi < T; ++qi) {
+          av = fmaf(pr[qi], Gs[qi * HDP + d], av);
+          ak = fmaf(dsr[qi], Qs[qi * HDP + d], ak);
+        }
+        op[2 * D + d] = av;
+        outr[d] = ak;
+      }
+      for (int d0 = lane * 4; d0 < HD; d0 += 256) {
+        float4 v = *reinterpret_cast<const float4*>(outr + d0);
+        if (d0 < R) v = rotate4(v, cos_tab, sin_tab, ks_ * rot_half + (d0 >> 1), true);
+        *reinterpret_cast<float4*>(op + D + d0) = v;
+      }
+    }
+  }
 }
 
 static int g_attn_split = -1;   // rgm_set_attn_split: -1 auto, 0 never, 1 always
@@ -357,25 +495,31 @@ static int launch_bwd(const float* qkv, const float* o, const float* d_o, const 
       RGM_TRY(attn_prepare_kernel(kkv, 512, lds_kv, "attn_bwd_dkv_kernel (per key tile)"));
       prepared = true;
     }
-    hipLaunchKernelGGL(kq, dim3(N * heads * nt), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
+    hipLaunchKernelGGL(kq, dim3(N * heads * nt), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, 0);
     RGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kkv, dim3(N * heads * nt), dim3(512), lds_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
+    hipLaunchKernelGGL(kkv, dim3(N * heads * nt), dim3(512), lds_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, 0);
     RGM_LAUNCH_CHECK();
     return RGM_OK;
   }
-  const size_t lds_q = attn_lds_one_per_cu(images);
-  const size_t lds_kv = attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float));
+  // the lone-token paths (T % 32 == 1 with more than one tile: the classifiers' 257 tokens) keep a few scratch rows behind the images
+  const size_t scr_q = (size_t)(3 * HDP + TP) * sizeof(float), scr_kv = (size_t)(3 * HDP + 2 * TP) * sizeof(float);
+  const size_t lds_q = attn_lds_one_per_cu(images + scr_q);
+  const size_t lds_kv = attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float) + scr_kv);
+  static const int lone_off = getenv("RGM_ATTN_LONE") ? !atoi(getenv("RGM_ATTN_LONE")) : 0;      // RGM_ATTN_LONE=0: every tile through the MFMAs (A/B)
+  const int lone = (!lone_off && (T & 31) == 1 && nt > 1 && lds_kv <= 160 * 1024) ? 1 : 0;
   auto kq = attn_bwd_dq_kernel<HD, NKT, false>;
   auto kkv = attn_bwd_dkv_kernel<HD, NKT, false>;
   static bool prepared = false;
   if (!prepared) {
-    RGM_TRY(attn_prepare_kernel(kq, 512, lds_q, "attn_bwd_dq_kernel"));
-    RGM_TRY(attn_prepare_kernel(kkv, 512, lds_kv, "attn_bwd_dkv_kernel"));
+    RGM_TRY(attn_prepare_kernel(kq, 512, lds_q <= 160 * 1024 ? lds_q : attn_lds_one_per_cu(images), "attn_bwd_dq_kernel"));
+    RGM_TRY(attn_prepare_kernel(kkv, 512, lds_kv <= 160 * 1024 ? lds_kv : attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float)), "attn_bwd_dkv_kernel"));
     prepared = true;
   }
-  hipLaunchKernelGGL(kq, dim3(N * heads), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
+  const size_t use_q = lds_q <= 160 * 1024 ? lds_q : attn_lds_one_per_cu(images);
+  const size_t use_kv = lds_kv <= 160 * 1024 ? lds_kv : attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float));
+  hipLaunchKernelGGL(kq, dim3(N * heads), dim3(512), use_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, lone);
   RGM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kkv, dim3(N * heads), dim3(512), lds_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half);
+  hipLaunchKernelGGL(kkv, dim3(N * heads), dim3(512), use_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, lone);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
