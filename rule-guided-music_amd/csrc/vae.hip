@@ -1087,6 +1087,19 @@ extern "C" size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M) {
 }
 
 // in: element (tile m = s*Nb + n, channel c, pitch i, time j) at in[n*n_stride + s*s_stride + c*sc + i*si + j*sj] * in_scale
+// conv_out (+ bias, scatter into the roll, optional uint8 quantise): one launcher for the plain and the saving decode
+static int conv_out_launch(const rgm_vae* h, const float* t1, float* roll, uint8_t* u8, int M, int Nb, int Tt, float thr, hipStream_t s) {
+  static const int tiled = getenv("RGM_CONV_OUT_TILED") ? atoi(getenv("RGM_CONV_OUT_TILED")) : 1;   // 0: the one-row kernel (A/B)
+  if (tiled)
+    hipLaunchKernelGGL(vae_conv_out_tiled_kernel, dim3(M * 64), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
+                       h->p("decoder.conv_out.bias"), roll, u8, M, Nb, Tt, thr);
+  else
+    hipLaunchKernelGGL(vae_conv_out_kernel, dim3(M * 128), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
+                       h->p("decoder.conv_out.bias"), roll, u8, M, Nb, Tt, thr);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+
 static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_stride, long long s_stride, long long sc,
                        long long si, long long sj, float in_scale, float* roll, uint8_t* u8, float thr, void* ws,
                        size_t ws_bytes, hipStream_t s) {
@@ -1138,15 +1151,7 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
     }
   }
   RGM_TRY(group_norm(c, cur, t1, 128 * 128, C, d + "norm_out", 1));
-  static const int conv_out_tiled = getenv("RGM_CONV_OUT_TILED") ? atoi(getenv("RGM_CONV_OUT_TILED")) : 1;   // 0: the one-row kernel (A/B)
-  if (conv_out_tiled)
-    hipLaunchKernelGGL(vae_conv_out_tiled_kernel, dim3(M * 64), dim3(256), 0, s, t1, h->p(d + "conv_out.weight"), h->p(d + "conv_out.bias"),
-                       roll, u8, M, Nb, S * 128, thr);
-  else
-    hipLaunchKernelGGL(vae_conv_out_kernel, dim3(M * 128), dim3(256), 0, s, t1, h->p(d + "conv_out.weight"), h->p(d + "conv_out.bias"),
-                       roll, u8, M, Nb, S * 128, thr);
-  RGM_LAUNCH_CHECK();
-  return RGM_OK;
+  return conv_out_launch(h, t1, roll, u8, M, Nb, S * 128, thr, s);
 }
 
 extern "C" int rgm_vae_decode(rgm_vae* h, const float* z, float* out, int M, void* ws, size_t ws_bytes, void* stream) {
@@ -1329,10 +1334,7 @@ static int decode_save_impl(rgm_vae* h, const float* in, int Nb, int S, long lon
     }
   }
   RGM_TRY(group_norm(c, g.x_last, t1, 128 * 128, 128, "decoder.norm_out", 1, 0, g.st_out));
-  hipLaunchKernelGGL(vae_conv_out_kernel, dim3(M * 128), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
-                     h->p("decoder.conv_out.bias"), roll, (uint8_t*)nullptr, M, Nb, S * 128, -0.95f);
-  RGM_LAUNCH_CHECK();
-  return RGM_OK;
+  return conv_out_launch(h, t1, roll, nullptr, M, Nb, S * 128, -0.95f, s);   // the same kernel as the plain decode: identical rolls
 }
 
 // d_in = (d roll / d in)^T d_roll for the decode decode_save_impl ran on this workspace

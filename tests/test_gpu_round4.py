@@ -127,3 +127,45 @@ def test_c4_step_with_classifiers_and_scg_against_the_reference(precision):
     assert np.array_equal(d.last_scg["max_ind"].cpu().numpy().reshape(-1), g["c4.max_ind"])
     assert rel(out["sample"].cpu().numpy(), g["c4.sample"]) < (5e-5 if precision == "fp32" else 2e-4)
     assert rel(out["pred_xstart"].cpu().numpy(), g["c4.pred_xstart"]) < (5e-5 if precision == "fp32" else 3e-4)
+
+
+def test_side_stream_classifiers_and_gradient_give_the_same_bits(precision):
+    """Round 4 runs independent chains of small launches on side streams: the classifiers of a composite cond_fn (composite_nn_zt) and the
+    guidance gradient beside the eps-network forward (p_sample, _search_step_inputs).  Forked from and joined to the caller's stream, summed
+    in the reference's order: a classifier-guided step and a classifier-guided SCG step must come out bit-identical with the streams on
+    and off."""
+    from gpu_util import dev
+    from guided_diffusion import condition_functions as cf, gaussian_diffusion as gd
+    from guided_diffusion.condition_functions import model_fn
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    from test_gpu_fullsize import XL2, _c4_classifiers, _diffusion, _dit, _vae
+    B, n = 4, 4
+    g = load_golden("round4")
+    x = dev(np.random.RandomState(11).randn(B, 4, 128, 16).astype(F32))
+    m, vae = _dit(XL2, 1), _vae(2)
+    fn = partial(model_fn, model=m, num_classes=3, class_cond=True, cfg=False, w=0.)
+    kw = {"y": torch.ones(B, dtype=torch.int64, device="cuda"),
+          "rule": {"pitch_hist": dev(g["c4.target.pitch_hist"]), "note_density": dev(g["c4.target.note_density"])}}
+    cond = _c4_classifiers()
+    outs = {}
+    keep = (cf.CONCURRENT_CLASSIFIERS, gd._CONCURRENT_GRAD)
+    try:
+        for on in (False, True):
+            cf.CONCURRENT_CLASSIFIERS = on
+            gd._CONCURRENT_GRAD = on
+            res = []
+            for scg in (None, {"num_samples": n, "pitch_hist": 40., "note_density": 1.}):
+                d = _diffusion("")
+                d.t_end = 0
+                d.noise = PhiloxNoise(seed=5)
+                t = torch.full((B,), 400, dtype=torch.int64, device="cuda")
+                guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="classifier_guidance")
+                out = d.p_sample(fn, x, t, clip_denoised=False, cond_fn=cond, model_kwargs=kw, embed_model=vae if scg else None,
+                                 scale_factor=1.2465, guidance_kwargs=guid, scg_kwargs=scg)
+                res.append(out["sample"].clone())
+            torch.cuda.synchronize()
+            outs[on] = res
+    finally:
+        cf.CONCURRENT_CLASSIFIERS, gd._CONCURRENT_GRAD = keep
+    for a, b in zip(outs[False], outs[True]):
+        assert bool(torch.isfinite(a).all()) and torch.equal(a, b)

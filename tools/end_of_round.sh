@@ -26,3 +26,14 @@ except Exception as e:
     print("unreadable:", e)
 PY
 done
+# un-profiled lines of the multi-stream workloads (rocprofv3's kernel trace serialises the side streams: C3 reads ~2 ms longer under it)
+for w in c3 scg long; do
+  python bench.py --no-extras --workload $w --steps $([ $w = c3 ] && echo 20 || echo 5) --warmup 3 > gpurun_out/${R}_${w}_bench_unprofiled.json 2>/dev/null
+  python - gpurun_out/${R}_${w}_bench_unprofiled.json <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+print("unprofiled", d["config"]["workload"][:50], d["ms_per_step"], d["config"].get("repeats_ms_per_step"))
+PY
+done
+python bench.py --no-extras --workload scg --simulate-ranks 8 --steps 10 --warmup 3 > gpurun_out/${R}_scg_r8_bench_unprofiled.json 2>/dev/null
+python -c "import json; d=json.loads(open('gpurun_out/${R}_scg_r8_bench_unprofiled.json').read().strip().splitlines()[-1]); print('unprofiled R=8', d['ms_per_step'])"
