@@ -66,6 +66,30 @@ def partition_roles(B, world_size=None, rank=None):
 _orig_partition_roles = partition_roles
 
 
+# ---- window sharding of a replicated DiffCollage forward (BASELINE config 5: ONE long sample on 8 ranks)
+# The x_t forward of a search step is per-sample work; with B = 1 every rank would repeat all 7 + 6 windows of the collage.  While
+# WINDOW_SHARD is set (gaussian_diffusion._search_step_inputs, around that forward only) diff_collage's CondIndSimple evaluates the
+# windows whose index is congruent to this rank and completes the rest with ONE all-reduce of the (zero-filled) window eps: every element
+# has exactly one non-zero contributor, so the sum is exact and identical on every rank.
+WINDOW_SHARD = False
+
+
+def window_ranks():
+    """ranks a replicated collage forward can be shared out over (bench.py --simulate-ranks replaces this and window_world)"""
+    return world()[0]
+
+
+def window_world():
+    """(world size, rank) the collage worker shards its windows over -- (1, 0) outside a sharded x_t forward"""
+    return world() if WINDOW_SHARD else (1, 0)
+
+
+def reduce_windows(t):
+    """sum over the ranks, in place: ONE collective per collage forward"""
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
 PER_SAMPLE_VECTORS = ("y", "t", "timesteps")      # the only 1-D tensors that carry one entry per sample
 
 

@@ -539,6 +539,22 @@ def test_eight_rank_scg_bench_control_flow_on_one_device():
     assert line["config"]["same_winners_on_every_rank"] is True, line
 
 
+def test_eight_rank_long_sequence_bench_control_flow_on_one_device():
+    """BASELINE config 5's topology: ONE 4 x 512 x 16 sample, n = 16 candidates over eight ranks.  The x_t forward has no rows to share
+    out, so the linear collage shares out its 7 + 6 windows (batch_shard.WINDOW_SHARD, one all-reduce of the window eps); candidates two
+    per rank, per-segment winners from one all-gather.  Eight processes on this one device over gloo (plumbing, never a measurement):
+    every rank must pick the same per-segment winners."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RGM_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-extras", "--workload", "long", "--steps", "1",
+                          "--warmup", "1", "--repeats", "1"], capture_output=True, text=True, timeout=2400, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and "PLUMBING" in line["data"]
+    assert line["config"]["same_winners_on_every_rank"] is True, line
+
+
 def test_two_gpu_scg_bench_runs_over_rccl_when_the_box_has_two_gpus():
     """Multi-GPU readiness: on a box with >= 2 GPUs this runs the sharded SCG bench over RCCL (bench.py spawns its own ranks) and
     requires the same winners on every rank; on the 1-GPU boxes of this round it is skipped -- the only test that may skip."""
