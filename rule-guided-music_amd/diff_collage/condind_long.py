@@ -39,9 +39,9 @@ class CondIndSimple(SimpleWork):
             yy = None if y is None else y.repeat_interleave(n)
             tt = scalar_t.repeat_interleave(n)
             keep = th.arange(Bn, device=long_x.device).view(-1, n)[:, :n - 1].reshape(-1)
-            mine_f = th.arange(min(r, Bn), Bn, R, device=long_x.device)
-            first_h = min((r - Bn) % R, keep.numel())                          # halves continue the numbering behind the full windows
-            mine_h = keep[th.arange(first_h, keep.numel(), R, device=long_x.device)]
+            rf, rh = batch_shard.window_share(Bn, keep.numel(), R, r)        # halves continue the numbering behind the full windows
+            mine_f = th.tensor(list(rf), dtype=th.long, device=long_x.device)
+            mine_h = keep[th.tensor(list(rh), dtype=th.long, device=long_x.device)]
             buf = th.zeros(Bn * xs[0].numel() + Bn * halves[0].numel(), dtype=th.float32, device=long_x.device)
             full_eps = buf[:Bn * xs[0].numel()].view(xs.shape)
             half_eps = buf[Bn * xs[0].numel():].view(halves.shape)

@@ -84,6 +84,13 @@ def window_world():
     return world() if WINDOW_SHARD else (1, 0)
 
 
+def window_share(n_full, n_half, world_size, rank):
+    """This rank's share of the window forwards of one collage evaluation: item i of the list [n_full full windows | n_half half windows]
+    goes to rank i % world_size.  Returns (indices into the full windows, indices into the half windows) as range objects."""
+    first_h = min((rank - n_full) % world_size, n_half)
+    return range(min(rank, n_full), n_full, world_size), range(first_h, n_half, world_size)
+
+
 def reduce_windows(t):
     """sum over the ranks, in place: ONE collective per collage forward"""
     dist.all_reduce(t, op=dist.ReduceOp.SUM)

@@ -541,3 +541,23 @@ def test_cfg_sample_roll_all_gather_two_ranks_gloo():
         assert vals == [0, 0, 0, 1, 1, 1, 10, 10, 10, 11]            # round 0: rank 0's batch, rank 1's batch; round 1 likewise; cut at 10
         assert idx == [0, 1, 2, 0, 1, 2, 0, 1, 2, 0]
         assert lab == [5, 5, 5, 6, 6, 6, 5, 5, 5, 6]
+
+
+def test_role_split_and_window_share_rules():
+    """rgm/batch_shard.py, the two round-4 rules of a search step's per-sample forwards: with at least twice as many ranks as samples the eps
+    rows and the guidance-gradient rows go to different ranks (partition_roles); with ONE sample the collage's window forwards are shared
+    out, every window to exactly one rank (window_share)."""
+    from rgm import batch_shard as bs
+    assert [bs.partition_roles(4, 8, r) for r in range(8)] == [(0, 0), (1, 0), (2, 0), (3, 0), (0, 1), (1, 1), (2, 1), (3, 1)]
+    assert [bs.partition_roles(2, 8, r) for r in range(8)] == [(0, 0), (1, 0), (0, 1), (1, 1), (0, 0), (1, 0), (0, 1), (1, 1)]
+    assert bs.partition_roles(4, 4, 0) is None and bs.partition_roles(3, 8, 0) is None and bs.partition_roles(4, 1, 0) is None
+    for n_full, n_half in ((7, 6), (3, 2), (1, 0), (14, 12)):
+        for R in (1, 2, 3, 4, 8, 16, 32):
+            full, half = [], []
+            for r in range(R):
+                f, h = bs.window_share(n_full, n_half, R, r)
+                full += list(f)
+                half += list(h)
+                assert abs((len(f) + len(h)) - (n_full + n_half) / R) < 1.0 + 1e-9          # balanced to within one window
+            assert sorted(full) == list(range(n_full)) and sorted(half) == list(range(n_half)), (n_full, n_half, R)
+    assert bs.window_world() == (1, 0) and bs.WINDOW_SHARD is False
