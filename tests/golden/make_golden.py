@@ -421,6 +421,7 @@ FIXTURE_SEEDS = {
     "next2": {"dpsscg.noise_seed": 1910, "dpsscg_off.noise_seed": 2410},
     "round3": {"lsig.seed": 21},
     "round4": {"c4.noise_seed": 4102, "c4.x_seed": 4101, "c5.w_seed": 4201, "prevx_lr.seed": 21, "xl28_b32.x_seed": 4001},
+    "round4b": {"c2.noise_seed": 4402, "c2.x_seed": 4401, "c3.noise_seed": 4302, "c3.x_seed": 4301},
     "seg": {"noise_seed": 1451},
     "steps2": {"circ.noise_seed": 1415, "dcg.noise_seed": 1411, "dscg.noise_seed": 1412, "dscgc.noise_seed": 1413},
     "vae_decoder": {"seed": 2},
@@ -1101,6 +1102,62 @@ def g_round4(vae):
     save("round4", **out)
 
 
+def g_round4b():
+    """The remaining BASELINE config sizes, directly from the reference (no chaining through this implementation's small batches):
+    (e) ONE classifier-guided DDPM step of config[2] at its batch: B = 32 on the '250' chain, unconditional DiTRotary_XL_8 (depth 28), the
+        note-density DiTRotary-S/8-cls (depth 12) with grad_nn_zt_mse x 10 shifting the posterior mean (condition_mean, :376-392);
+    (f) ONE DDIM step (eta = 1) of config[1] at its batch: B = 16 on the 'ddim50' chain, the same unconditional network."""
+    print("[round4b: C3-size classifier-guided step (B=32), C2-size DDIM step (B=16), both XL-28 unconditional]")
+    from functools import partial
+    from types import SimpleNamespace
+    sk = FIXTURE_SEEDS["round4b"]
+    out = {}
+    m, _ = ref_dit(dict(XL28, num_classes=0), 1, final_std=0.3 / 1152 ** 0.5)
+    mf = ref_model_fn(m, 0, False)
+    cm, _ = ref_cls(CLS, 3)
+    # ---- (e)
+    t0 = time.time()
+    B = 32
+    x = np.random.RandomState(sk["c3.x_seed"]).randn(B, 4, 128, 16).astype(F32)
+    nz = np.random.RandomState(sk["c3.noise_seed"]).randn(B, 4, 128, 16).astype(F32)
+    tgt = np.tile(np.array([3.] * 16, dtype=F32), (B, 1))
+    tgt[:, ::3] = 5.                                             # not one flat target: the gradient differs along the windows
+    cond = partial(rcf.composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[cm], rule_names=["note_density"])
+    d = make_diffusion("250")
+    d.t_end = 0
+    t = np.random.RandomState(sk["c3.x_seed"] + 1).randint(1, 250, size=B).astype(np.int64)     # per-row timesteps of the respaced chain
+    NQ.push(nz)
+    r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, cond_fn=cond,
+                   model_kwargs={"rule": {"note_density": torch.from_numpy(tgt)}},
+                   guidance_kwargs=SimpleNamespace(schedule=False, method="classifier_guidance"))
+    NQ.q.clear()
+    print(f"    C3 step: {time.time() - t0:.0f} s; |sample| max {r['sample'].abs().max().item():.3f}")
+    out.update({"c3.x_seed": np.array(sk["c3.x_seed"]), "c3.noise_seed": np.array(sk["c3.noise_seed"]), "c3.t": t, "c3.target": tgt,
+                "c3.sample": r["sample"].detach().numpy(), "c3.pred_xstart": r["pred_xstart"].detach().numpy()})
+    # the same step without the classifier: how far the guidance moved the sample (the test's resolution check)
+    NQ.push(nz)
+    r0 = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, model_kwargs={})
+    NQ.q.clear()
+    shift = (r["sample"] - r0["sample"]).abs().amax(dim=(1, 2, 3)).numpy()
+    print(f"    guidance shift per row: min {shift.min():.4f} max {shift.max():.4f}")
+    out["c3.guidance_shift"] = shift.astype(F32)
+    # ---- (f)
+    t0 = time.time()
+    B = 16
+    x = np.random.RandomState(sk["c2.x_seed"]).randn(B, 4, 128, 16).astype(F32)
+    nz = np.random.RandomState(sk["c2.noise_seed"]).randn(B, 4, 128, 16).astype(F32)
+    d = make_diffusion("ddim50")
+    d.t_end = 0
+    t = np.full((B,), 31, dtype=np.int64)
+    NQ.push(nz)
+    r = d.ddim_sample(mf, torch.from_numpy(x), torch.from_numpy(t), clip_denoised=False, model_kwargs={}, eta=1.0)
+    NQ.q.clear()
+    print(f"    C2 step: {time.time() - t0:.0f} s; |sample| max {r['sample'].abs().max().item():.3f}")
+    out.update({"c2.x_seed": np.array(sk["c2.x_seed"]), "c2.noise_seed": np.array(sk["c2.noise_seed"]), "c2.t": t,
+                "c2.sample": r["sample"].detach().numpy(), "c2.pred_xstart": r["pred_xstart"].detach().numpy()})
+    save("round4b", **out)
+
+
 def g_configs():
     """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
     checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
@@ -1608,7 +1665,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "midi_rolls"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "round4b", "midi_rolls"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1643,6 +1700,8 @@ if __name__ == "__main__":
         g_learned()
     if "round4" in which:
         g_round4(vae)
+    if "round4b" in which:
+        g_round4b()
     if "configs" in which:
         g_configs()
     if "collage" in which:

@@ -1,7 +1,8 @@
 """-m gpu: round-4 pins against tests/golden/round4.npz (make_golden.py round4, generated from the imported reference): values the
 REFERENCE computes at the sizes the configs run -- the XL-28 forward at B = 32, one guided step of cond_table/all/scg_classifier_all.yml
 (classifier guidance AND SCG, B = 4, n = 16, 512 decoder squares), condind_long's 13-window collage eps at XL-28 -- and
-ModelMeanType.PREVIOUS_X together with learned-range variances."""
+ModelMeanType.PREVIOUS_X together with learned-range variances; and against round4b.npz: one classifier-guided step of config[2] at B = 32
+and one DDIM step of config[1] at B = 16."""
 from functools import partial
 from types import SimpleNamespace
 
@@ -18,11 +19,12 @@ F32 = np.float32
 XL28 = dict(depth=28, hidden=1152, heads=16, patch=8, in_ch=4, out_ch=4, num_classes=3)
 
 
-def _xl28():
+def _xl28(num_classes=3):
     from gpu_util import load_module
     from guided_diffusion.dit import DiTRotary
-    m = DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=1152, depth=28, num_heads=16, num_classes=3, learn_sigma=False)
-    return load_module(m, synth.dit_state_dict(1, final_std=0.3 / 1152 ** 0.5, device="cuda", **XL28))
+    m = DiTRotary(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=1152, depth=28, num_heads=16, num_classes=num_classes,
+                  learn_sigma=False)
+    return load_module(m, synth.dit_state_dict(1, final_std=0.3 / 1152 ** 0.5, device="cuda", **dict(XL28, num_classes=num_classes)))
 
 
 @pytest.mark.parametrize("tag,clip,use_dfn", [("prevx_lr_clip", True, False), ("prevx_lr_dfn", False, True)])
@@ -127,6 +129,55 @@ def test_c4_step_with_classifiers_and_scg_against_the_reference(precision):
     assert np.array_equal(d.last_scg["max_ind"].cpu().numpy().reshape(-1), g["c4.max_ind"])
     assert rel(out["sample"].cpu().numpy(), g["c4.sample"]) < (5e-5 if precision == "fp32" else 2e-4)
     assert rel(out["pred_xstart"].cpu().numpy(), g["c4.pred_xstart"]) < (5e-5 if precision == "fp32" else 3e-4)
+
+
+def test_c3_step_at_batch_32_against_the_reference(precision):
+    """ONE classifier-guided DDPM step of BASELINE config[2] at its batch, against the reference's own run of it (round4b.npz): B = 32 on
+    the '250' chain with a different timestep per row, unconditional XL-28, the note-density DiTRotary-S/8-cls (depth 12) through
+    grad_nn_zt_mse x 10.  The error must stay far below what the guidance itself moved (stored per row by the generator)."""
+    from gpu_util import dev, load_module, rel
+    from guided_diffusion.condition_functions import composite_nn_zt, model_fn
+    from guided_diffusion.dit import DiTRotaryClassifier
+    from test_gpu_fullsize import _diffusion
+    g = load_golden("round4b")
+    B = 32
+    x = np.random.RandomState(int(g["c3.x_seed"])).randn(B, 4, 128, 16).astype(F32)
+    nz = np.random.RandomState(int(g["c3.noise_seed"])).randn(B, 4, 128, 16).astype(F32)
+    arch = dict(depth=12, hidden=384, heads=6, patch=8, in_ch=4, classifier=True, cls_classes=16)
+    clf = load_module(DiTRotaryClassifier(input_size=[128, 16], patch_size=8, in_channels=4, hidden_size=384, depth=12, num_heads=6,
+                                          num_classes=16), synth.dit_state_dict(3, **arch))
+    cond = partial(composite_nn_zt, fns=["grad_nn_zt_mse"], classifier_scales=[10.], classifiers=[clf], rule_names=["note_density"])
+    fn = partial(model_fn, model=_xl28(0), num_classes=0, class_cond=False, cfg=False, w=0.)
+    d = _diffusion("250")
+    d.t_end = 0
+    _inject(d, nz)
+    out = d.p_sample(fn, dev(x), dev(g["c3.t"]), clip_denoised=False, cond_fn=cond, model_kwargs={"rule": {"note_density": dev(g["c3.target"])}},
+                     guidance_kwargs=SimpleNamespace(schedule=False, method="classifier_guidance"))
+    a, b = out["sample"].cpu().numpy(), g["c3.sample"]
+    assert rel(a, b) < (5e-5 if precision == "fp32" else 2e-4)
+    assert rel(out["pred_xstart"].cpu().numpy(), g["c3.pred_xstart"]) < (5e-5 if precision == "fp32" else 3e-4)
+    # per row: the deviation is a small fraction of the shift the classifier gradient produced in the reference
+    dev_row = np.abs(a - b).reshape(B, -1).max(1)
+    assert (dev_row < 0.05 * g["c3.guidance_shift"] + 2e-5).all(), (dev_row / g["c3.guidance_shift"]).max()
+
+
+def test_c2_ddim_step_at_batch_16_against_the_reference(precision):
+    """ONE DDIM step (eta = 1, 'ddim50' chain) of BASELINE config[1] at its batch of 16, unconditional XL-28, against the reference's
+    ddim_sample on the same seeded x_t and noise -- the step bench.py times, in the arithmetic it times it in."""
+    from gpu_util import dev, rel
+    from guided_diffusion.condition_functions import model_fn
+    from test_gpu_fullsize import _diffusion
+    g = load_golden("round4b")
+    B = 16
+    x = np.random.RandomState(int(g["c2.x_seed"])).randn(B, 4, 128, 16).astype(F32)
+    nz = np.random.RandomState(int(g["c2.noise_seed"])).randn(B, 4, 128, 16).astype(F32)
+    fn = partial(model_fn, model=_xl28(0), num_classes=0, class_cond=False, cfg=False, w=0.)
+    d = _diffusion("ddim50")
+    d.t_end = 0
+    _inject(d, nz)
+    out = d.ddim_sample(fn, dev(x), dev(g["c2.t"]), clip_denoised=False, model_kwargs={}, eta=1.0)
+    assert rel(out["sample"].cpu().numpy(), g["c2.sample"]) < (5e-5 if precision == "fp32" else 2e-4)
+    assert rel(out["pred_xstart"].cpu().numpy(), g["c2.pred_xstart"]) < (5e-5 if precision == "fp32" else 3e-4)
 
 
 def test_side_stream_classifiers_and_gradient_give_the_same_bits(precision):
