@@ -184,6 +184,9 @@ struct GemmParams {
 int gemm_launch(const GemmParams& p, hipStream_t stream);
 // gemm2.hip: the same contraction on operands already in split-row format (K bf16 hi | K bf16 lo per row)
 int gemm2_launch(const GemmParams& p, hipStream_t stream);
+// gemm144.hip: 128x144 tiles (16x16x32 MFMAs) for N % 144 == 0 -- tile 81 of gemm2_launch
+bool gemm144_supports(const GemmParams& p);
+int gemm144_launch(const GemmParams& p, hipStream_t stream);
 constexpr size_t GEMM_SK_FLAG_BYTES = 4096;   // reserved head of the scratch (the split-K partial sums start behind it)
 // scratch a caller must provide for GEMMs of up to M rows and N columns to use the deterministic split-K
 size_t gemm2_scratch_bytes(int M, int N);

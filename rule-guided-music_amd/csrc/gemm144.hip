@@ -1,0 +1,284 @@
+// gemm144.hip -- pre-split GEMM on 128 x 144 output tiles (16x16x32 MFMAs): the tile for grids the 32-column-granular kernels of
+// gemm2.hip cannot balance.
+//
+// Every N of DiTRotary_XL_8 (1152, 3456, 4608) is a multiple of 144 = 1152 / 8, and M = 256 B rows: fc1 at B = 4 is 8 x 32 = 256 tiles
+// -- one per CU -- where 128x128 gives 288 (32 CUs carry two, the launch takes two tile-times) and 128x64 576 (0.75 of the 768 slots);
+// proj at B = 16 is 32 x 8 = 256 where 128x64 gives 576 latency-bound tiles at 0.24 of the MFMA peak.  144 columns are nine 16-wide
+// MFMA tiles, so the kernel multiplies with v_mfma_f32_16x16x32_bf16 (same rate as 32x32x16, K = 32 = one 128-B split-row line per
+// instruction): a wave owns 32 rows x 144 columns = 2 x 9 accumulator tiles (72 registers).
+//
+// Operands: A (M, K) and B (N, K) in split-row format ([32 hi | 32 lo] per 128-B line, common.h), C = A . B^T; the same GemmParams
+// epilogue subset the DiT forward uses (bias, SiLU / GELU, split output, gate, residual, K slices as a batch).  Structure = gemm2.hip's
+// loader/consumer split (PIPE 4): waves 4-7 issue all LDS-DMA (36 KiB stages: 128 A rows, 144 B rows, 16 rows of padding so that
+// every loader wave owns 9 pieces), waves 0-3 multiply from registers and fetch the next tile's 22 fragments between the MFMAs of the
+// last two thirds of a tile; one barrier per K-tile.  The product is computed transposed (the B fragment is the MFMA's A operand): a lane
+// then holds FOUR CONSECUTIVE COLUMNS of one output row and the epilogue reads bias / gate / residual and writes C 16 B per lane
+// straight from the accumulators -- no pass through LDS.  Term order per accumulator: al*bh, ah*bl, ah*bh (as everywhere).
+#include "common.h"
+
+namespace rgm {
+namespace {
+
+typedef split_t bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifdef RGM_SPLIT_F16
+#define RGM_MFMA_SPLIT_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#else
+#define RGM_MFMA_SPLIT_16x16x32 __builtin_amdgcn_mfma_f32_16x16x32_bf16
+#endif
+
+__device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {   // 16 B per lane, LDS destination = wave-uniform base + lane*16
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+constexpr int BM = 128, BN = 144, PAD = 16;
+constexpr int ROWS = BM + BN + PAD;           // LDS rows per stage
+constexpr int STAGE = ROWS * 128;             // 36 KiB
+constexpr int LSEG = ROWS / 8 / 4;            // 1-KiB pieces per loader wave and K-tile: 9
+constexpr int TM = 2, TN = 9;                 // 16x16 accumulator tiles per consumer wave (32 rows x 144 columns)
+
+template <int NSTAGE>
+__global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m, int tiles_n) {
+  extern __shared__ __attribute__((aligned(16))) char ring[];
+  const int z = blockIdx.z;
+  // XCD-contiguous raster, row tiles fastest: an XCD's tiles are a few column panels of B (weights: read once, by one L2) x all row tiles
+  const int bid = blockIdx.x, nb = tiles_m * tiles_n;
+  const int xcd = bid & 7, loc = bid >> 3, q = nb >> 3, r = nb & 7;
+  const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  const int m0 = (sid % tiles_m) * BM, n0 = (sid / tiles_m) * BN;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = tid & 63;
+  const int KT = p.K >> 5;
+  const char* Ab = reinterpret_cast<const char*>(p.A + (long long)z * p.sA);
+  const char* Bb = reinterpret_cast<const char*>(p.B + (long long)z * p.sB);
+
+  if (wave >= 4) {
+    // ---- loader waves.  Piece s of a stage = LDS rows 8s..8s+7; lane = (row r8, physical 16-B chunk pc) fetches logical chunk
+    // pc ^ ((row >> 1) & 7) of its row's line (the read-side swizzle of the fragment reads, applied on the source side)
+    const int lw = wave - 4, r8 = lane >> 3;
+    const char* src[LSEG];
+    int inc[LSEG];
+#pragma unroll
+    for (int i = 0; i < LSEG; ++i) {
+      const int row_l = (lw + i * 4) * 8 + r8;
+      const int cs = ((lane & 7) ^ ((row_l >> 1) & 7)) << 4;
+      const bool isA = row_l < BM;
+      const int row = isA ? m0 + row_l : n0 + row_l - BM;
+      const bool ok = isA ? row < p.M : (row_l < BM + BN && row < p.N);
+      src[i] = ok ? (isA ? Ab + (long long)row * p.lda * 4 : Bb + (long long)row * p.ldb * 4) + cs : zero_page + cs;
+      inc[i] = ok ? 128 : 0;
+    }
+    auto issue_tile = [&](char* dst) {
+      static_for<0, LSEG>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        dma16(src[i], dst + (lw + i * 4) * 1024);
+        src[i] += inc[i];
+      });
+    };
+    auto wait_flying = [&](int tiles) {                 // wave-uniform: at most `tiles` of the newest tiles may still fly
+      static_for<0, NSTAGE - 1>([&](auto c) {
+        if (tiles == decltype(c)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(c)::value * LSEG) : "memory");
+      });
+    };
+    static_for<0, NSTAGE - 1>([&](auto c) {
+      if (decltype(c)::value < KT) issue_tile(ring + decltype(c)::value * STAGE);
+    });
+    wait_flying(min(NSTAGE - 2, KT - 1));
+    __builtin_amdgcn_s_barrier();                       // barrier P: tile 0 is in LDS
+    int s2 = NSTAGE - 1;
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+      if (kt + NSTAGE - 1 < KT) issue_tile(ring + s2 * STAGE);   // into tile kt-1's stage: every consumer read it before barrier kt-1
+      wait_flying(min(NSTAGE - 2, KT - 2 - kt));
+      __builtin_amdgcn_s_barrier();                     // barrier kt: tile kt+1 is in LDS
+      s2 = s2 == NSTAGE - 1 ? 0 : s2 + 1;
+    }
+    return;
+  }
+
+  // ---- consumer waves
+  const int l15 = lane & 15, kb = lane >> 4;
+  const int rq = (l15 >> 1) & 7;                        // tile row offsets are multiples of 16
+  const int arow0 = wave * 32;
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Fragments of one K-tile: row l15 of the 16-row tile, k = 8 kb .. 8 kb + 7.  Term t of an accumulator (t-major MFMA order) multiplies
+  //   t = 0: a.lo x b.hi     t = 1: a.hi x b.lo     t = 2: a.hi x b.hi
+  // so the lo halves are dead after their term and are overwritten with the NEXT tile's while the tile is still being multiplied; only
+  // the hi halves (live to the end) are double-buffered: 72 + 2 x 44 + 44 = 204 registers (a second full set does not fit the 256 of
+  // two waves per SIMD).
+  struct Half {
+    bf16x8 a[TM], b[TN];
+  };
+  constexpr int NT = TM * TN;                           // 18 MFMAs per term
+  auto rd = [&](bf16x8& dst, const char* st, int row, int lo) {
+    dst = *reinterpret_cast<const bf16x8*>(st + row * 128 + (((4 * lo + kb) ^ rq) << 4));
+  };
+  const int ar = arow0 + l15, br = BM + l15;
+  // term T of the tile whose halves are (hi, lo); the reads riding on its MFMAs (from stage `nst`, the next tile):
+  //   T = 1: next a.lo (2), then the next tile's hi halves (2 + 9) into `nhi`       T = 2: next b.lo (9)
+  auto term = [&](auto tc, const Half& hi, Half& lo, Half& nhi, const char* nst, auto prec) {
+    constexpr int T = decltype(tc)::value;
+    constexpr bool PRE = decltype(prec)::value != 0;
+    static_for<0, NT>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      constexpr int im = m / TN, in = m % TN;
+      // transposed product: D[n][m] -> the lane holds columns 4 kb .. 4 kb + 3 of row l15
+      if constexpr (T == 0) acc[im][in] = RGM_MFMA_SPLIT_16x16x32(hi.b[in], lo.a[im], acc[im][in], 0, 0, 0);
+      if constexpr (T == 1) acc[im][in] = RGM_MFMA_SPLIT_16x16x32(lo.b[in], hi.a[im], acc[im][in], 0, 0, 0);
+      if constexpr (T == 2) acc[im][in] = RGM_MFMA_SPLIT_16x16x32(hi.b[in], hi.a[im], acc[im][in], 0, 0, 0);
+      if constexpr (PRE && T == 1) {
+        if constexpr (m < TM) rd(lo.a[m], nst, ar + m * 16, 1);
+        else if constexpr (m < 2 * TM) rd(nhi.a[m - TM], nst, ar + (m - TM) * 16, 0);
+        else if constexpr (m < 2 * TM + TN) rd(nhi.b[m - 2 * TM], nst, br + (m - 2 * TM) * 16, 0);
+      }
+      if constexpr (PRE && T == 2) {
+        // b.lo[in] is free once the LAST row tile's term-1 MFMA has used it: all of term 1 is behind us
+        if constexpr (m < TN) rd(lo.b[m], nst, br + m * 16, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  static_assert(2 * TM + TN <= NT && TN <= NT, "the next tile's reads fit between the MFMAs of terms 1 and 2");
+  Half h0, h1, lo;
+  __builtin_amdgcn_s_barrier();                         // barrier P (loaders: tile 0 landed)
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    rd(h0.a[i], ring, ar + i * 16, 0);
+    rd(lo.a[i], ring, ar + i * 16, 1);
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+    rd(h0.b[i], ring, br + i * 16, 0);
+    rd(lo.b[i], ring, br + i * 16, 1);
+  }
+  int s1 = 1;
+  // a tile with a successor (its fragments are fetched on the way) / the last tile.  Kept apart -- and the loop below peeled -- so that no
+  // path carries a stale fragment set to a merge point: the register allocator would keep it alive (346 registers instead of ~210)
+  auto iter_more = [&](Half& cur, Half& nxt) {
+    term(I0{}, cur, lo, nxt, nullptr, I0{});
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // tile kt+1 in LDS; every consumer read tile kt during tile kt-1
+    __builtin_amdgcn_sched_barrier(0);
+    const char* nst = ring + s1 * STAGE;
+    term(I1{}, cur, lo, nxt, nst, I1{});
+    term(I2{}, cur, lo, nxt, nst, I1{});
+    s1 = s1 == NSTAGE - 1 ? 0 : s1 + 1;
+  };
+  auto iter_last = [&](Half& cur) {
+    term(I0{}, cur, lo, cur, nullptr, I0{});
+    term(I1{}, cur, lo, cur, nullptr, I0{});
+    term(I2{}, cur, lo, cur, nullptr, I0{});
+  };
+  int kt = 0;
+  for (; kt + 2 < KT; kt += 2) {
+    iter_more(h0, h1);
+    iter_more(h1, h0);
+  }
+  if (KT - kt == 2) {
+    iter_more(h0, h1);
+    iter_last(h1);
+  } else {
+    iter_last(h0);
+  }
+
+  // ---- epilogue, straight from the accumulators: acc[im][in][e] = C[m0 + arow0 + 16 im + l15][n0 + 16 in + 4 kb + e]
+  float* __restrict__ Cb = p.C + (long long)z * p.sC;
+  const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
+  const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
+  const int colb = n0 + 4 * kb;
+  float4 bv[TN];
+#pragma unroll
+  for (int in = 0; in < TN; ++in) bv[in] = biasb ? *reinterpret_cast<const float4*>(biasb + colb + in * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int im = 0; im < TM; ++im) {
+    const int row = m0 + arow0 + im * 16 + l15;
+    const bool ok = row < p.M;
+    float4 g4[TN], r4[TN];
+    const bool reads = (p.gate || resb) && ok;
+    if (reads) {
+      const float* gp = p.gate ? p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + colb : nullptr;
+      const float* rp = resb ? resb + (long long)row * p.ldres + colb : nullptr;
+#pragma unroll
+      for (int in = 0; in < TN; ++in) {
+        g4[in] = gp ? *reinterpret_cast<const float4*>(gp + in * 16) : make_float4(1.f, 1.f, 1.f, 1.f);
+        r4[in] = rp ? *reinterpret_cast<const float4*>(rp + in * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int in = 0; in < TN; ++in) {
+      const int col = colb + in * 16;
+      float v[4] = {acc[im][in][0] * p.alpha + bv[in].x, acc[im][in][1] * p.alpha + bv[in].y, acc[im][in][2] * p.alpha + bv[in].z,
+                    acc[im][in][3] * p.alpha + bv[in].w};
+      if (p.act == 1) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+      } else if (p.act == 2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_tanh_fast_f(v[e]);
+      }
+      if (reads) {
+        v[0] = v[0] * g4[in].x + r4[in].x; v[1] = v[1] * g4[in].y + r4[in].y;
+        v[2] = v[2] * g4[in].z + r4[in].z; v[3] = v[3] * g4[in].w + r4[in].w;
+      }
+      if (!ok) continue;
+      if (p.out_split) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          hi[e] = (split_t)v[e];
+          lo[e] = (split_t)(v[e] - (float)hi[e]);
+        }
+        split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
+        *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
+        *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
+      } else {
+        *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  }
+}
+
+char* g_zero144 = nullptr;
+}  // namespace
+
+// shapes and epilogues this kernel carries (gemm2_launch asks before it picks tile 81)
+bool gemm144_supports(const GemmParams& p) {
+  if (p.aload || p.stats || p.act >= 3 || p.aux || p.N % BN != 0 || p.K % 32 != 0 || p.K < 64) return false;
+  if (((p.N | p.ldc | p.ldres | p.gate_ld) & 3) != 0) return false;
+  const uintptr_t al = (uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate;
+  if ((al & 15) != 0 || ((p.sC | p.sRes | p.sBias) & 3) != 0) return false;
+  if (p.gate && p.rows_per_gate <= 0) return false;
+  return true;
+}
+
+int gemm144_launch(const GemmParams& p, hipStream_t s) {
+  RGM_REQUIRE(gemm144_supports(p), "gemm144: unsupported call (N=%d must be a multiple of 144; dense operands; act 0-2)", p.N);
+  if (!g_zero144) {
+    RGM_CHECK_HIP(hipMalloc(&g_zero144, 4096));
+    RGM_CHECK_HIP(hipMemset(g_zero144, 0, 4096));
+  }
+  constexpr int NSTAGE = 4;      // 144 KiB of the 160: one workgroup per CU (profiler id 135)
+  const int tm = cdiv(p.M, BM), tn = p.N / BN;
+  const size_t lds = (size_t)NSTAGE * STAGE;
+  auto k = gemm144_kernel<NSTAGE>;
+  static bool attr = false;
+  if (!attr) {
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr = true;
+  }
+  const int pi = gemm2_prof_begin(135, 2.0 * p.M * (double)p.N * p.K * p.batch, s);
+  hipLaunchKernelGGL(k, dim3((unsigned)(tm * tn), 1, (unsigned)p.batch), dim3(512), lds, s, p, (const char*)g_zero144, tm, tn);
+  gemm2_prof_end(pi, s);
+  RGM_LAUNCH_CHECK();
+  return RGM_OK;
+}
+}  // namespace rgm

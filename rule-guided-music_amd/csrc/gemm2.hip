@@ -1439,6 +1439,7 @@ static int splitk_factor(const GemmParams& p) {
   return best;
 }
 
+static int g_t144 = getenv("RGM_T144") ? atoi(getenv("RGM_T144")) : 9;   // which grids take the 128x144 tiles (bit mask, gemm2_launch)
 static int g_fuse_reduce_ln = getenv("RGM_FUSE_REDUCE_LN") ? atoi(getenv("RGM_FUSE_REDUCE_LN")) : 1;
 static long long g_fused_reduce_ln_launches = 0;
 
@@ -1547,7 +1548,37 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   // this kernel and the leftover columns through the heuristic again (fc1 at B = 16: 16 x 16 tiles + 512 columns on 128x64 tiles).
   int S = 1;
   int sk_tile = 44;
-  const bool big_ok = p.tile == 0 && g_big_tiles && !p.aload && p.batch == 1 && !p.stats && p.act < 3 && !p.aux && p.M >= 2048 &&
+  // ---- 128x144 tiles (gemm144.hip, tile 81) at the samplers' small batches.  g_t144 bit 1: a grid that is ONE full round of them (224-256
+  // tiles) where 128x128 tiles give more than a round -- fc1 at B = 4: 8 x 32 = 256 against 288, 43.7 -> 33.8 us in isolation (cold weights,
+  // tools/gemm_sweep.py 100 181), forward 5.73 -> 5.47 ms; bit 8: K slices ON these tiles where even they leave most CUs idle -- fc2 at
+  // B = 2 .. 4: 48-64 tiles x 4 slices, forward 4.39 -> 4.30 ms at B = 2, 5.47 -> 5.32 at B = 4.  Measured and NOT taken (same sweeps,
+  // in the forward): fc2 at B = 16 unsliced (one round of 256 tiles, 108 against 128 us in isolation -- but the K-slice path's reduce also
+  // writes the next LayerNorm: forward 12.17 -> 12.74 ms), proj at B = 16 (12.17 -> 12.08 and 13.11 -> 13.19 on two boxes: noise),
+  // fc1 at B = 8 as two rounds (no change), fc2 at B = 8 as 128 tiles x 2 slices (8.18 -> 8.43 ms).
+  if (p.tile == 0 && g_t144 && p.batch == 1 && p.M < 2048 && gemm144_supports(p)) {
+    const long long t144 = (long long)cdiv(p.M, 128) * (p.N / 144);
+    const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    const int KT = p.K >> 5;
+    if ((g_t144 & 1) && t144 >= 224 && t144 <= 256 && t128 > 256) {
+      GemmParams q = p;
+      q.tile = 81;
+      q.ln_out = nullptr;
+      return gemm2_launch(q, s);
+    }
+    if ((g_t144 & 8) && p.sk_ws && t144 <= 64 && KT >= 72 && p.act == 0 && !p.out_split) {
+      int best = 1;
+      for (int c = 2; c <= 8; ++c) {
+        if (KT % c || KT / c < 18 || t144 * c > 256) continue;
+        if ((size_t)c * p.M * p.N * sizeof(float) + GEMM_SK_FLAG_BYTES > p.sk_ws_bytes) continue;
+        best = c;
+      }
+      if (best > 1 && t144 * best >= 192) {
+        S = best;
+        sk_tile = 81;
+      }
+    }
+  }
+  const bool big_ok = S == 1 && p.tile == 0 && g_big_tiles && !p.aload && p.batch == 1 && !p.stats && p.act < 3 && !p.aux && p.M >= 2048 &&
                       (!p.gate || p.rows_per_gate >= 32) &&     // the big tiles' gate / residual epilogue: at most two gate rows per 32-row slab
 
                       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 &&
@@ -1742,6 +1773,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     // one wave per SIMD, 128x128 per wave (PIPE == 5)
     case 71: return launch2<256, 256, 2, 2, 2, 5>(p, s, 71);   // 128 KB: 1 per CU, 512 registers
     case 73: return launch2<128, 256, 1, 4, 2, 5>(p, s, 73);   // 96 KB: 128x64 wave tiles, for M of a few thousand rows (B = 8: the shapes B = 16 has at 256 rows)
+    case 81: return gemm144_launch(p, s);                     // gemm144.hip: 128x144 tiles on 16x16x32 MFMAs (N % 144 == 0)
     case 72: return launch2<512, 128, 4, 1, 2, 5>(p, s, 72);   // 160 KB (all of the LDS): the same 128x128 wave tiles for N = 128 (VAE convs at 128 channels)
     default: break;
   }

@@ -108,6 +108,57 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
         assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, 2304), _ref(A, W, b2, 2, 1.0, None, 1, None)) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K,T", [(1024, 4608, 1152, 256), (1000, 1152, 1152, 128), (512, 3456, 1152, 256), (768, 1152, 4608, 256),
+                                     (4096, 1152, 1152, 256)])
+def test_tile_144_kernel_epilogues_and_its_place_in_the_heuristic(M, N, K, T):
+    """csrc/gemm144.hip (tile 81: 128x144 output tiles on v_mfma_f32_16x16x32, the product computed transposed so that a lane owns four
+    consecutive columns): proj / fc2's gated in-place residual and fc1's GELU + split-row output against the fp64 product on the shapes of
+    B = 2 .. 4 (one ragged M), bit-identical run to run; and through the heuristic (tile 0) -- fc1 at B = 4 is one round of 256 of
+    these tiles, fc2 at B = 3 / 4 runs as K slices ON them -- the launch records prove the kernel took the call."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    rng = np.random.RandomState(M + N + K + 81)
+    A, B = rng.randn(M, K).astype(F32), (rng.randn(N, K) * 0.03).astype(F32)
+    bias, res = rng.randn(N).astype(F32), rng.randn(M, N).astype(F32)
+    gate = rng.randn((M + T - 1) // T, N + 64).astype(F32)
+    As, Bs, bd, gd = _split(A), _split(B), dev(bias), dev(gate)
+    need = max(int(R.lib.rgm_gemm_scratch_bytes(M, N)), 4096 + 8 * M * N * 4)
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    ws.fill_(0xAB)
+    st = R.current_stream()
+    want = _ref(A, B, bias, 0, 0.7, gate[:, :N], T, res)
+    for tile in (81, 0):
+        outs = []
+        for rep in range(2):
+            x = dev(res)
+            R.check(R.lib.rgm_prof_reset())
+            R.check(R.lib.rgm_prof_enable(1))
+            R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 0.7, R.ptr(gd), N + 64, T,
+                                             R.ptr(x), N, tile, 0, R.ptr(ws), need, st))
+            torch.cuda.synchronize()
+            R.check(R.lib.rgm_prof_enable(0))
+            n144 = _launches([135])[135]
+            outs.append(x.cpu().numpy())
+        assert np.array_equal(outs[0], outs[1])
+        assert rel(outs[0], want) < 3e-5, (tile, rel(outs[0], want))
+        if tile == 81:
+            assert n144 == 1
+        elif (M, N, K) in ((1024, 4608, 1152), (768, 1152, 4608)):
+            assert n144 == 1, n144                                   # the heuristic's choice: one round / K slices of 128x144 tiles
+    R.check(R.lib.rgm_prof_reset())
+    h = torch.zeros(M, N, device="cuda")
+    R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(h), N, M, N, K, R.ptr(bd), 2, 1.0, None, 0, 1, None, 0, 81, 1,
+                                     R.ptr(ws), need, st))
+    torch.cuda.synchronize()
+    raw = h.view(__import__("gpu_util").split_torch_dtype()).view(M, N // 32, 2, 32).float().cpu().numpy().astype(np.float64)
+    assert rel((raw[:, :, 0] + raw[:, :, 1]).reshape(M, N), _ref(A, B, bias, 2, 1.0, None, 1, None)) < 3e-5
+    # SiLU, plain output, no bias (the remaining branches of the epilogue)
+    c = torch.zeros(M, N, device="cuda")
+    R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(c), N, M, N, K, None, 1, 1.0, None, 0, 1, None, 0, 81, 0,
+                                     R.ptr(ws), need, st))
+    assert rel(c.cpu().numpy(), _ref(A, B, np.zeros(N), 1, 1.0, None, 1, None)) < 3e-5
+
+
 @pytest.mark.parametrize("M,N,K,T", [(3072, 1152, 4608, 128), (7168, 3456, 1152, 256), (3072, 4608, 1152, 128), (4096, 4608, 1152, 256),
                                      (4096, 1152, 4608, 256), (16384, 1152, 1152, 256), (7168, 1152, 4608, 256), (2048 + 256, 3456, 1152, 256),
                                      (2048, 4608, 1152, 256),      # fc1 at B = 8: 144 tiles, one partial round of the 256x256 kernel
