@@ -135,6 +135,12 @@ long long rgm_fused_reduce_ln_launches(void);
  * stream by events (still stream-ordered for the caller; capturable) while block 0 computes; 0 (default; measured equal or better) = one
  * GEMM in front of block 0. */
 int rgm_set_adaln_overlap(int on);
+/* Blocks of an eps-network forward (ref guided_diffusion/dit.py:618-634: samples are independent inside a block) as TWO half batches, the
+ * second on a side stream owned by the handle, forked from and joined to the caller's stream by events (stream-ordered for the caller):
+ * one half's kernels fill the CUs the other half's last round of one-workgroup-per-CU tiles leaves idle.  Batches of at least
+ * min_batch samples take it; 0 = never; -1 (default) = the batch sizes where a same-box sweep found it ahead (2, 5..9, 17..39, 57..).
+ * *prev (optional) receives the previous setting. */
+int rgm_set_dit_halves(int min_batch, int* prev);
 /* Deterministic split-K of the pre-split GEMM (csrc/gemm2.hip: K slices as a batch + one fixed-order reduce kernel, which for the fc2
  * of a DiT block also writes the next adaLN-LayerNorm): the scratch is caller memory like every other workspace,
  * rgm_gemm_scratch_bytes(M, N) bytes for GEMMs of up to M rows and N columns, 16-byte aligned, no initialisation.  tile 0 lets the

@@ -154,6 +154,9 @@ struct GemmParams {
   int conv_kmajor = 0;
   // tile override for experiments: 0 auto, 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 32x128
   int tile = 0;
+  // gemm2 heuristic: a launch of comparable size runs beside this one on a second stream (dit.hip: the blocks as two half batches), so a
+  // partial round of one-workgroup-per-CU tiles is not idle time -- the 256x256 kernel is taken from far fewer tiles (gemm2_launch)
+  int co_sched = 0;
   // gemm2 raster: row-tiles per column sweep of the XCD-contiguous grouped raster (0 = 8).  The one-wave-per-SIMD kernels set it to
   // ~sqrt(tiles per XCD): an XCD's tiles then form a near-square block and its L2 fetches the fewest operand panels
   int raster_group = 0;

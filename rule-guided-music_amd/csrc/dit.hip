@@ -47,6 +47,21 @@ struct Slot {
 
 static int g_adaln_overlap = getenv("RGM_ADALN_OVERLAP") ? atoi(getenv("RGM_ADALN_OVERLAP")) : 0;   // measured: no gain
 
+// The blocks of an eps-network forward as TWO half batches on two streams (rows of different samples never meet inside a block): one
+// half's kernels fill the CUs the other half's last tile round leaves idle, and their write-bound epilogues fall under the other half's
+// K loops.  g_dit_halves (rgm_set_dit_halves / RGM_DIT_HALVES): -1 = where the same-box sweep of tools/halves_exp.py found it ahead
+// (profiles/r04_halves_sweep.txt: B = 2, 5..9, 17..39 and from 57 up -- 2..8 % -- but behind at 10..14 and 40..56, and even at 16, where
+// ONE round of 256x256 tiles per GEMM leaves nothing to overlap); 0 = never; n > 0 = every batch of at least n samples.
+static int g_dit_halves = getenv("RGM_DIT_HALVES") ? atoi(getenv("RGM_DIT_HALVES")) : -1;
+static bool dit_halves_for(int N) {
+  if (g_dit_halves == 0 || N < 2) return false;
+  if (g_dit_halves > 0) return N >= g_dit_halves;
+  return N == 2 || (N >= 5 && N <= 9) || (N >= 17 && N <= 39) || N >= 57;
+}
+// where in block 0 of the first half the second half is released: 0 = with it, 1 .. 5 = behind its qkv / attention / proj / second LayerNorm /
+// fc1 (the halves then run out of phase: one's short-K GEMMs beside the other's long-K ones)
+static int g_dit_stagger = getenv("RGM_DIT_STAGGER") ? atoi(getenv("RGM_DIT_STAGGER")) : 0;
+
 struct rgm_dit {
   rgm_dit_cfg cfg{};
   int device = 0;
@@ -352,6 +367,7 @@ struct Plan {
   size_t L;
   float *tok_in, *h1, *x, *xm, *qkv, *ao, *hid, *temb, *c1, *c, *cs, *mod, *tok_out, *pool, *pooln, *z1;
   char* sk;          // split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
+  char* sk2;         // the same for the second half batch when the blocks run as two half batches on two streams
   size_t sk_bytes;
   size_t bytes;
 };
@@ -387,6 +403,7 @@ Plan make_plan(const rgm_dit* h, int N, int H, void* ws, size_t cap) {
   p.z1 = w.take((size_t)N * groups * (D / 4));
   p.sk_bytes = gemm2_scratch_bytes(p.M, 4 * (int)D);
   p.sk = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
+  p.sk2 = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
   p.bytes = w.off;
   return p;
 }
@@ -459,43 +476,93 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     return RGM_OK;
   };
   const bool v2 = rgm_get_gemm_precision() == 2;   // bf16x3 with pre-split operands: producers emit split rows, gemm2 consumes
-  // next_mod (fc2 only): shift of the NEXT block's first adaLN-LayerNorm (its scale is D further).  A K-sliced fc2 then writes that
-  // LayerNorm from its reduce kernel (GemmParams::ln_out) and *ln_done tells the loop to skip the separate launch.
-  auto lin2 = [&](const float* A, const std::string& wkey, const float* bias, float* C, int N, int K, int act, int out_split,
-                  const float* gate, const float* res, int tile, const float* next_mod = nullptr, int* ln_done = nullptr) {
-    GemmParams g;
-    g.tile = tile;
-    g.A = A; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
-    g.M = p.M; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
-    g.sk_ws = p.sk; g.sk_ws_bytes = p.sk_bytes;
-    if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
-    if (next_mod) {
-      g.ln_out = p.xm; g.ln_shift = next_mod; g.ln_scale = next_mod + D; g.ln_mod_ld = L; g.ln_rows_per_batch = T;
-      g.ln_out_split = 1; g.ln_eps = 1e-6f; g.ln_done = ln_done;
-    }
-    return gemm2_launch(g, s);
-  };
   static const int dit_exp = RGM_EXP_ENV("RGM_DIT_EXP");   // timing experiments (common.h): 1 = fc1 without GELU/split, 2 = block-0 weights everywhere
-  int xm_ready = 0;   // the previous block's fc2 has already written this block's first LayerNorm to plan.xm
+  if (v2) {
+    // every producer (adaLN-LayerNorm, attention, fc1's GELU epilogue) writes split rows; all four GEMMs run on the LDS-DMA kernel
+    // (gemm2.hip picks the tile).  A "part" is a contiguous range of samples: the whole batch on the caller's stream, or -- from
+    // g_dit_halves samples up -- two half batches, the second on the handle's side stream (every buffer is row-major over samples, so a
+    // part is a pointer offset; each part has its own split-K scratch).  Block i of both parts is enqueued before block i + 1 of either.
+    struct Part { int n0, n; hipStream_t st; char* sk; int xm_ready; };
+    Part parts[2];
+    int nparts = 1;
+    parts[0] = Part{0, p.N, s, p.sk, 0};
+    const bool halves = c.kind == 0 && dit_halves_for(p.N) && joined;
+    if (halves) {
+      if (!h->side) {
+        RGM_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+        RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+        RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
+      }
+      const int n_a = (p.N + 1) / 2;
+      parts[0] = Part{0, n_a, s, p.sk, 0};
+      parts[1] = Part{n_a, p.N - n_a, h->side, p.sk2, 0};
+      nparts = 2;
+    }
+    auto release = [&](int i, int k, int point) -> int {   // the second half may start: everything in front of it on s is done
+      if (halves && i == 0 && k == 0 && point == g_dit_stagger) {
+        RGM_CHECK_HIP(hipEventRecord(h->ev_fork, s));
+        RGM_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+      }
+      return RGM_OK;
+    };
+    for (int i = 0; i < c.depth; ++i) {
+      const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
+      for (int k = 0; k < nparts; ++k) {
+        Part& q = parts[k];
+        const size_t r0 = (size_t)q.n0 * T;
+        const int Mq = q.n * T;
+        const float* m = p.mod + (size_t)q.n0 * L + (size_t)i * 6 * D;   // this part's first sample, block i
+        float* x = p.x + r0 * D;
+        float* xm = p.xm + r0 * D;
+        float* qkv = p.qkv + r0 * 3 * D;
+        float* ao = p.ao + r0 * D;
+        float* hid = p.hid + r0 * 4 * D;
+        // next_mod (fc2 only): shift of the NEXT block's first adaLN-LayerNorm (its scale is D further).  A K-sliced fc2 then writes that
+        // LayerNorm from its reduce kernel (GemmParams::ln_out) and *ln_done tells the loop to skip the separate launch.
+        auto lin2 = [&](const float* A, const std::string& wkey, const float* bias, float* C, int N, int K, int act, int out_split,
+                        const float* gate, const float* res, int tile, const float* next_mod = nullptr, int* ln_done = nullptr) {
+          GemmParams g;
+          g.tile = tile;
+          g.co_sched = halves ? 1 : 0;
+          g.A = A; g.lda = K; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = N;
+          g.M = Mq; g.N = N; g.K = K; g.bias = bias; g.act = act; g.out_split = out_split;
+          g.sk_ws = q.sk; g.sk_ws_bytes = p.sk_bytes;
+          if (gate) { g.gate = gate; g.gate_ld = L; g.rows_per_gate = T; g.res = res; g.ldres = N; }
+          if (next_mod) {
+            g.ln_out = xm; g.ln_shift = next_mod; g.ln_scale = next_mod + D; g.ln_mod_ld = L; g.ln_rows_per_batch = T;
+            g.ln_out_split = 1; g.ln_eps = 1e-6f; g.ln_done = ln_done;
+          }
+          return gemm2_launch(g, q.st);
+        };
+        RGM_TRY(release(i, k, 0));
+        if (!q.xm_ready) RGM_TRY(layernorm_modulate_launch(x, xm, Mq, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, q.st, 1));
+        q.xm_ready = 0;
+        RGM_TRY(lin2(xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), qkv, 3 * D, D, 0, 0, nullptr, nullptr, RGM_EXP_ENV("RGM_QKV_TILE")));
+        RGM_TRY(release(i, k, 1));
+        RGM_TRY(rotary_attention_fwd(qkv, ao, h->cos_tab, h->sin_tab, q.n, T, c.heads, h->hd, h->rot_half, q.st, 1));
+        RGM_TRY(release(i, k, 2));
+        RGM_TRY(lin2(ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x, D, D, 0, 0, m + 2 * D, x, 0));
+        RGM_TRY(release(i, k, 3));
+        RGM_TRY(layernorm_modulate_launch(x, xm, Mq, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, q.st, 1));
+        RGM_TRY(release(i, k, 4));
+        RGM_TRY(lin2(xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr,
+                     RGM_EXP_ENV("RGM_FC1_TILE")));
+        RGM_TRY(release(i, k, 5));
+        if (!halves) RGM_TRY(join());          // block i + 1's shift / scale feed the fused reduce + LayerNorm of this fc2
+        RGM_TRY(lin2(hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), x, D, 4 * D, 0, 0, m + 5 * D, x, RGM_EXP_ENV("RGM_FC2_TILE"),
+                     i + 1 < c.depth ? m + 6 * D : nullptr, &q.xm_ready));
+      }
+    }
+    if (halves) {
+      RGM_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
+      RGM_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    }
+    RGM_TRY(join());
+    return RGM_OK;
+  }
   for (int i = 0; i < c.depth; ++i) {
     const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
     const float* m = p.mod + (size_t)i * 6 * D;
-    if (v2) {
-      // every producer (adaLN-LayerNorm, attention, fc1's GELU epilogue) writes split rows; all four GEMMs run on the
-      // LDS-DMA kernel (gemm2.hip picks the tile)
-      if (!xm_ready) RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s, 1));
-      xm_ready = 0;
-      RGM_TRY(lin2(p.xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D, 0, 0, nullptr, nullptr, RGM_EXP_ENV("RGM_QKV_TILE")));
-      RGM_TRY(rotary_attention_fwd(p.qkv, p.ao, h->cos_tab, h->sin_tab, p.N, T, c.heads, h->hd, h->rot_half, s, 1));
-      RGM_TRY(lin2(p.ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D, 0, 0, m + 2 * D, p.x, 0));
-      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
-      RGM_TRY(lin2(p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr,
-                   RGM_EXP_ENV("RGM_FC1_TILE")));
-      RGM_TRY(join());          // block i + 1's shift / scale feed the fused reduce + LayerNorm of this fc2
-      RGM_TRY(lin2(p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), p.x, D, 4 * D, 0, 0, m + 5 * D, p.x, RGM_EXP_ENV("RGM_FC2_TILE"),
-                   i + 1 < c.depth ? m + 6 * D : nullptr, &xm_ready));
-      continue;
-    }
     if (i > 0) RGM_TRY(join());
     RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, T, s));
     RGM_TRY(lin(p.xm, D, h->p(b + "attn.qkv.weight"), h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, p.M, 3 * D, D, 0, s));
@@ -607,6 +674,7 @@ struct GPlan {
   float *xm, *hid, *dx, *dx1, *t1, *dbig, *dqkv, *dsmall;
   float *pool, *pooln, *z1pre, *z1, *logits, *dl, *dz1, *dpooln, *dpool, *dz, *dtin;
   char* sk;          // split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
+  char* sk2;         // the same for the second half batch when the blocks run as two half batches on two streams
   size_t sk_bytes;
   size_t bytes;
 };
@@ -653,6 +721,7 @@ GPlan gplan(const rgm_dit* h, int N, int H, void* ws) {
   p.dtin = w.take((size_t)p.M0 * c.in_ch * c.patch);
   p.sk_bytes = gemm2_scratch_bytes(p.M, 4 * (int)D);
   p.sk = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
+  p.sk2 = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
   p.bytes = w.off;
   return p;
 }
@@ -918,6 +987,15 @@ extern "C" int rgm_dit_vjp(rgm_dit* h, const float* x, const int64_t* t, const i
 // 1: the adaLN conditioning of blocks 1.. runs on the handle's side stream under block 0 (fork / join by events on the caller's stream:
 // still stream-ordered for the caller, capturable); 0 (default): one GEMM in front of block 0.  Same-box A/B at C2: 12.67 ms (0) vs
 // 12.72 ms (1) -- the one-wave-per-SIMD GEMMs own every register of their CUs, the side launch only runs in their gaps
+// Eps-network forwards of at least `min_batch` samples run their blocks as two half batches on two streams (0: never; -1, the default:
+// the batch sizes where it measured ahead).  Returns the previous value through *prev when given.
+extern "C" int rgm_set_dit_halves(int min_batch, int* prev) {
+  RGM_REQUIRE(min_batch >= -1, "set_dit_halves: %d", min_batch);
+  if (prev) *prev = g_dit_halves;
+  g_dit_halves = min_batch;
+  return RGM_OK;
+}
+
 extern "C" int rgm_set_adaln_overlap(int on) {
   RGM_REQUIRE(on == 0 || on == 1, "set_adaln_overlap: %d (0 / 1)", on);
   g_adaln_overlap = on;

@@ -1440,6 +1440,8 @@ static int splitk_factor(const GemmParams& p) {
 }
 
 static int g_t144 = getenv("RGM_T144") ? atoi(getenv("RGM_T144")) : 9;   // which grids take the 128x144 tiles (bit mask, gemm2_launch)
+static int g_co_min = getenv("RGM_CO_MIN_TILES") ? atoi(getenv("RGM_CO_MIN_TILES")) : 100;   // co-scheduled launches (GemmParams::co_sched)
+static int g_co_kt = getenv("RGM_CO_KT") ? atoi(getenv("RGM_CO_KT")) : 36;
 static int g_fuse_reduce_ln = getenv("RGM_FUSE_REDUCE_LN") ? atoi(getenv("RGM_FUSE_REDUCE_LN")) : 1;
 static long long g_fused_reduce_ln_launches = 0;
 
@@ -1583,7 +1585,31 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
 
                       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 &&
                       (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0;
-  if (big_ok) {
+  if (big_ok && p.co_sched) {
+    // Two half batches in flight (dit.hip): the other stream's kernels fill the CUs a partial round leaves, so what counts is the work per
+    // tile, not the fill of the launch's last round.  Whole GEMM on 256x256 tiles from g_co_min tiles up (no column split: fc1's 288 tiles
+    // at M = 4096 go out as ONE launch); long K as slices of about g_co_kt K-tiles.
+    const int tm = cdiv(p.M, 256), tn = cdiv(p.N, 256), KT = p.K >> 5;
+    const long long total = (long long)tm * tn;
+    const double waste = (double)((long long)tn * 256 - p.N) / ((double)tn * 256);
+    if (waste <= 0.12) {
+      if (KT >= 72 && p.sk_ws && total < 200) {
+        int best = 1;
+        for (int c = 2; c <= 8; ++c) {
+          if (KT % c || KT / c < g_co_kt || total * c > 256) continue;
+          if ((size_t)c * p.M * p.N * sizeof(float) + GEMM_SK_FLAG_BYTES > p.sk_ws_bytes) continue;
+          best = c;
+        }
+        if (best > 1) { S = best; sk_tile = 71; }
+      }
+      if (S == 1 && total >= g_co_min) {
+        GemmParams q = p;
+        q.tile = 71;
+        return gemm2_launch(q, s);
+      }
+    }
+  }
+  if (big_ok && !(p.co_sched && S > 1)) {
     const int tm = cdiv(p.M, 256), tn = cdiv(p.N, 256), KT = p.K >> 5;
     const long long total = (long long)tm * tn;
     const long long rounds = (total + 255) / 256;

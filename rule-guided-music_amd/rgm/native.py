@@ -81,6 +81,7 @@ def _load():
         "rgm_set_big_tiles": (C.c_int, [i32, i32]),
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
+        "rgm_set_dit_halves": (C.c_int, [i32, vp]),
         "rgm_split_dtype": (C.c_int, []),
         "rgm_set_attn_split": (C.c_int, [i32]),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),

@@ -286,12 +286,41 @@ def test_xl_model_at_c3_and_c4_batch_sizes_is_row_independent(B, depth, precisio
         assert rel(big[i:i + 2].cpu().numpy(), small.cpu().numpy()) < tol * (4 if depth == 28 else 1), (i, rec.n)
 
 
+@pytest.mark.parametrize("B,depth", [(2, 2), (5, 2), (8, 28), (19, 2), (32, 28), (64, 2)])
+def test_blocks_as_two_half_batches_on_two_streams_equal_the_single_stream_forward(B, depth, precision):
+    """rgm_set_dit_halves: the blocks of an eps-network forward as two half batches, the second on the handle's side stream (forked from /
+    joined to the caller's stream by events).  Same values as the single-stream forward up to the tile choice (K slices of fc2 differ with
+    M), identical from call to call, and ordered for the caller: the output is consumed on the caller's stream right behind the call."""
+    from gpu_util import dev, rel
+    from rgm import native as R
+    m = _dit(dict(XL2, depth=depth), 3)
+    rng = np.random.RandomState(100 + B)
+    x = dev(rng.randn(B, 4, 128, 16).astype(F32))
+    t = dev(rng.randint(0, 1000, size=B).astype(np.int64))
+    y = dev(rng.randint(0, 3, size=B).astype(np.int64))
+    prev = C.c_int(0)
+    R.check(R.lib.rgm_set_dit_halves(0, C.byref(prev)))
+    try:
+        assert prev.value == -1        # the default: the measured batch sizes
+        one = m(x, t, y).clone()
+        R.check(R.lib.rgm_set_dit_halves(2, None))
+        two = [(m(x, t, y) * 1.0).clone() for _ in range(3)]
+    finally:
+        R.check(R.lib.rgm_set_dit_halves(prev.value, None))
+    assert bool(torch.isfinite(two[0]).all())
+    assert torch.equal(two[0], two[1]) and torch.equal(two[0], two[2])
+    tol = 3e-5 if precision == "bf16x3_presplit" else 2e-6
+    assert rel(two[0].cpu().numpy(), one.cpu().numpy()) < tol * (4 if depth == 28 else 1)
+    if precision != "bf16x3_presplit":      # the other arithmetics keep one stream: bit-identical
+        assert torch.equal(two[0], one)
+
+
 @pytest.mark.parametrize("B", [4, 8, 16])
 def test_fc2_reduce_with_the_next_layernorm_equals_the_two_kernels(B):
     """fc2 of a block runs as K slices at B = 4 / 8 / 16 (M = 1024 .. 4096 rows); the kernel that reduces the slices holds whole rows
     and also writes the next block's adaLN-LayerNorm (GemmParams::ln_out, csrc/gemm2.hip; ref guided_diffusion/dit.py:334-336).
     Same arithmetic in the same order as the separate LayerNorm launch: the outputs must be IDENTICAL with the fusion on and off,
-    and the library's counter must show that the fused route really ran (depth - 1 launches per forward)."""
+    and the library's counter must show that the fused route really ran (depth - 1 launches per forward and half batch)."""
     from gpu_util import dev
     from rgm import native as R
     R.set_gemm_precision("bf16x3_presplit")          # K slices exist in the pre-split arithmetic only
@@ -308,7 +337,8 @@ def test_fc2_reduce_with_the_next_layernorm_equals_the_two_kernels(B):
         assert R.lib.rgm_fused_reduce_ln_launches() == n0
         R.check(R.lib.rgm_set_fuse_reduce_ln(1))
         fused = m(x, t, y).clone()
-        assert R.lib.rgm_fused_reduce_ln_launches() == n0 + depth - 1, "fc2 did not take the K-slice route with the fused LayerNorm"
+        parts = 2 if B == 8 else 1       # B = 8 runs as two half batches (rgm_set_dit_halves' default rule): every half's fc2 reduces its own rows
+        assert R.lib.rgm_fused_reduce_ln_launches() == n0 + parts * (depth - 1), "fc2 did not take the K-slice route with the fused LayerNorm"
     finally:
         R.check(R.lib.rgm_set_fuse_reduce_ln(1))
         R.set_gemm_precision("fp32")
