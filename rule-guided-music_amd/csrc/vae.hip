@@ -207,6 +207,77 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
   }
 }
 
+// The same pass with EIGHT channels of a pixel per lane and two such units per lane, all four 16-byte loads issued before the first
+// result: a split-row store is then 16 B of hi halves + 16 B of lo halves per lane (whole 32-B sectors instead of 8-B pieces) and twice
+// the bytes are in flight per wave.  Same arithmetic per element as gn_apply_kernel (identical values); C % 8 == 0.
+__global__ __launch_bounds__(256) void gn_apply8_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ stats,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, long long total8,
+                                                        long long half, int P, int C, int swish, int out_split, float* __restrict__ raw_split) {
+  typedef split_t bf16x8 __attribute__((ext_vector_type(8)));
+  const long long i0 = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i0 >= half) return;
+  const int q = C >> 3;
+  long long idx[2] = {i0, i0 + half};
+  float4 v[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (idx[u] < total8) {
+      v[u][0] = reinterpret_cast<const float4*>(x)[idx[u] * 2];
+      v[u][1] = reinterpret_cast<const float4*>(x)[idx[u] * 2 + 1];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const long long i = idx[u];
+    if (i >= total8) continue;
+    const int c8 = (int)(i % q);
+    const int m = (int)(i / ((long long)q * P));
+    const int gw = C >> 5;                       // channels per group: 4, 8 or 16 -> the 8 channels of a lane meet one or two groups
+    const int g0 = (c8 * 8) / gw, g1 = (c8 * 8 + 4) / gw;
+    const float mean0 = stats[(m * 32 + g0) * 2], rstd0 = stats[(m * 32 + g0) * 2 + 1];
+    const float mean1 = stats[(m * 32 + g1) * 2], rstd1 = stats[(m * 32 + g1) * 2 + 1];
+    const float4 ga0 = reinterpret_cast<const float4*>(gamma)[c8 * 2], ga1 = reinterpret_cast<const float4*>(gamma)[c8 * 2 + 1];
+    const float4 be0 = reinterpret_cast<const float4*>(beta)[c8 * 2], be1 = reinterpret_cast<const float4*>(beta)[c8 * 2 + 1];
+    const float in[8] = {v[u][0].x, v[u][0].y, v[u][0].z, v[u][0].w, v[u][1].x, v[u][1].y, v[u][1].z, v[u][1].w};
+    const long long pix = i / q;
+    const int si = split_idx(c8 * 8);
+    if (raw_split) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        hi[e] = (split_t)in[e];
+        lo[e] = (split_t)(in[e] - (float)hi[e]);
+      }
+      split_t* px = reinterpret_cast<split_t*>(raw_split + pix * C);
+      *reinterpret_cast<bf16x8*>(px + si) = hi;
+      *reinterpret_cast<bf16x8*>(px + si + 32) = lo;
+    }
+    const float gam[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w};
+    const float bet[8] = {be0.x, be0.y, be0.z, be0.w, be1.x, be1.y, be1.z, be1.w};
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float mean = e < 4 ? mean0 : mean1, rstd = e < 4 ? rstd0 : rstd1;
+      o[e] = (in[e] - mean) * rstd * gam[e] + bet[e];
+      if (swish) o[e] = silu_f(o[e]);
+    }
+    if (out_split) {
+      bf16x8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        hi[e] = (split_t)o[e];
+        lo[e] = (split_t)(o[e] - (float)hi[e]);
+      }
+      split_t* px = reinterpret_cast<split_t*>(y + pix * C);
+      *reinterpret_cast<bf16x8*>(px + si) = hi;
+      *reinterpret_cast<bf16x8*>(px + si + 32) = lo;
+    } else {
+      reinterpret_cast<float4*>(y)[i * 2] = make_float4(o[0], o[1], o[2], o[3]);
+      reinterpret_cast<float4*>(y)[i * 2 + 1] = make_float4(o[4], o[5], o[6], o[7]);
+    }
+  }
+}
+
 // rows softmax, one wave per row, cols <= 1024 and % 4 == 0
 __global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int rows, int cols) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -940,6 +1011,14 @@ int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(c.M * 32, 256)), dim3(256), 0, c.s, c.p.part, stats, c.M, GN_CHUNKS,
                        (double)P * (C / 32), 1e-6f);
     RGM_LAUNCH_CHECK();
+  }
+  static const int apply8 = getenv("RGM_GN_APPLY8") ? atoi(getenv("RGM_GN_APPLY8")) : 1;   // 0: the four-channels-per-lane kernel (A/B runs)
+  if (apply8 && C % 128 == 0) {
+    const long long total8 = (long long)c.M * P * C / 8, half = (total8 + 1) / 2;
+    hipLaunchKernelGGL(gn_apply8_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, c.s, x, y, stats,
+                       c.h->p(key + ".weight"), c.h->p(key + ".bias"), total8, half, P, C, swish, out_split, raw_split);
+    RGM_LAUNCH_CHECK();
+    return RGM_OK;
   }
   const long long total4 = (long long)c.M * P * C / 4;
   hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, c.s, x, y, stats,
