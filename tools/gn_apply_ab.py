@@ -18,7 +18,7 @@ def child(N):
     from taming.models.klvae_pedal import AutoencoderKL
     from guided_diffusion.gaussian_diffusion import _decode
     R.set_gemm_precision("bf16x3_presplit")
-    vae = load_module(AutoencoderKL(), synth.vae_state_dict(2, encoder=False))
+    vae = load_module(AutoencoderKL(), synth.vae_state_dict(2, encoder=True))
     z = torch.from_numpy(np.random.RandomState(0).randn(N, 4, 128, 16).astype(np.float32)).cuda()
     for _ in range(2):
         roll = _decode(z, vae, 1.0)
