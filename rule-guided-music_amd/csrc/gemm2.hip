@@ -1089,7 +1089,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
               estamp(1);
             }
             // this slab's residual rows have landed: only the stores of the previous slab's pass 2 were issued after their DMA
-            if (im == 0 || !full) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the counted waits below assume exactly ONE store per row and lane for fp32 rows and TWO for split rows -- store_row's out16 /
+            // out8 pair -- behind the DMA; the experiment variants that drop stores wait for everything)
+            if (im == 0 || !full || exp != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (p.out_split) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
             staged_pass1(stg, rslab, row_w + im * 32, g_lo[im], g_hi[im], bnd[im]);
@@ -1281,8 +1283,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     if (fixed > 0) g = fixed;
     pr.raster_group = g < 1 ? 1 : (g > tm ? tm : g);
   }
-  RGM_REQUIRE(!p.gate || p.rows_per_gate >= 32 || BM * BN <= 128 * 128,
-              "gemm2: tiles above 128x128 take at most two gate rows per 32-row slab (rows_per_gate %d < 32)", p.rows_per_gate);
+  RGM_REQUIRE(!p.gate || p.rows_per_gate >= 32 || BM * BN <= 128 * 128 || PIPE != 5,   // (the 256x128 tiles of PIPE 0 / 3 run linear_rows: any gate period)
+              "gemm2: the one-wave-per-SIMD tiles take at most two gate rows per 32-row slab (rows_per_gate %d < 32)", p.rows_per_gate);
   Prof2 rec{};
   if (g2_prof_on) {
     RGM_CHECK_HIP(hipEventCreate(&rec.a));
