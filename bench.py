@@ -261,12 +261,19 @@ class DPSRuleWorkload(SCGWorkload):
 def roofline_pass(work, steps=2):
     """Dominant-kernel roofline from HIP events around every GEMM launch (its own short pass)."""
     from rgm import native as R
-    R.check(R.lib.rgm_prof_reset())
-    R.check(R.lib.rgm_prof_enable(1))
-    for _ in range(steps):
-        work.step()
-    torch.cuda.synchronize()
-    R.check(R.lib.rgm_prof_enable(0))
+    # per-launch durations must be exclusive: with the blocks as two half batches on two streams (rgm_set_dit_halves, B = 32 / 64 / 8 ...)
+    # the launches of the halves overlap in time and every one of them reads as long as the pair -- this pass runs the single-stream forward
+    prev = C.c_int(0)
+    R.check(R.lib.rgm_set_dit_halves(0, C.byref(prev)))
+    try:
+        R.check(R.lib.rgm_prof_reset())
+        R.check(R.lib.rgm_prof_enable(1))
+        for _ in range(steps):
+            work.step()
+        torch.cuda.synchronize()
+        R.check(R.lib.rgm_prof_enable(0))
+    finally:
+        R.check(R.lib.rgm_set_dit_halves(prev.value, None))
     rows = {}
     for kid in range(1, 140):
         n, ms, fl = C.c_int(), C.c_double(), C.c_double()
