@@ -60,6 +60,9 @@ static bool dit_halves_for(int N) {
 }
 // where in block 0 of the first half the second half is released: 0 = with it, 1 .. 5 = behind its qkv / attention / proj / second LayerNorm /
 // fc1 (the halves then run out of phase: one's short-K GEMMs beside the other's long-K ones)
+// parts of a split forward (2 .. 4; read once: the workspace plan depends on it).  Three and four parts measured behind two at every batch
+// size but B = 112 (profiles/r04_halves_parts.txt): the parts of a forward re-read the weights and shrink the tile grids
+static const int g_dit_parts = getenv("RGM_DIT_PARTS") ? atoi(getenv("RGM_DIT_PARTS")) : 2;
 static int g_dit_stagger = getenv("RGM_DIT_STAGGER") ? atoi(getenv("RGM_DIT_STAGGER")) : 0;
 
 struct rgm_dit {
@@ -82,6 +85,8 @@ struct rgm_dit {
   // joined to the caller's stream by events, while block 0 runs (rgm_set_adaln_overlap)
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side_x[2] = {nullptr, nullptr};       // third / fourth part of a forward split into more than two parts (g_dit_parts)
+  hipEvent_t ev_join_x[2] = {nullptr, nullptr};
 
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
   float* sp(const Slot& sl) const { return (sl.in_t ? arena_t : arena) + sl.off; }
@@ -247,6 +252,10 @@ extern "C" void rgm_dit_destroy(rgm_dit* h) {
   if (h->side) (void)hipStreamDestroy(h->side);
   if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
   if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+  for (int i = 0; i < 2; ++i) {
+    if (h->side_x[i]) (void)hipStreamDestroy(h->side_x[i]);
+    if (h->ev_join_x[i]) (void)hipEventDestroy(h->ev_join_x[i]);
+  }
   delete h;
 }
 
@@ -368,6 +377,7 @@ struct Plan {
   float *tok_in, *h1, *x, *xm, *qkv, *ao, *hid, *temb, *c1, *c, *cs, *mod, *tok_out, *pool, *pooln, *z1;
   char* sk;          // split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
   char* sk2;         // the same for the second half batch when the blocks run as two half batches on two streams
+  char* sk_x[2];     // ... and for a third / fourth part
   size_t sk_bytes;
   size_t bytes;
 };
@@ -404,6 +414,7 @@ Plan make_plan(const rgm_dit* h, int N, int H, void* ws, size_t cap) {
   p.sk_bytes = gemm2_scratch_bytes(p.M, 4 * (int)D);
   p.sk = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
   p.sk2 = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
+  for (int i = 0; i < 2; ++i) p.sk_x[i] = g_dit_parts > 2 + i ? reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float))) : nullptr;
   p.bytes = w.off;
   return p;
 }
@@ -483,7 +494,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     // g_dit_halves samples up -- two half batches, the second on the handle's side stream (every buffer is row-major over samples, so a
     // part is a pointer offset; each part has its own split-K scratch).  Block i of both parts is enqueued before block i + 1 of either.
     struct Part { int n0, n; hipStream_t st; char* sk; int xm_ready; };
-    Part parts[2];
+    Part parts[4];
     int nparts = 1;
     parts[0] = Part{0, p.N, s, p.sk, 0};
     const bool halves = c.kind == 0 && dit_halves_for(p.N) && joined;
@@ -493,15 +504,25 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
         RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
         RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming));
       }
-      const int n_a = (p.N + 1) / 2;
-      parts[0] = Part{0, n_a, s, p.sk, 0};
-      parts[1] = Part{n_a, p.N - n_a, h->side, p.sk2, 0};
-      nparts = 2;
+      nparts = g_dit_parts < 2 ? 2 : (g_dit_parts > 4 ? 4 : g_dit_parts);
+      if (nparts > p.N) nparts = p.N;
+      for (int k = 2; k < nparts; ++k) {
+        if (!h->side_x[k - 2]) {
+          RGM_CHECK_HIP(hipStreamCreateWithFlags(&h->side_x[k - 2], hipStreamNonBlocking));
+          RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_join_x[k - 2], hipEventDisableTiming));
+        }
+      }
+      int n0 = 0;
+      for (int k = 0; k < nparts; ++k) {                 // contiguous, near-equal: the first N % nparts parts take one sample more
+        const int n = p.N / nparts + (k < p.N % nparts ? 1 : 0);
+        parts[k] = Part{n0, n, k == 0 ? s : (k == 1 ? h->side : h->side_x[k - 2]), k == 0 ? p.sk : (k == 1 ? p.sk2 : p.sk_x[k - 2]), 0};
+        n0 += n;
+      }
     }
     auto release = [&](int i, int k, int point) -> int {   // the second half may start: everything in front of it on s is done
       if (halves && i == 0 && k == 0 && point == g_dit_stagger) {
         RGM_CHECK_HIP(hipEventRecord(h->ev_fork, s));
-        RGM_CHECK_HIP(hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        for (int j = 1; j < nparts; ++j) RGM_CHECK_HIP(hipStreamWaitEvent(parts[j].st, h->ev_fork, 0));
       }
       return RGM_OK;
     };
@@ -553,9 +574,10 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
                      i + 1 < c.depth ? m + 6 * D : nullptr, &q.xm_ready));
       }
     }
-    if (halves) {
-      RGM_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
-      RGM_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
+    for (int k = 1; k < nparts; ++k) {
+      hipEvent_t ev = k == 1 ? h->ev_join : h->ev_join_x[k - 2];
+      RGM_CHECK_HIP(hipEventRecord(ev, parts[k].st));
+      RGM_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
     }
     RGM_TRY(join());
     return RGM_OK;
@@ -674,7 +696,6 @@ struct GPlan {
   float *xm, *hid, *dx, *dx1, *t1, *dbig, *dqkv, *dsmall;
   float *pool, *pooln, *z1pre, *z1, *logits, *dl, *dz1, *dpooln, *dpool, *dz, *dtin;
   char* sk;          // split-K scratch of the pre-split GEMMs (gemm2_scratch_bytes)
-  char* sk2;         // the same for the second half batch when the blocks run as two half batches on two streams
   size_t sk_bytes;
   size_t bytes;
 };
@@ -721,7 +742,6 @@ GPlan gplan(const rgm_dit* h, int N, int H, void* ws) {
   p.dtin = w.take((size_t)p.M0 * c.in_ch * c.patch);
   p.sk_bytes = gemm2_scratch_bytes(p.M, 4 * (int)D);
   p.sk = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
-  p.sk2 = reinterpret_cast<char*>(w.take(p.sk_bytes / sizeof(float)));
   p.bytes = w.off;
   return p;
 }
