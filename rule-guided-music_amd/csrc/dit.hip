@@ -514,7 +514,9 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       }
       int n0 = 0;
       for (int k = 0; k < nparts; ++k) {                 // contiguous, near-equal: the first N % nparts parts take one sample more
-        const int n = p.N / nparts + (k < p.N % nparts ? 1 : 0);
+        int n = p.N / nparts + (k < p.N % nparts ? 1 : 0);
+        static const int first_n = (getenv("RGM_DIT_FIRST_PART") ? atoi(getenv("RGM_DIT_FIRST_PART")) : 0);      // experiments: an unequal pair (first part's samples)
+        if (first_n > 0 && first_n < p.N && nparts == 2) n = k == 0 ? first_n : p.N - first_n;
         parts[k] = Part{n0, n, k == 0 ? s : (k == 1 ? h->side : h->side_x[k - 2]), k == 0 ? p.sk : (k == 1 ? p.sk2 : p.sk_x[k - 2]), 0};
         n0 += n;
       }
