@@ -58,12 +58,15 @@ static bool dit_halves_for(int N) {
   if (g_dit_halves > 0) return N >= g_dit_halves;
   return N == 2 || (N >= 5 && N <= 9) || (N >= 17 && N <= 39) || N >= 57;
 }
-// where in block 0 of the first half the second half is released: 0 = with it, 1 .. 5 = behind its qkv / attention / proj / second LayerNorm /
-// fc1 (the halves then run out of phase: one's short-K GEMMs beside the other's long-K ones)
 // parts of a split forward (2 .. 4; read once: the workspace plan depends on it).  Three and four parts measured behind two at every batch
 // size but B = 112 (profiles/r04_halves_parts.txt): the parts of a forward re-read the weights and shrink the tile grids
 static const int g_dit_parts = getenv("RGM_DIT_PARTS") ? atoi(getenv("RGM_DIT_PARTS")) : 2;
-static int g_dit_stagger = getenv("RGM_DIT_STAGGER") ? atoi(getenv("RGM_DIT_STAGGER")) : 0;
+// where in block 0 of the first part the other parts are released: 0 = with it, 1 .. 5 = behind its qkv / attention / proj / second LayerNorm /
+// fc1 (the parts then run out of phase: one's short-K GEMMs beside the other's long-K ones).  Measured: no gain (profiles/r04_halves_stagger.txt)
+static int dit_stagger() {
+  static const int v = getenv("RGM_DIT_STAGGER") ? atoi(getenv("RGM_DIT_STAGGER")) : 0;
+  return v >= 0 && v <= 5 ? v : 0;       // the release must happen exactly once per forward
+}
 
 struct rgm_dit {
   rgm_dit_cfg cfg{};
@@ -522,7 +525,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       }
     }
     auto release = [&](int i, int k, int point) -> int {   // the second half may start: everything in front of it on s is done
-      if (halves && i == 0 && k == 0 && point == g_dit_stagger) {
+      if (halves && i == 0 && k == 0 && point == dit_stagger()) {
         RGM_CHECK_HIP(hipEventRecord(h->ev_fork, s));
         for (int j = 1; j < nparts; ++j) RGM_CHECK_HIP(hipStreamWaitEvent(parts[j].st, h->ev_fork, 0));
       }
