@@ -135,6 +135,13 @@ long long rgm_fused_reduce_ln_launches(void);
  * stream by events (still stream-ordered for the caller; capturable) while block 0 computes; 0 (default; measured equal or better) = one
  * GEMM in front of block 0. */
 int rgm_set_adaln_overlap(int on);
+/* GroupNorm + swish of a ResnetBlock's conv1 output (ref taming/modules/diffusionmodules/model.py:117-126: h = conv1(.); h = norm2(h);
+ * h = nonlinearity(h)) inside the conv launch of the decoder: the tiles of an image leave their partial sums, meet at an L2-resident
+ * counter (bounded wait) and write normalised split rows -- the separate HBM pass over the tensor disappears.  mode 0 = never, 1 = where
+ * the launch qualifies (default), 2 = every tile on the fallback path (raw rows + in-place fix-up kernel; tests).  *prev (optional)
+ * receives the previous mode; rgm_gn_fused_launches() counts the launches that took the route. */
+int rgm_set_gn_fuse(int mode, int* prev);
+long long rgm_gn_fused_launches(void);
 /* Blocks of an eps-network forward (ref guided_diffusion/dit.py:618-634: samples are independent inside a block) as TWO half batches, the
  * second on a side stream owned by the handle, forked from and joined to the caller's stream by events (stream-ordered for the caller):
  * one half's kernels fill the CUs the other half's last round of one-workgroup-per-CU tiles leaves idle.  Batches of at least

@@ -89,6 +89,12 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// the same function through v_exp_f32 + v_rcp_f32 (~2e-7 relative): the decoder's GroupNorm-swish, which since round 4 also runs inside conv
+// epilogues (64-256 values per lane on the tile's critical path).  Every swish of the VAE uses THIS form, fused or not, so that a decode does
+// not depend on which launches qualified for the fusion.  x -> -inf: x * rcp(inf) = -0; x -> +inf: x * rcp(1) = x.
+__device__ __forceinline__ float silu_fast_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -1.4426950409f));
+}
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   const float c = 0.7978845608028654f;  // sqrt(2/pi)
   return 0.5f * x * (1.0f + tanhf(c * (x + 0.044715f * x * x * x)));
@@ -179,6 +185,21 @@ struct GemmParams {
   // whatever tile shape the heuristic picked: results stay independent of the batch size); vae.hip group_norm consumes them
   double* stats = nullptr;
   int stats_gw = 0;
+  // gemm2, one-wave-per-SIMD conv tiles (PIPE 5, ALOAD 2) with `stats`: GroupNorm + swish of the OUTPUT applied in this launch's epilogue
+  // (the conv1 -> norm2 pair of a ResnetBlock: taming model.py:117-126).  A tile first leaves its partial sums in `stats`, arrives at the
+  // counter of its (image, column tile) -- gn_count[(row tile / gn_tiles) * column tiles + column tile], zeroed by the caller -- and waits
+  // (bounded) until all gn_tiles row tiles of the image have arrived; it then sums the image's partials in tile order (the arithmetic of
+  // gn_finalize_tiles_kernel), normalises its accumulators, applies swish and writes split rows.  A tile whose wait runs out writes its raw
+  // fp32 rows instead and raises gn_fail[row tile * column tiles + column tile]; vae.hip's gn_fixup pass converts such tiles in place.
+  unsigned* gn_count = nullptr;
+  int* gn_fail = nullptr;
+  int gn_tiles = 0;              // row tiles per image (image pixels / tile rows)
+  const float* gn_gamma = nullptr;
+  const float* gn_beta = nullptr;
+  double gn_n = 0.0;             // elements per group: pixels per image x channels per group
+  float gn_eps = 0.f;
+  int gn_swish = 0;
+  int gn_force_fail = 0;         // tests: every tile takes the fallback
   // caller-provided scratch of the deterministic split-K (gemm2_scratch_bytes): the first 4096 bytes are reserved, the rest holds the
   // K slices' partial sums.  nullptr: no K slicing.
   void* sk_ws = nullptr;

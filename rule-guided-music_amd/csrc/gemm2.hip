@@ -1041,8 +1041,166 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         }
       }
     };
+    auto reduce_stats = [&](bool coherent) {   // GroupNorm partial sums of this tile (uniform branch): lanes -> waves -> groups, all in a fixed order
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
+      }
+      __syncthreads();                                                // every wave is done with its staging slab
+      double* sred = reinterpret_cast<double*>(ring);                 // [wave][quad of its WCOLS columns][8]
+      if (lr == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) sred[(wave * LPR + lane) * 8 + k] = gs[k];
+      }
+      __syncthreads();
+      const int qpg = p.stats_gw >> 2;                                // column quads per group
+      const int ngrp = BN / p.stats_gw;
+      if (tid < ngrp && n0 + tid * p.stats_gw < p.N) {
+        double sum = 0., sq = 0.;
+        for (int qq = 0; qq < qpg; ++qq) {
+          const int quad = tid * qpg + qq;                            // quad index inside the BN columns of the tile
+          const int wc_ = quad / LPR, l = quad - wc_ * LPR;
+          for (int wr_ = 0; wr_ < WM; ++wr_) {
+            const double* r = sred + ((wr_ * WN + wc_) * LPR + l) * 8;
+            sum += (r[0] + r[1]) + (r[2] + r[3]);
+            sq += (r[4] + r[5]) + (r[6] + r[7]);
+          }
+        }
+        double* o2 = p.stats + ((long long)(m0 / BM) * (p.N / p.stats_gw) + n0 / p.stats_gw + tid) * 2;
+        if (coherent) {   // read by other workgroups of this launch: device-coherent stores (written through; no cache flush needed)
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(o2), (unsigned long long)__double_as_longlong(sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(o2) + 1, (unsigned long long)__double_as_longlong(sq), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          o2[0] = sum;
+          o2[1] = sq;
+        }
+      }
+    };
+    bool gn_done = false;
+    if constexpr (PIPE == 5 && ALOAD == 2 && !ALL_IM) {
+      if (p.gn_count) {
+        // ---- GroupNorm + swish of this conv's output inside the launch (GemmParams::gn_count).  Pass A: the tile's sums from the
+        // accumulators (no store) -> partials to p.stats -> arrive at the image's counter and wait for the image's other tiles
+        // (bounded) -> mean / rstd from all partials in tile order -> pass B: normalise, swish, split rows.
+        const int row_w2 = m0 + arow0 + lr;
+        static_for<0, TM>([&](auto im_c) {
+          constexpr int im = decltype(im_c)::value;
+          write_slab(im_c, stg);
+          const int row0 = row_w2 + im * 32;
+#pragma unroll 1
+          for (int j0 = 0; j0 < NJ; j0 += 4) {
+            float4 a4s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4s[u] = *reinterpret_cast<const float4*>(stg + ((j0 + u) * RPI + lr) * WCOLS + lc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int row = row0 + (j0 + u) * RPI;
+              if (row < p.M && col_ok) {
+                const float v[4] = {a4s[u].x * p.alpha + bv.x, a4s[u].y * p.alpha + bv.y, a4s[u].z * p.alpha + bv.z, a4s[u].w * p.alpha + bv.w};
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                  gs[q4] += (double)v[q4];
+                  gs[4 + q4] += (double)v[q4] * (double)v[q4];
+                }
+              }
+            }
+          }
+        });
+        // No fence: an agent-scope fence writes the L2 back (dirty with every tile's output) -- 176 against 168 ms per 64-latent decode
+        // when each tile fenced twice.  The partials go out as device-coherent stores, are complete when vmcnt retires them, and only
+        // then does the tile arrive; the readers use device-coherent loads for the counter and the partials and read nothing else.
+        reduce_stats(true);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* okf = reinterpret_cast<int*>(ring + 32768);  // behind reduce_stats' scratch
+        const int tile_m = m0 / BM, tile_n = n0 / BN;
+        if (tid == 0) {
+          unsigned* cnt = p.gn_count + (long long)(tile_m / p.gn_tiles) * tiles_n + tile_n;
+          __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+          int ok = 0;
+          if (!p.gn_force_fail) {
+            while (true) {
+              if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)p.gn_tiles) {
+                ok = 1;
+                break;
+              }
+              if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) break;     // 4 ms of the 100 MHz clock: a sibling tile is not resident
+              __builtin_amdgcn_s_sleep(16);
+            }
+          }
+          *okf = ok;
+          if (!ok) p.gn_fail[(long long)tile_m * tiles_n + tile_n] = 1;
+        }
+        __syncthreads();
+        const int ok = *okf;
+        // (mean, rstd) of the tile's groups: one thread per group sums the image's partials in tile order (the sums of
+        // gn_finalize_tiles_kernel) and leaves the pair in LDS
+        float2* mr = reinterpret_cast<float2*>(ring + 32768 + 64);
+        {
+          const int ngr = p.N / p.stats_gw, ngrp_t = BN / p.stats_gw;
+          if (ok && tid < ngrp_t && n0 + tid * p.stats_gw < p.N) {
+            const int g = n0 / p.stats_gw + tid;
+            const unsigned long long* part = reinterpret_cast<const unsigned long long*>(p.stats) +
+                                             ((long long)(tile_m / p.gn_tiles) * p.gn_tiles * ngr + g) * 2;
+            double s_ = 0., ss_ = 0.;
+            for (int t = 0; t < p.gn_tiles; ++t) {
+              s_ += __longlong_as_double((long long)__hip_atomic_load(part + (long long)t * ngr * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+              ss_ += __longlong_as_double((long long)__hip_atomic_load(part + (long long)t * ngr * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            const double mean_d = s_ / p.gn_n;
+            double var = ss_ / p.gn_n - mean_d * mean_d;
+            if (var < 0.0) var = 0.0;
+            mr[tid] = make_float2((float)mean_d, (float)(1.0 / sqrt(var + (double)p.gn_eps)));
+          }
+        }
+        __syncthreads();                                 // the pairs are in LDS; every wave has read the flag
+        float mean = 0.f, rstd = 1.f;
+        float4 ga = make_float4(1.f, 1.f, 1.f, 1.f), be = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && col_ok) {
+          const float2 m2 = mr[(col - n0) / p.stats_gw];
+          mean = m2.x;
+          rstd = m2.y;
+          ga = *reinterpret_cast<const float4*>(p.gn_gamma + col);
+          be = *reinterpret_cast<const float4*>(p.gn_beta + col);
+        }
+        __syncthreads();                                 // ... and the pairs: pass B may overwrite the slabs
+        static_for<0, TM>([&](auto im_c) {
+          constexpr int im = decltype(im_c)::value;
+          write_slab(im_c, stg);
+          const int row0 = row_w2 + im * 32;
+#pragma unroll 1
+          for (int j0 = 0; j0 < NJ; j0 += 4) {
+            float4 a4s[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4s[u] = *reinterpret_cast<const float4*>(stg + ((j0 + u) * RPI + lr) * WCOLS + lc);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int row = row0 + (j0 + u) * RPI;
+              if (row < p.M && col_ok) {
+                const float v[4] = {a4s[u].x * p.alpha + bv.x, a4s[u].y * p.alpha + bv.y, a4s[u].z * p.alpha + bv.z, a4s[u].w * p.alpha + bv.w};
+                if (ok) {
+                  float o[4] = {(v[0] - mean) * rstd * ga.x + be.x, (v[1] - mean) * rstd * ga.y + be.y, (v[2] - mean) * rstd * ga.z + be.z,
+                                (v[3] - mean) * rstd * ga.w + be.w};
+                  if (p.gn_swish) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) o[q4] = silu_fast_f(o[q4]);
+                  }
+                  store_row(row, o);
+                } else {
+                  out16(Cb + (long long)row * p.ldc + col, v);     // raw fp32 rows: gn_fixup converts the tile in place
+                }
+              }
+            }
+          }
+        });
+        gn_done = true;
+      }
+    }
     const int row_w = m0 + arow0 + lr;                          // this lane's row in slab row lr of the wave's first slab
-    if constexpr (ALL_IM) {
+    if (gn_done) {
+    } else if constexpr (ALL_IM) {
       static_for<0, TM>([&](auto im_c) { write_slab(im_c, stg + decltype(im_c)::value * 32 * WCOLS); });
       if (linear) {
         static_for<0, TM>([&](auto im_c) { linear_rows(stg + decltype(im_c)::value * 32 * WCOLS, row_w + decltype(im_c)::value * 32); });
@@ -1127,37 +1285,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         estamp(5);
       }
     }
-    if (p.stats) {   // GroupNorm partial sums of this tile (uniform branch): lanes -> waves -> groups, all in a fixed order
-#pragma unroll
-      for (int o = LPR; o < 64; o <<= 1) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) gs[k] += __shfl_xor(gs[k], o, 64);
-      }
-      __syncthreads();                                                // every wave is done with its staging slab
-      double* sred = reinterpret_cast<double*>(ring);                 // [wave][quad of its WCOLS columns][8]
-      if (lr == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) sred[(wave * LPR + lane) * 8 + k] = gs[k];
-      }
-      __syncthreads();
-      const int qpg = p.stats_gw >> 2;                                // column quads per group
-      const int ngrp = BN / p.stats_gw;
-      if (tid < ngrp && n0 + tid * p.stats_gw < p.N) {
-        double sum = 0., sq = 0.;
-        for (int qq = 0; qq < qpg; ++qq) {
-          const int quad = tid * qpg + qq;                            // quad index inside the BN columns of the tile
-          const int wc_ = quad / LPR, l = quad - wc_ * LPR;
-          for (int wr_ = 0; wr_ < WM; ++wr_) {
-            const double* r = sred + ((wr_ * WN + wc_) * LPR + l) * 8;
-            sum += (r[0] + r[1]) + (r[2] + r[3]);
-            sq += (r[4] + r[5]) + (r[6] + r[7]);
-          }
-        }
-        double* o2 = p.stats + ((long long)(m0 / BM) * (p.N / p.stats_gw) + n0 / p.stats_gw + tid) * 2;
-        o2[0] = sum;
-        o2[1] = sq;
-      }
-    }
+    if (p.stats && !gn_done) reduce_stats(false);
   } else
   static_for<0, TM>([&](auto im_c) {
     static_for<0, TN>([&](auto in_c) {

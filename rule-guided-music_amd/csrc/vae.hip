@@ -191,7 +191,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, float* __restrict__
   o.z = (v.z - mean) * rstd * ga.z + be.z;
   o.w = (v.w - mean) * rstd * ga.w + be.w;
   if (swish) {
-    o.x = silu_f(o.x); o.y = silu_f(o.y); o.z = silu_f(o.z); o.w = silu_f(o.w);
+    o.x = silu_fast_f(o.x); o.y = silu_fast_f(o.y); o.z = silu_fast_f(o.z); o.w = silu_fast_f(o.w);
   }
   if (out_split) {   // split-row pixels (common.h split_idx) for the pre-split conv GEMM
     typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const float* __restrict_
     for (int e = 0; e < 8; ++e) {
       const float mean = e < 4 ? mean0 : mean1, rstd = e < 4 ? rstd0 : rstd1;
       o[e] = (in[e] - mean) * rstd * gam[e] + bet[e];
-      if (swish) o[e] = silu_f(o[e]);
+      if (swish) o[e] = silu_fast_f(o[e]);
     }
     if (out_split) {
       bf16x8 hi, lo;
@@ -275,6 +275,56 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const float* __restrict_
       reinterpret_cast<float4*>(y)[i * 2] = make_float4(o[0], o[1], o[2], o[3]);
       reinterpret_cast<float4*>(y)[i * 2 + 1] = make_float4(o[4], o[5], o[6], o[7]);
     }
+  }
+}
+
+// Tiles of a conv launch with GemmParams::gn_count whose wait for the image's other tiles ran out wrote their RAW fp32 rows (and raised
+// fail[tile]): this pass finalises the image's statistics from the per-tile partial sums (the arithmetic of gn_finalize_tiles_kernel)
+// and converts such a tile to normalised split rows in place -- a 128-byte line holds the same 32 elements in both formats and its
+// eight lanes read it before any of them writes.  One workgroup per tile; it leaves at once when the flag is down (the normal case).
+__global__ __launch_bounds__(256) void gn_fixup_kernel(float* __restrict__ y, const int* __restrict__ fail, const double* __restrict__ tp,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta, int tiles_n,
+                                                       int rows, int bn, int C, int tiles_per_img, double count, float eps, int swish) {
+  const int tile = blockIdx.x;
+  if (!fail[tile]) return;
+  typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const int qpr = bn >> 2;                               // column quads per tile row: 32 or 64
+  const int quad = threadIdx.x % qpr, r0 = threadIdx.x / qpr, rstep = 256 / qpr;
+  const int col = tile_n * bn + quad * 4;
+  const int gw = C >> 5, g = col / gw;
+  const long long img_tile0 = (long long)(tile_m / tiles_per_img) * tiles_per_img;
+  double s = 0., ss = 0.;
+  for (int t = 0; t < tiles_per_img; ++t) {
+    const double* r = tp + ((img_tile0 + t) * 32 + g) * 2;
+    s += r[0];
+    ss += r[1];
+  }
+  const double mean_d = s / count;
+  double var = ss / count - mean_d * mean_d;
+  if (var < 0.0) var = 0.0;
+  const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float4 ga = *reinterpret_cast<const float4*>(gamma + col), be = *reinterpret_cast<const float4*>(beta + col);
+  for (int r = r0; r < rows; r += rstep) {
+    float* rowp = y + ((long long)tile_m * rows + r) * C;
+    const float4 v = *reinterpret_cast<const float4*>(rowp + col);
+    float o[4] = {(v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y, (v.z - mean) * rstd * ga.z + be.z,
+                  (v.w - mean) * rstd * ga.w + be.w};
+    if (swish) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = silu_fast_f(o[e]);
+    }
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      hi[e] = (split_t)o[e];
+      lo[e] = (split_t)(o[e] - (float)hi[e]);
+    }
+    __builtin_amdgcn_s_waitcnt(0);                       // the line's eight lanes have their values before the first store
+    __builtin_amdgcn_wave_barrier();
+    split_t* px = reinterpret_cast<split_t*>(rowp);
+    *reinterpret_cast<bf16x4*>(px + split_idx(col)) = hi;
+    *reinterpret_cast<bf16x4*>(px + split_idx(col) + 32) = lo;
   }
 }
 
@@ -954,6 +1004,8 @@ constexpr int GN_CHUNKS = 16;
 struct VPlan {
   float *pq, *b0, *b1, *b2, *q, *k, *v, *vt, *sc, *stats;
   double *part, *tpart;
+  unsigned* gn_count;     // arrival counters of a conv launch that normalises its own output: one per (image, column tile)
+  int* gn_fail;           // per-tile flags of that launch (a tile whose wait ran out wrote raw rows)
   size_t bytes;
 };
 VPlan vplan(int M, void* ws) {
@@ -979,9 +1031,16 @@ VPlan vplan(int M, void* ws) {
   p.stats = (float*)take((size_t)M * 32 * 2 * sizeof(float));
   p.part = (double*)take((size_t)M * GN_CHUNKS * 32 * 2 * sizeof(double));
   p.tpart = (double*)take((size_t)M * 128 * 32 * 2 * sizeof(double));   // per-tile GroupNorm sums from a conv epilogue (<= 128 row tiles)
+  p.gn_count = (unsigned*)take((size_t)M * 2 * sizeof(unsigned));
+  p.gn_fail = (int*)take((size_t)M * 64 * sizeof(int));
   p.bytes = off;
   return p;
 }
+
+// GroupNorm + swish inside the producing conv (GemmParams::gn_count): 0 = never, 1 = where the launch qualifies (conv3), 2 = the same with
+// every tile forced onto the fallback (tests of gn_fixup_kernel)
+static int g_gn_fuse = getenv("RGM_GN_FUSE") ? atoi(getenv("RGM_GN_FUSE")) : 1;
+static long long g_gn_fused_launches = 0;
 
 struct Ctx {
   rgm_vae* h;
@@ -1035,8 +1094,10 @@ int ilog2(int v) {
 
 // out[M*H*W, Cout] = conv3x3(in NHWC [M, H>>ups, W>>ups, Cin]) + bias (+ res)
 // in_split: `in` holds split-row pixels (group_norm(..., out_split=1) or split_rows) -> pre-split LDS-DMA kernel
+// fuse_norm (optional): key of the GroupNorm that consumes this conv's output and nothing else does -- applied (with swish) inside the
+// launch when it qualifies; *fused then tells the caller that `out` already holds the normalised split rows.
 int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const std::string& key, int ups, const float* res,
-          int in_split = 0) {
+          int in_split = 0, const std::string* fuse_norm = nullptr, int* fused = nullptr) {
   GemmParams g;
   g.A = in; g.B = c.h->p(key + (in_split ? ".weight.S" : ".weight")); g.ldb = 9 * Cin; g.C = out; g.ldc = Cout;
   g.M = c.M * H * H; g.N = Cout; g.K = 9 * Cin; g.lda = Cin;
@@ -1076,6 +1137,42 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
       c.tp_seq = my;
       c.tp_rows = rows;
     }
+    // GroupNorm + swish in this launch's epilogue: one-wave-per-SIMD tiles with channel-block-major K, no residual, and an image's row
+    // tiles must be dispatched together -- one column tile, whole images per XCD chunk of the raster (tiles / 8 a multiple of the tiles of
+    // an image), at most 32 tiles per image (the CUs of an XCD) on the 256-CU part -- or be a whole image each.
+    if (fuse_norm && fused && g_gn_fuse && g.stats && g.conv_kmajor && !res && (g.tile == 71 || g.tile == 72)) {
+      const int bn = g.tile == 71 ? 256 : 128;
+      const long long tm = g.M / rows, tn = (Cout + bn - 1) / bn, tpi = (long long)H * H / rows;
+      static int cus = -1;
+      if (cus < 0) {
+        int dev = 0;
+        RGM_CHECK_HIP(hipGetDevice(&dev));
+        RGM_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+      }
+      const bool together = tpi == 1 || (tn == 1 && tpi <= 32 && cus == 256 && tm % 8 == 0 && (tm / 8) % tpi == 0);
+      if (together && Cout % bn == 0 && tm * tn <= (long long)c.M * 64 && (tm / tpi) * tn <= (long long)c.M * 2) {
+        RGM_CHECK_HIP(hipMemsetAsync(c.p.gn_count, 0, (size_t)c.M * 2 * sizeof(unsigned), c.s));
+        RGM_CHECK_HIP(hipMemsetAsync(c.p.gn_fail, 0, (size_t)tm * tn * sizeof(int), c.s));
+        g.gn_count = c.p.gn_count;
+        g.gn_fail = c.p.gn_fail;
+        g.gn_tiles = (int)tpi;
+        g.gn_gamma = c.h->p(*fuse_norm + ".weight");
+        g.gn_beta = c.h->p(*fuse_norm + ".bias");
+        g.gn_n = (double)H * H * (Cout / 32);
+        g.gn_eps = 1e-6f;
+        g.gn_swish = 1;
+        g.gn_force_fail = g_gn_fuse == 2 ? 1 : 0;
+        g.out_split = 1;
+        RGM_TRY(gemm2_launch(g, c.s));
+        hipLaunchKernelGGL(gn_fixup_kernel, dim3((unsigned)(tm * tn)), dim3(256), 0, c.s, out, (const int*)c.p.gn_fail, (const double*)c.p.tpart,
+                           g.gn_gamma, g.gn_beta, (int)tn, rows, bn, Cout, (int)tpi, g.gn_n, g.gn_eps, 1);
+        RGM_LAUNCH_CHECK();
+        *fused = 1;
+        ++g_gn_fused_launches;
+        c.tp_for = nullptr;                 // the sums belong to a tensor that no longer exists in raw form
+        return RGM_OK;
+      }
+    }
     return gemm2_launch(g, c.s);
   }
   return gemm_launch(g, c.s);
@@ -1106,7 +1203,14 @@ int resnet(Ctx& c, const float* x, float* b, float* hbuf, float* out, float* t1,
            float* st1 = nullptr, float* st2 = nullptr) {
   const int P = H * H;
   RGM_TRY(group_norm(c, x, t1, P, Cin, key + "norm1", 1, c.split, st1));
-  RGM_TRY(conv3(c, t1, b, H, Cin, Cout, key + "conv1", 0, nullptr, c.split));
+  if (c.split && !st2 && Cin == Cout) {   // plain decode: norm2 + swish inside conv1's launch where it qualifies (the saving decode keeps raw b)
+    const std::string n2 = key + "norm2";
+    int fused = 0;
+    RGM_TRY(conv3(c, t1, b, H, Cin, Cout, key + "conv1", 0, nullptr, 1, &n2, &fused));
+    if (fused) return conv3(c, b, out, H, Cout, Cout, key + "conv2", 0, x, 1);             // b holds swish(norm2(conv1(.))) as split rows
+  } else {
+    RGM_TRY(conv3(c, t1, b, H, Cin, Cout, key + "conv1", 0, nullptr, c.split));
+  }
   RGM_TRY(group_norm(c, b, t1, P, Cout, key + "norm2", 1, c.split, st2));
   if (Cin == Cout) return conv3(c, t1, out, H, Cout, Cout, key + "conv2", 0, x, c.split);  // out = conv2(.) + x
   RGM_TRY(conv3(c, t1, hbuf, H, Cout, Cout, key + "conv2", 0, nullptr, c.split));
@@ -1121,7 +1225,10 @@ int resnet(Ctx& c, float*& cur, float*& t1, float*& t2, int H, int Cin, int Cout
     const int P = H * H;
     RGM_TRY(group_norm(c, cur, t1, P, Cin, key + "norm1", 1, 1, nullptr, t2));
     RGM_TRY(conv1(c, t2, cur, c.M * P, Cin, Cout, key + "nin_shortcut", nullptr, 1));            // cur <- nin(x)
-    RGM_TRY(conv3(c, t1, t2, H, Cin, Cout, key + "conv1", 0, nullptr, 1));                          // t2 <- conv1(swish(norm1(x)))
+    const std::string n2 = key + "norm2";
+    int fused = 0;
+    RGM_TRY(conv3(c, t1, t2, H, Cin, Cout, key + "conv1", 0, nullptr, 1, &n2, &fused));            // t2 <- conv1(swish(norm1(x)))
+    if (fused) return conv3(c, t2, cur, H, Cout, Cout, key + "conv2", 0, cur, 1);                   // (t2 already swish(norm2(.)) as split rows)
     RGM_TRY(group_norm(c, t2, t1, P, Cout, key + "norm2", 1, 1));
     return conv3(c, t1, cur, H, Cout, Cout, key + "conv2", 0, cur, 1);                              // cur <- conv2(.) + nin(x)
   }
@@ -1159,6 +1266,16 @@ int attn_block(Ctx& c, const float* cur, float* out, float* t1, const std::strin
   return conv1(c, t1, out, rows, C, C, a + "proj_out", cur);  // x + proj_out(o)
 }
 }  // namespace
+
+// GroupNorm + swish of a ResnetBlock's conv1 output inside the conv launch (0 = never; 1 = where the launch qualifies, the default; 2 = the
+// same with every tile on the fallback path -- raw rows + gn_fixup_kernel -- for its test).  *prev (optional): the previous mode.
+extern "C" int rgm_set_gn_fuse(int mode, int* prev) {
+  RGM_REQUIRE(mode >= 0 && mode <= 2, "set_gn_fuse: %d (0 / 1 / 2)", mode);
+  if (prev) *prev = g_gn_fuse;
+  g_gn_fuse = mode;
+  return RGM_OK;
+}
+extern "C" long long rgm_gn_fused_launches(void) { return g_gn_fused_launches; }
 
 extern "C" size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M) {
   if (!h || M <= 0) return 0;

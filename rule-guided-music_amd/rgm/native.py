@@ -82,6 +82,8 @@ def _load():
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
         "rgm_set_dit_halves": (C.c_int, [i32, vp]),
+        "rgm_set_gn_fuse": (C.c_int, [i32, vp]),
+        "rgm_gn_fused_launches": (C.c_longlong, []),
         "rgm_split_dtype": (C.c_int, []),
         "rgm_set_attn_split": (C.c_int, [i32]),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),

@@ -788,6 +788,41 @@ def test_half_window_batches_through_the_xl_model_are_deterministic(precision):
     assert rel(outs[0].cpu().numpy(), small.cpu().numpy()) < (3e-5 if precision == "bf16x3_presplit" else 2e-6)
 
 
+@pytest.mark.parametrize("n", [8, 12])
+def test_groupnorm_inside_the_conv_launch_equals_the_separate_pass(n):
+    """rgm_set_gn_fuse: conv1 of a decoder ResnetBlock normalises its own output (the tiles of an image meet at a counter, bounded wait) and
+    writes swish(norm2(.)) as split rows -- no separate pass over the tensor (ref taming model.py:117-126).  Same partial sums in the same
+    order, same element arithmetic: the roll must be IDENTICAL to the separate pass, the library's counter must show the route ran, and
+    the fallback (mode 2: every tile writes raw rows, gn_fixup_kernel converts them in place) must give the same roll again.  n = 12 latents
+    (96 squares) does not fill whole XCD chunks with whole images at the 128x128 level: those launches must stay on the separate pass."""
+    from gpu_util import dev
+    from rgm import native as R
+    from guided_diffusion.gaussian_diffusion import _decode
+    R.set_gemm_precision("bf16x3_presplit")
+    vae = _vae()
+    z = dev(np.random.RandomState(n).randn(n, 4, 128, 16).astype(F32))
+    prev = C.c_int(0)
+    R.check(R.lib.rgm_set_gn_fuse(0, C.byref(prev)))
+    try:
+        assert prev.value == 1
+        n0 = R.lib.rgm_gn_fused_launches()
+        apart = _decode(z, vae, 1.0).clone()
+        assert R.lib.rgm_gn_fused_launches() == n0
+        R.check(R.lib.rgm_set_gn_fuse(1, None))
+        fused = [_decode(z, vae, 1.0).clone() for _ in range(2)]
+        launches = R.lib.rgm_gn_fused_launches() - n0
+        R.check(R.lib.rgm_set_gn_fuse(2, None))
+        fallback = _decode(z, vae, 1.0).clone()
+    finally:
+        R.check(R.lib.rgm_set_gn_fuse(prev.value, None))
+        R.set_gemm_precision("fp32")
+    assert launches >= 2 * (5 if n == 8 else 2), launches       # per decode: the 16x16 level always qualifies; n = 8: every level
+    assert bool(torch.isfinite(fused[0]).all())
+    assert torch.equal(fused[0], fused[1])
+    assert torch.equal(fused[0], apart), float((fused[0] - apart).abs().max())
+    assert torch.equal(fallback, apart), float((fallback - apart).abs().max())
+
+
 def test_vae_decoder_golden_through_the_big_tile_conv_kernels():
     """The VAE's 3x3 convs take the 256x256 / 512x128 one-wave-per-SIMD kernels (implicit-GEMM loader, GroupNorm sums in the epilogue at
     256- / 512-row granularity) once a launch fills the chip -- far above the golden fixtures' two squares.  rgm_set_big_tiles lowers that
