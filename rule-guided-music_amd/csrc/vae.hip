@@ -1001,6 +1001,7 @@ extern "C" int rgm_vae_enable_grad(rgm_vae* h) {
 
 namespace {
 constexpr int GN_CHUNKS = 16;
+constexpr int GN_SLOTS = 16;   // conv launches per decode that may normalise their own output (14 conv1's in the decoder)
 struct VPlan {
   float *pq, *b0, *b1, *b2, *q, *k, *v, *vt, *sc, *stats;
   double *part, *tpart;
@@ -1031,8 +1032,9 @@ VPlan vplan(int M, void* ws) {
   p.stats = (float*)take((size_t)M * 32 * 2 * sizeof(float));
   p.part = (double*)take((size_t)M * GN_CHUNKS * 32 * 2 * sizeof(double));
   p.tpart = (double*)take((size_t)M * 128 * 32 * 2 * sizeof(double));   // per-tile GroupNorm sums from a conv epilogue (<= 128 row tiles)
-  p.gn_count = (unsigned*)take((size_t)M * 2 * sizeof(unsigned));
-  p.gn_fail = (int*)take((size_t)M * 64 * sizeof(int));
+  // GN_SLOTS launches of a decode each own a slice (M * 2 counters + M * 64 flags, contiguous): ONE memset when the first of them is met
+  p.gn_count = (unsigned*)take((size_t)GN_SLOTS * M * 66 * sizeof(unsigned));
+  p.gn_fail = nullptr;
   p.bytes = off;
   return p;
 }
@@ -1052,6 +1054,7 @@ struct Ctx {
   // a group_norm that is the very next op on that tensor finalises them instead of re-reading the tensor from HBM
   int seq = 0, tp_seq = -1;
   const float* tp_for = nullptr;
+  int gn_slot = 0;               // next free slice of the plan's counters / flags (GemmParams::gn_count); zeroed when slot 0 is taken
   int tp_rows = 128;             // tile height of the conv that left those sums (128: heuristic tiles; 256 / 512: the 256x256 / 512x128 kernels)
 };
 
@@ -1150,11 +1153,11 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
         RGM_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
       }
       const bool together = tpi == 1 || (tn == 1 && tpi <= 32 && cus == 256 && tm % 8 == 0 && (tm / 8) % tpi == 0);
-      if (together && Cout % bn == 0 && tm * tn <= (long long)c.M * 64 && (tm / tpi) * tn <= (long long)c.M * 2) {
-        RGM_CHECK_HIP(hipMemsetAsync(c.p.gn_count, 0, (size_t)c.M * 2 * sizeof(unsigned), c.s));
-        RGM_CHECK_HIP(hipMemsetAsync(c.p.gn_fail, 0, (size_t)tm * tn * sizeof(int), c.s));
-        g.gn_count = c.p.gn_count;
-        g.gn_fail = c.p.gn_fail;
+      if (together && c.gn_slot < GN_SLOTS && Cout % bn == 0 && tm * tn <= (long long)c.M * 64 && (tm / tpi) * tn <= (long long)c.M * 2) {
+        if (c.gn_slot == 0) RGM_CHECK_HIP(hipMemsetAsync(c.p.gn_count, 0, (size_t)GN_SLOTS * c.M * 66 * sizeof(unsigned), c.s));
+        g.gn_count = c.p.gn_count + (size_t)c.gn_slot * c.M * 66;
+        g.gn_fail = reinterpret_cast<int*>(g.gn_count + (size_t)c.M * 2);
+        ++c.gn_slot;
         g.gn_tiles = (int)tpi;
         g.gn_gamma = c.h->p(*fuse_norm + ".weight");
         g.gn_beta = c.h->p(*fuse_norm + ".bias");
@@ -1164,7 +1167,7 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
         g.gn_force_fail = g_gn_fuse == 2 ? 1 : 0;
         g.out_split = 1;
         RGM_TRY(gemm2_launch(g, c.s));
-        hipLaunchKernelGGL(gn_fixup_kernel, dim3((unsigned)(tm * tn)), dim3(256), 0, c.s, out, (const int*)c.p.gn_fail, (const double*)c.p.tpart,
+        hipLaunchKernelGGL(gn_fixup_kernel, dim3((unsigned)(tm * tn)), dim3(256), 0, c.s, out, (const int*)g.gn_fail, (const double*)c.p.tpart,
                            g.gn_gamma, g.gn_beta, (int)tn, rows, bn, Cout, (int)tpi, g.gn_n, g.gn_eps, 1);
         RGM_LAUNCH_CHECK();
         *fused = 1;
