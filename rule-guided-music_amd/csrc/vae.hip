@@ -430,9 +430,15 @@ __global__ __launch_bounds__(256) void vae_conv_out_kernel(const float* __restri
 // launch instead of the 3x of one-row workgroups plus nothing but coalesced 128-B lines), a lane owns a PIXEL and keeps its three
 // outputs in registers (no cross-lane reduction: the old kernel spent 15 shuffles per pixel), the 3 x 9 x 128 weights are wave-uniform
 // and come through the scalar cache.  Same sums in another order than vae_conv_out_kernel: 3.67 -> ~1.3 ms per 512-square decode.
+// NORM: x is the RAW residual stream and norm_out + swish (ref taming model.py:535-537: h = norm_out(h); h = nonlinearity(h); conv_out(h))
+// are applied as the values are staged -- gn_apply's expression, so the conv sees the values the separate pass would have written; every
+// value is staged by two workgroups (four rows for two output rows), i.e. normalised twice instead of being written and read once.
+template <bool NORM>
 __global__ __launch_bounds__(256) void vae_conv_out_tiled_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                  const float* __restrict__ b, float* __restrict__ roll,
-                                                                 uint8_t* __restrict__ u8, int M, int Nb, int Tt, float thr) {
+                                                                 uint8_t* __restrict__ u8, int M, int Nb, int Tt, float thr,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta) {
   constexpr int C = 128, CQ = 8, ROWS = 4, PX = 130, PLANE = ROWS * PX + 1;   // float4 units
   __shared__ float4 tile[CQ * PLANE];
   const int tid = threadIdx.x;
@@ -453,6 +459,25 @@ __global__ __launch_bounds__(256) void vae_conv_out_tiled_kernel(const float* __
       const int yy = y0 - 1 + row, xs = px - 1;
       stage[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (i < ROWS * PX * CQ && (unsigned)yy < 128u && (unsigned)xs < 128u) stage[k] = xb[((yy << 7) + xs) * (C / 4) + cb * 8 + (i & 7)];
+    }
+    if constexpr (NORM) {   // lane = channel quad cb * 8 + (tid & 7) for every k: one group (4 channels per group at C = 128), one gamma / beta quad
+      const int cq = cb * 8 + (tid & 7);
+      const float mean = stats[(m * 32 + cq) * 2], rstd = stats[(m * 32 + cq) * 2 + 1];
+      const float4 ga = reinterpret_cast<const float4*>(gamma)[cq], be = reinterpret_cast<const float4*>(beta)[cq];
+#pragma unroll
+      for (int k = 0; k < NLD; ++k) {
+        const int i = tid + k * 256;
+        const int pp = i >> 3, row = pp / PX, px = pp - row * PX;
+        const int yy = y0 - 1 + row, xs = px - 1;
+        if (i < ROWS * PX * CQ && (unsigned)yy < 128u && (unsigned)xs < 128u) {      // the conv's zero padding stays zero
+          float4 o;
+          o.x = silu_fast_f((stage[k].x - mean) * rstd * ga.x + be.x);
+          o.y = silu_fast_f((stage[k].y - mean) * rstd * ga.y + be.y);
+          o.z = silu_fast_f((stage[k].z - mean) * rstd * ga.z + be.z);
+          o.w = silu_fast_f((stage[k].w - mean) * rstd * ga.w + be.w);
+          stage[k] = o;
+        }
+      }
     }
 #pragma unroll
     for (int k = 0; k < NLD; ++k) {
@@ -1059,6 +1084,7 @@ struct Ctx {
 };
 
 // stats: where (mean, rstd) of the M x 32 groups go (kept for the backward when given; default the shared scratch)
+// y == nullptr: statistics only (the consumer normalises as it loads: conv_out_launch)
 int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string& key, int swish, int out_split = 0,
                float* stats = nullptr, float* raw_split = nullptr) {
   if (!stats) stats = c.p.stats;
@@ -1074,6 +1100,7 @@ int group_norm(Ctx& c, const float* x, float* y, int P, int C, const std::string
                        (double)P * (C / 32), 1e-6f);
     RGM_LAUNCH_CHECK();
   }
+  if (!y) return RGM_OK;
   static const int apply8 = getenv("RGM_GN_APPLY8") ? atoi(getenv("RGM_GN_APPLY8")) : 1;   // 0: the four-channels-per-lane kernel (A/B runs)
   if (apply8 && C % 128 == 0) {
     const long long total8 = (long long)c.M * P * C / 8, half = (total8 + 1) / 2;
@@ -1287,11 +1314,16 @@ extern "C" size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M) {
 
 // in: element (tile m = s*Nb + n, channel c, pitch i, time j) at in[n*n_stride + s*s_stride + c*sc + i*si + j*sj] * in_scale
 // conv_out (+ bias, scatter into the roll, optional uint8 quantise): one launcher for the plain and the saving decode
-static int conv_out_launch(const rgm_vae* h, const float* t1, float* roll, uint8_t* u8, int M, int Nb, int Tt, float thr, hipStream_t s) {
+// stats (optional): t1 is the RAW input of norm_out and (mean, rstd) of its M x 32 groups are in `stats`: the tiled kernel normalises as it stages
+static int conv_out_launch(const rgm_vae* h, const float* t1, float* roll, uint8_t* u8, int M, int Nb, int Tt, float thr, hipStream_t s,
+                           const float* stats = nullptr) {
   static const int tiled = getenv("RGM_CONV_OUT_TILED") ? atoi(getenv("RGM_CONV_OUT_TILED")) : 1;   // 0: the one-row kernel (A/B)
-  if (tiled)
-    hipLaunchKernelGGL(vae_conv_out_tiled_kernel, dim3(M * 64), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
-                       h->p("decoder.conv_out.bias"), roll, u8, M, Nb, Tt, thr);
+  if (stats)
+    hipLaunchKernelGGL(vae_conv_out_tiled_kernel<true>, dim3(M * 64), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
+                       h->p("decoder.conv_out.bias"), roll, u8, M, Nb, Tt, thr, stats, h->p("decoder.norm_out.weight"), h->p("decoder.norm_out.bias"));
+  else if (tiled)
+    hipLaunchKernelGGL(vae_conv_out_tiled_kernel<false>, dim3(M * 64), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
+                       h->p("decoder.conv_out.bias"), roll, u8, M, Nb, Tt, thr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
   else
     hipLaunchKernelGGL(vae_conv_out_kernel, dim3(M * 128), dim3(256), 0, s, t1, h->p("decoder.conv_out.weight"),
                        h->p("decoder.conv_out.bias"), roll, u8, M, Nb, Tt, thr);
@@ -1348,6 +1380,14 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
       }
       std::swap(cur, t1);
     }
+  }
+  // norm_out + swish inside conv_out's staging (g_gn_fuse, C = 128, the tiled kernel): no pass over the largest tensor of the decode
+  static const int tiled = getenv("RGM_CONV_OUT_TILED") ? atoi(getenv("RGM_CONV_OUT_TILED")) : 1;
+  static const int out_fuse = getenv("RGM_NORM_OUT_FUSE") ? atoi(getenv("RGM_NORM_OUT_FUSE")) : 1;   // 0: the separate pass (A/B runs)
+  if (g_gn_fuse && out_fuse && tiled && C == 128) {
+    RGM_TRY(group_norm(c, cur, nullptr, 128 * 128, C, d + "norm_out", 1));
+    ++g_gn_fused_launches;
+    return conv_out_launch(h, cur, roll, u8, M, Nb, S * 128, thr, s, c.p.stats);
   }
   RGM_TRY(group_norm(c, cur, t1, 128 * 128, C, d + "norm_out", 1));
   return conv_out_launch(h, t1, roll, u8, M, Nb, S * 128, thr, s);
