@@ -1572,6 +1572,12 @@ static int decode_save_impl(rgm_vae* h, const float* in, int Nb, int S, long lon
       RGM_TRY(conv3(c, n.x, n.out, n.H, n.Cin, n.Cin, n.key, 1, nullptr));
     }
   }
+  static const int tiled = getenv("RGM_CONV_OUT_TILED") ? atoi(getenv("RGM_CONV_OUT_TILED")) : 1;
+  static const int out_fuse = getenv("RGM_NORM_OUT_FUSE") ? atoi(getenv("RGM_NORM_OUT_FUSE")) : 1;
+  if (g_gn_fuse && out_fuse && tiled) {   // as in the plain decode: statistics only (kept for the backward), norm_out inside conv_out's staging
+    RGM_TRY(group_norm(c, g.x_last, nullptr, 128 * 128, 128, "decoder.norm_out", 1, 0, g.st_out));
+    return conv_out_launch(h, g.x_last, roll, nullptr, M, Nb, S * 128, -0.95f, s, g.st_out);
+  }
   RGM_TRY(group_norm(c, g.x_last, t1, 128 * 128, 128, "decoder.norm_out", 1, 0, g.st_out));
   return conv_out_launch(h, t1, roll, nullptr, M, Nb, S * 128, -0.95f, s);   // the same kernel as the plain decode: identical rolls
 }
