@@ -1079,6 +1079,7 @@ struct Ctx {
   // a group_norm that is the very next op on that tensor finalises them instead of re-reading the tensor from HBM
   int seq = 0, tp_seq = -1;
   const float* tp_for = nullptr;
+  int final_split = 0;           // the next same-channel ResnetBlock writes its OUTPUT as split rows only (its one consumer is the upsampling conv)
   int gn_slot = 0;               // next free slice of the plan's counters / flags (GemmParams::gn_count); zeroed when slot 0 is taken
   int tp_rows = 128;             // tile height of the conv that left those sums (128: heuristic tiles; 256 / 512: the 256x256 / 512x128 kernels)
 };
@@ -1127,7 +1128,7 @@ int ilog2(int v) {
 // fuse_norm (optional): key of the GroupNorm that consumes this conv's output and nothing else does -- applied (with swish) inside the
 // launch when it qualifies; *fused then tells the caller that `out` already holds the normalised split rows.
 int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const std::string& key, int ups, const float* res,
-          int in_split = 0, const std::string* fuse_norm = nullptr, int* fused = nullptr) {
+          int in_split = 0, const std::string* fuse_norm = nullptr, int* fused = nullptr, int out_split = 0) {
   GemmParams g;
   g.A = in; g.B = c.h->p(key + (in_split ? ".weight.S" : ".weight")); g.ldb = 9 * Cin; g.C = out; g.ldc = Cout;
   g.M = c.M * H * H; g.N = Cout; g.K = 9 * Cin; g.lda = Cin;
@@ -1136,6 +1137,7 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
   g.aload = 1; g.H = H; g.W = H; g.Cin = Cin; g.logH = ilog2(H); g.logW = ilog2(H); g.ups = ups;
   const int my = ++c.seq;
   if (in_split) {
+    g.out_split = out_split;                 // split rows instead of fp32 rows (same bytes): a consumer that is a pre-split GEMM reads them as they are
     g.tile = RGM_EXP_ENV("RGM_CONV_TILE");   // 0 = gemm2's heuristic (timing experiments: common.h)
     int rows = 128;
     if (g.tile == 0 && big_tiles_mode()) {
@@ -1237,12 +1239,12 @@ int resnet(Ctx& c, const float* x, float* b, float* hbuf, float* out, float* t1,
     const std::string n2 = key + "norm2";
     int fused = 0;
     RGM_TRY(conv3(c, t1, b, H, Cin, Cout, key + "conv1", 0, nullptr, 1, &n2, &fused));
-    if (fused) return conv3(c, b, out, H, Cout, Cout, key + "conv2", 0, x, 1);             // b holds swish(norm2(conv1(.))) as split rows
+    if (fused) return conv3(c, b, out, H, Cout, Cout, key + "conv2", 0, x, 1, nullptr, nullptr, c.final_split);   // b holds swish(norm2(conv1(.))) as split rows
   } else {
     RGM_TRY(conv3(c, t1, b, H, Cin, Cout, key + "conv1", 0, nullptr, c.split));
   }
   RGM_TRY(group_norm(c, b, t1, P, Cout, key + "norm2", 1, c.split, st2));
-  if (Cin == Cout) return conv3(c, t1, out, H, Cout, Cout, key + "conv2", 0, x, c.split);  // out = conv2(.) + x
+  if (Cin == Cout) return conv3(c, t1, out, H, Cout, Cout, key + "conv2", 0, x, c.split, nullptr, nullptr, c.split ? c.final_split : 0);  // out = conv2(.) + x
   RGM_TRY(conv3(c, t1, hbuf, H, Cout, Cout, key + "conv2", 0, nullptr, c.split));
   return conv1(c, x, out, c.M * P, Cin, Cout, key + "nin_shortcut", hbuf);                  // out = nin(x) + h
 }
@@ -1366,13 +1368,21 @@ static int decode_impl(rgm_vae* h, const float* in, int Nb, int S, long long n_s
   int H = 16;
   for (int lvl = 3; lvl >= 0; --lvl) {
     const int bo = h->ch * CH_MULT[lvl];
+    static const int presplit_ups = getenv("RGM_UPS_PRESPLIT") ? atoi(getenv("RGM_UPS_PRESPLIT")) : 1;   // 0: the split_rows pass (A/B runs)
+    bool ups_in_split = false;
     for (int ib = 0; ib < 3; ++ib) {
+      // the last block of a level that is followed by an upsampling conv has that conv as its ONLY consumer: it writes split rows straight away
+      c.final_split = (ib == 2 && lvl != 0 && c.split && presplit_ups && C == bo) ? 1 : 0;
+      ups_in_split = c.final_split != 0;
       RGM_TRY(resnet(c, cur, t1, t2, H, C, bo, d + "up." + std::to_string(lvl) + ".block." + std::to_string(ib) + "."));
+      c.final_split = 0;
       C = bo;
     }
     if (lvl != 0) {
       H *= 2;
-      if (c.split) {   // the upsample conv reads the raw residual stream: one HBM pass turns it into split rows
+      if (c.split && ups_in_split) {
+        RGM_TRY(conv3(c, cur, t1, H, C, C, d + "up." + std::to_string(lvl) + ".upsample.conv", 1, nullptr, 1));
+      } else if (c.split) {   // the upsample conv reads the raw residual stream: one HBM pass turns it into split rows
         RGM_TRY(split_rows_launch(cur, t2, (long long)c.M * (H / 2) * (H / 2), C, C, C, s));
         RGM_TRY(conv3(c, t2, t1, H, C, C, d + "up." + std::to_string(lvl) + ".upsample.conv", 1, nullptr, 1));
       } else {
