@@ -179,6 +179,11 @@ struct GemmParams {
   int prec = -1;
   // gemm2 (pre-split operands): write C in split-row format (N bf16 hi | N bf16 lo per row) for the next GEMM
   int out_split = 0;
+  // gemm2, plain epilogue (bias + activation, nothing read per row) with out_split: a SECOND output -- C2 (row stride ldc2) takes the split rows
+  // of act(v) while C takes the fp32 rows of the pre-activation v = alpha * acc + bias (the value-and-gradient chain of a classifier keeps
+  // fc1's pre-activation for the backward and feeds fc2 its GELU: one launch instead of GEMM + an elementwise pass)
+  float* C2 = nullptr;
+  int ldc2 = 0;
   // gemm2, 128-row tiles: also write per-tile GroupNorm partial sums of the OUTPUT (after bias / residual):
   // stats[(tile_m * (N / stats_gw) + col / stats_gw) * 2 + {0, 1}] = sum, sum of squares over the tile's rows of the stats_gw
   // (4, 8 or 16) channels of group col / stats_gw -- fp64, fixed-order tree, no atomics (deterministic, and the same to 1e-16

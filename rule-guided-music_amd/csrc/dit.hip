@@ -837,8 +837,17 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
       RGM_TRY(split_rows_launch(ao, p.t1, M, D, D, D, s));          // the backward needs O in fp32, proj its split image
       RGM_TRY(lin_split(h, p.t1, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x1, M, D, D, 0, 0, m + 2 * D, L, T, xi, s));
       RGM_TRY(layernorm_modulate_launch(x1, p.xm, M, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, s, 1));
-      RGM_TRY(lin_split(h, p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), pre, M, 4 * D, D, 0, 0, nullptr, 0, 1, nullptr, s));
-      RGM_TRY(act_rows_launch(pre, p.hid, M, 4 * D, 2, s, 1));
+      static const int fc1_dual = getenv("RGM_FC1_DUAL") ? atoi(getenv("RGM_FC1_DUAL")) : 1;   // 0: GEMM + elementwise pass (A/B runs)
+      if (fc1_dual) {   // one launch: the pre-activation (fp32, kept for the backward) and its GELU as split rows (fc2's operand)
+        GemmParams g;
+        g.A = p.xm; g.lda = D; g.B = h->p(b + "mlp.fc1.weight.S"); g.ldb = D; g.C = pre; g.ldc = 4 * D;
+        g.M = M; g.N = 4 * D; g.K = D; g.bias = h->p(b + "mlp.fc1.bias"); g.act = 2; g.out_split = 1;
+        g.C2 = p.hid; g.ldc2 = 4 * D;
+        RGM_TRY(gemm2_launch(g, s));
+      } else {
+        RGM_TRY(lin_split(h, p.xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), pre, M, 4 * D, D, 0, 0, nullptr, 0, 1, nullptr, s));
+        RGM_TRY(act_rows_launch(pre, p.hid, M, 4 * D, 2, s, 1));
+      }
       RGM_TRY(lin_split(h, p.hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), xn, M, D, 4 * D, 0, 0, m + 5 * D, L, T, x1, s));
       continue;
     }

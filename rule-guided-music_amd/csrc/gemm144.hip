@@ -252,7 +252,7 @@ char* g_zero144 = nullptr;
 
 // shapes and epilogues this kernel carries (gemm2_launch asks before it picks tile 81)
 bool gemm144_supports(const GemmParams& p) {
-  if (p.aload || p.stats || p.act >= 3 || p.aux || p.N % BN != 0 || p.K % 32 != 0 || p.K < 64) return false;
+  if (p.aload || p.stats || p.act >= 3 || p.aux || p.C2 || p.N % BN != 0 || p.K % 32 != 0 || p.K < 64) return false;
   if (((p.N | p.ldc | p.ldres | p.gate_ld) & 3) != 0) return false;
   const uintptr_t al = (uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate;
   if ((al & 15) != 0 || ((p.sC | p.sRes | p.sBias) & 3) != 0) return false;

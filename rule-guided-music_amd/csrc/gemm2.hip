@@ -869,6 +869,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
               const float4 a4 = a4s[u];
               if (row < p.M && col_ok) {
                 float v[4] = {a4.x * p.alpha + bv.x, a4.y * p.alpha + bv.y, a4.z * p.alpha + bv.z, a4.w * p.alpha + bv.w};
+                if constexpr (SPLIT) {
+                  if (p.C2) out16(Cb + (long long)row * p.ldc + col, v);       // second output: the pre-activation as fp32 rows in C
+                }
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) v[q4] = ACT == 1 ? silu_f(v[q4]) : (ACT == 2 ? gelu_tanh_fast_f(v[q4]) : v[q4]);
                 if constexpr (SPLIT) {
@@ -879,7 +882,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                     hi[q4] = (split_t)v[q4];
                     lo[q4] = (split_t)(v[q4] - (float)hi[q4]);
                   }
-                  split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
+                  split_t* rowp = p.C2 ? reinterpret_cast<split_t*>(p.C2 + (long long)z * p.sC + (long long)row * p.ldc2)
+                                       : reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
                   out8(rowp + split_idx(col), hi);
                   out8(rowp + split_idx(col) + 32, lo);
                 } else {
@@ -1554,6 +1558,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ P, GemmParams p, 
 // number of K slices for a dense, unbatched GEMM whose 128x64 grid leaves most of the chip idle; 1 = do not split
 static int splitk_factor(const GemmParams& p) {
   if (!p.sk_ws) return 1;                        // the partial sums live in caller-provided scratch (include/rgm.h conventions)
+  if (p.C2) return 1;                            // two outputs: the plain epilogue only
   if (p.aload || p.batch != 1 || p.tile != 0 || p.act >= 3 || (p.N & 3) || (p.ldc & 3) || (p.ldres & 3) || (p.gate_ld & 3)) return 1;
   if ((((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) != 0) return 1;
   const long long t64 = (long long)cdiv(p.M, 128) * cdiv(p.N, 64);
@@ -1667,6 +1672,9 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   RGM_REQUIRE(((uintptr_t)p.A & 15) == 0 && ((uintptr_t)p.B & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0,
               "gemm2: operands must be 16-byte aligned with ld%%4==0");
   RGM_REQUIRE(!p.out_split || ((p.N & 31) == 0 && (p.ldc & 31) == 0), "gemm2: split-row output needs N%%32==0 (N=%d)", p.N);
+  RGM_REQUIRE(!p.C2 || (p.out_split && !p.gate && !p.res && !p.stats && !p.aload && p.act < 3 && !p.ln_out && p.batch == 1 && (p.ldc2 & 31) == 0 &&
+                        ((p.N | p.ldc) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.C2 | (uintptr_t)p.bias) & 15) == 0),
+              "gemm2: the second output (C2) belongs to the plain split-row epilogue: bias + activation, 16-byte aligned rows, no gate / residual / statistics");
   RGM_REQUIRE(!p.stats || ((p.stats_gw == 4 || p.stats_gw == 8 || p.stats_gw == 16) && p.N % 64 == 0 && p.batch == 1 &&
                            ((p.tile == 0 && p.aload) || p.tile == 21 || p.tile == 22 || p.tile == 43 || p.tile == 44 || p.tile == 71 || p.tile == 72) &&
                            ((p.N | p.ldc | p.ldres | p.gate_ld | p.ldaux) & 3) == 0 &&
@@ -1723,7 +1731,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     const long long total = (long long)tm * tn;
     const double waste = (double)((long long)tn * 256 - p.N) / ((double)tn * 256);
     if (waste <= 0.12) {
-      if (KT >= 72 && p.sk_ws && total < 200) {
+      if (KT >= 72 && p.sk_ws && !p.C2 && total < 200) {
         int best = 1;
         for (int c = 2; c <= 8; ++c) {
           if (KT % c || KT / c < g_co_kt || total * c > 256) continue;
@@ -1754,7 +1762,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
       q.tile = 71;
       return gemm2_launch(q, s);
     }
-    if (total < 200 && KT >= 72 && p.sk_ws && waste <= 0.12) {
+    if (total < 200 && KT >= 72 && p.sk_ws && !p.C2 && waste <= 0.12) {
       int best = 1;
       for (int c = 2; c <= 8; ++c) {
         if (KT % c || KT / c < 24 || total * c > 256) continue;
@@ -1778,6 +1786,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
         pr.N = p.N - n_main;
         pr.B = p.B + (long long)n_main * p.ldb;
         pr.C = p.C + n_main;                       // split-row output: a 256-column block is 256 floats wide as well
+        if (p.C2) pr.C2 = p.C2 + n_main;
         if (p.bias) pr.bias = p.bias + n_main;
         if (p.res) pr.res = p.res + n_main;
         if (p.gate) pr.gate = p.gate + n_main;
@@ -1800,6 +1809,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
         pr.M = p.M - (int)rows_main;
         pr.A = p.A + rows_main * p.lda;
         pr.C = p.C + rows_main * p.ldc;
+        if (p.C2) pr.C2 = p.C2 + rows_main * p.ldc2;
         if (p.res) pr.res = p.res + rows_main * p.ldres;
         if (p.gate) pr.gate = p.gate + (rows_main / p.rows_per_gate) * p.gate_ld;
         RGM_TRY(gemm2_launch(pm, s));
@@ -1808,7 +1818,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     }
   }
   if (S == 1 && !p.stats) S = splitk_factor(p);
-  if (S == 1 && p.tile == 0 && p.sk_ws && !p.stats && !p.aload && p.batch == 1 && p.act < 3 && (p.K >> 5) >= 96 &&
+  if (S == 1 && p.tile == 0 && p.sk_ws && !p.C2 && !p.stats && !p.aload && p.batch == 1 && p.act < 3 && (p.K >> 5) >= 96 &&
       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 && (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0) {
     // long-K GEMM on a grid that leaves the second 128x128 workgroup slot of most CUs empty (fc2 at B = 16: 288 tiles on 512
     // slots, 144 K-tiles each): K slices as a batch fill whole rounds.  Cost model in K-tile times, from tools/gemm_sweep.py
