@@ -10,11 +10,27 @@
 
 namespace rgm {
 
+__device__ __forceinline__ void store4(float* __restrict__ out, long long row, int D, int c, float4 v, int out_split) {
+  if (out_split) {
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+    hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+    lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
+    lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
+    split_t* rp = reinterpret_cast<split_t*>(out + row * D);
+    *reinterpret_cast<bf16x4*>(rp + split_idx(c)) = hi;
+    *reinterpret_cast<bf16x4*>(rp + split_idx(c) + 32) = lo;
+  } else {
+    *reinterpret_cast<float4*>(out + row * D + c) = v;
+  }
+}
+
 template <int MAXV>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          const float* __restrict__ res, float* __restrict__ out, int M, int D,
                                                          float eps, const float* __restrict__ weight,
-                                                         const float* __restrict__ scale, int mod_ld, int rows_per_batch) {
+                                                         const float* __restrict__ scale, int mod_ld, int rows_per_batch,
+                                                         const float* __restrict__ gate2, float* __restrict__ gated) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
@@ -75,40 +91,32 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
       o = make_float4(o.x + r.x, o.y + r.y, o.z + r.z, o.w + r.w);
     }
     orow[c] = o;
+    if (gated) {   // the next GEMM's operand in the same pass: out * gate2 (gate_rows_kernel's product) as split rows
+      const float4 g2 = reinterpret_cast<const float4*>(gate2 + mo)[c];
+      store4(gated, row, D, c * 4, make_float4(o.x * g2.x, o.y * g2.y, o.z * g2.z, o.w * g2.w), 1);
+    }
   }
 }
 
 int ln_mod_bwd_launch(const float* dy, const float* x, const float* res, float* out, int M, int D, float eps,
-                      const float* weight, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s) {
+                      const float* weight, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s, const float* gate2,
+                      float* gated) {
   RGM_REQUIRE(M > 0 && (D & 3) == 0 && D <= 2048, "ln_mod_bwd: D=%d", D);
+  RGM_REQUIRE(!gated || (gate2 && (D & 31) == 0), "ln_mod_bwd: the gated split output needs a gate and D%%32==0");
   if (rows_per_batch <= 0) rows_per_batch = 1;
   dim3 grid(cdiv(M, 4)), block(256);
   const int nv = D / 4;
   if (nv <= 128)
-    hipLaunchKernelGGL(ln_mod_bwd_kernel<2>, grid, block, 0, s, dy, x, res, out, M, D, eps, weight, scale, mod_ld, rows_per_batch);
+    hipLaunchKernelGGL(ln_mod_bwd_kernel<2>, grid, block, 0, s, dy, x, res, out, M, D, eps, weight, scale, mod_ld, rows_per_batch, gate2, gated);
   else if (nv <= 320)
-    hipLaunchKernelGGL(ln_mod_bwd_kernel<5>, grid, block, 0, s, dy, x, res, out, M, D, eps, weight, scale, mod_ld, rows_per_batch);
+    hipLaunchKernelGGL(ln_mod_bwd_kernel<5>, grid, block, 0, s, dy, x, res, out, M, D, eps, weight, scale, mod_ld, rows_per_batch, gate2, gated);
   else
-    hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, grid, block, 0, s, dy, x, res, out, M, D, eps, weight, scale, mod_ld, rows_per_batch);
+    hipLaunchKernelGGL(ln_mod_bwd_kernel<8>, grid, block, 0, s, dy, x, res, out, M, D, eps, weight, scale, mod_ld, rows_per_batch, gate2, gated);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
 // write 4 consecutive values of a row either as fp32 or in the split-row format of the pre-split GEMMs (common.h split_idx)
-__device__ __forceinline__ void store4(float* __restrict__ out, long long row, int D, int c, float4 v, int out_split) {
-  if (out_split) {
-    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
-    bf16x4 hi, lo;
-    hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
-    lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
-    lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
-    split_t* rp = reinterpret_cast<split_t*>(out + row * D);
-    *reinterpret_cast<bf16x4*>(rp + split_idx(c)) = hi;
-    *reinterpret_cast<bf16x4*>(rp + split_idx(c) + 32) = lo;
-  } else {
-    *reinterpret_cast<float4*>(out + row * D + c) = v;
-  }
-}
 
 __global__ void gate_rows_kernel(const float* __restrict__ dx, const float* __restrict__ gate, float* __restrict__ out,
                                  long long total4, int D, int gate_ld, int rows_per_batch, int out_split) {

@@ -27,7 +27,8 @@ int cond_finish_launch(const float* c, const float* table, const int32_t* y, flo
 int fill_cls_launch(const float* cls, float* x, int N, int T, int D, hipStream_t s);
 int pool_rows_launch(const float* x, float* out, int N, int T, int D, int first, int groups, int per, hipStream_t s);
 int ln_mod_bwd_launch(const float* dy, const float* x, const float* res, float* out, int M, int D, float eps,
-                      const float* weight, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s);
+                      const float* weight, const float* scale, int mod_ld, int rows_per_batch, hipStream_t s,
+                      const float* gate2 = nullptr, float* gated = nullptr);   // gated: also out * gate2[row / rows_per_batch] as split rows
 int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int D, int gate_ld, int rows_per_batch, hipStream_t s,
                      int out_split = 0);
 int act_rows_launch(const float* in, float* out, long long rows, int D, int act, hipStream_t s, int out_split = 0);
@@ -888,17 +889,27 @@ static int grad_blocks_backward(rgm_dit* h, const GPlan& p, hipStream_t s) {
     const float* xi = p.xs + i * MD;
     const float* x1 = p.x1s + i * MD;
     if (rgm_get_gemm_precision() == 2) {   // same chain on the pre-split kernel: every GEMM operand is produced as split rows
-      RGM_TRY(gate_rows_launch(p.dx, m + 5 * D, p.t1, M, D, L, T, s, 1));
+      // the gated split operand of a dgrad GEMM comes out of the LayerNorm backward in front of it (one pass less each); only the very first
+      // one, behind the head's backward, is a pass of its own (RGM_BWD_GATE_FUSE=0: all of them, for A/B runs)
+      static const int gate_fuse = getenv("RGM_BWD_GATE_FUSE") ? atoi(getenv("RGM_BWD_GATE_FUSE")) : 1;
+      if (!gate_fuse || i == c.depth - 1) RGM_TRY(gate_rows_launch(p.dx, m + 5 * D, p.t1, M, D, L, T, s, 1));
       RGM_TRY(dgrad2(h, b + "mlp.fc2.weight", p.t1, D, p.dbig, 4 * D, M, p.pres + i * MD * 4, 4 * D, 3, 1, s));
       RGM_TRY(dgrad2(h, b + "mlp.fc1.weight", p.dbig, 4 * D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
-      RGM_TRY(ln_mod_bwd_launch(p.dsmall, x1, p.dx, p.dx1, M, D, 1e-6f, nullptr, m + 4 * D, L, T, s));
-      RGM_TRY(gate_rows_launch(p.dx1, m + 2 * D, p.t1, M, D, L, T, s, 1));
+      if (gate_fuse) {
+        RGM_TRY(ln_mod_bwd_launch(p.dsmall, x1, p.dx, p.dx1, M, D, 1e-6f, nullptr, m + 4 * D, L, T, s, m + 2 * D, p.t1));
+      } else {
+        RGM_TRY(ln_mod_bwd_launch(p.dsmall, x1, p.dx, p.dx1, M, D, 1e-6f, nullptr, m + 4 * D, L, T, s));
+        RGM_TRY(gate_rows_launch(p.dx1, m + 2 * D, p.t1, M, D, L, T, s, 1));
+      }
       RGM_TRY(dgrad2(h, b + "attn.proj.weight", p.t1, D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
       RGM_TRY(rotary_attention_bwd_launch(p.qkvs + i * MD * 3, p.aos + i * MD, p.dsmall, p.lses + i * lse_sz, p.dqkv, h->cos_tab,
                                           h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s));
       RGM_TRY(split_rows_launch(p.dqkv, p.dbig, M, 3 * D, 3 * D, 3 * D, s));
       RGM_TRY(dgrad2(h, b + "attn.qkv.weight", p.dbig, 3 * D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
-      RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s));
+      if (gate_fuse && i > 0)     // ... with block i - 1's fc2 gate: the operand of the next iteration's first dgrad
+        RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s, m - 6 * D + 5 * D, p.t1));
+      else
+        RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s));
       continue;
     }
     RGM_TRY(gate_rows_launch(p.dx, m + 5 * D, p.t1, M, D, L, T, s));                                   // d f2 = g2 * dx
