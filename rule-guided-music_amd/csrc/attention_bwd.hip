@@ -40,11 +40,38 @@ __device__ __forceinline__ float4 rotate4(float4 v, const float* __restrict__ ct
 // key tiles w, w + 8, ...), the partial dQ tiles meet in LDS (over the K / V images, behind a barrier) and are summed in wave order.  For
 // the grids that leave the chip empty -- the classifiers at the samplers' batches: 6 heads x B samples of 257 tokens = 9 query tiles on 8
 // waves, i.e. two tile-times on 24 .. 192 of 256 CUs -- this turns 2 x 9 serial key tiles into 2 and fills the CUs (launch_bwd).
+// d(qkv) rows go out as fp32 or -- for a pre-split dgrad GEMM right behind (dit.hip grad chain) -- as split rows (common.h split_idx);
+// col = column of the value's first channel inside the 3 D wide row, a multiple of 4 (the four channels share a 32-block)
+__device__ __forceinline__ void dqkv_store4(float* __restrict__ dqkv, long long row, int D3, int col, const float4& v, int osplit) {
+  if (osplit) {
+    typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 hi, lo;
+    hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+    lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
+    lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
+    split_t* rp = reinterpret_cast<split_t*>(dqkv + row * D3);
+    *reinterpret_cast<bf16x4*>(rp + split_idx(col)) = hi;
+    *reinterpret_cast<bf16x4*>(rp + split_idx(col) + 32) = lo;
+  } else {
+    *reinterpret_cast<float4*>(dqkv + row * D3 + col) = v;
+  }
+}
+__device__ __forceinline__ void dqkv_store1(float* __restrict__ dqkv, long long row, int D3, int col, float v, int osplit) {
+  if (osplit) {
+    split_t* rp = reinterpret_cast<split_t*>(dqkv + row * D3);
+    const split_t hi = (split_t)v;
+    rp[split_idx(col)] = hi;
+    rp[split_idx(col) + 32] = (split_t)(v - (float)hi);
+  } else {
+    dqkv[row * D3 + col] = v;
+  }
+}
+
 template <int HD, int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, const float* __restrict__ cos_tab,
-                                                          const float* __restrict__ sin_tab, int T, int heads, int rot_half, int lone) {
+                                                          const float* __restrict__ sin_tab, int T, int heads, int rot_half, int lone, int osplit) {
   constexpr int HDP = HD + 4, KB = HD / 8, DT = (HD + 31) / 32, TP = NKT * 32;   // hd = 72: the third channel tile is partial
   // (its operand reads run past a row into the next row / the following array: finite data feeding accumulator rows that are never stored)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -158,11 +185,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
         }
         float4 v = make_float4(a.x * scale, a.y * scale, a.z * scale, a.w * scale);
         if (d < R) v = rotate4(v, cos_tab, sin_tab, qq * rot_half + (d >> 1), true);
-        *reinterpret_cast<float4*>(dqkv + ((long long)n * T + qq) * D3 + head * HD + d) = v;
+        dqkv_store4(dqkv, (long long)n * T + qq, D3, head * HD + d, v, osplit);
       }
     } else
     if (q < T) {   // dQ^T[d][query]: lane = query row, registers 4g..4g+3 = channels dt*32 + 8g + 4hh ..+3
-      float* op = dqkv + ((long long)n * T + q) * D3 + head * HD;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -171,7 +197,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
           if (d >= HD) continue;
           float4 v = make_float4(dq[dt][4 * g] * scale, dq[dt][4 * g + 1] * scale, dq[dt][4 * g + 2] * scale, dq[dt][4 * g + 3] * scale);
           if (d < R) v = rotate4(v, cos_tab, sin_tab, q * rot_half + (d >> 1), true);
-          *reinterpret_cast<float4*>(op + d) = v;
+          dqkv_store4(dqkv, (long long)n * T + q, D3, head * HD + d, v, osplit);
         }
     }
   }
@@ -221,7 +247,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
       for (int d0 = lane * 4; d0 < HD; d0 += 256) {
         float4 v = *reinterpret_cast<const float4*>(outr + d0);
         if (d0 < R) v = rotate4(v, cos_tab, sin_tab, qs_ * rot_half + (d0 >> 1), true);
-        *reinterpret_cast<float4*>(dqkv + ((long long)n * T + qs_) * D3 + head * HD + d0) = v;
+        dqkv_store4(dqkv, (long long)n * T + qs_, D3, head * HD + d0, v, osplit);
       }
     }
   }
@@ -233,7 +259,7 @@ template <int HD, int NKT, bool SPLIT>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, const float* __restrict__ cos_tab,
-                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half, int lone) {
+                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half, int lone, int osplit) {
   constexpr int HDP = HD + 4, KB = HD / 8, DT = (HD + 31) / 32, TP = NKT * 32;   // hd = 72: the third channel tile is partial
   // (its operand reads run past a row into the next row / the following array: finite data feeding accumulator rows that are never stored)
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -398,11 +424,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
           a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
         if (which == 0 && d < R) a = rotate4(a, cos_tab, sin_tab, kk * rot_half + (d >> 1), true);
-        *reinterpret_cast<float4*>(dqkv + ((long long)n * T + kk) * D3 + head * HD + (which == 0 ? D : 2 * D) + d) = a;
+        dqkv_store4(dqkv, (long long)n * T + kk, D3, head * HD + (which == 0 ? D : 2 * D) + d, a, osplit);
       }
     } else
     if (key_ok) {
-      float* op = dqkv + ((long long)n * T + key) * D3 + head * HD;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
@@ -411,8 +436,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
           if (d >= HD) continue;
           float4 kv = make_float4(dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
           if (d < R) kv = rotate4(kv, cos_tab, sin_tab, key * rot_half + (d >> 1), true);
-          *reinterpret_cast<float4*>(op + D + d) = kv;
-          *reinterpret_cast<float4*>(op + 2 * D + d) = make_float4(dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+          dqkv_store4(dqkv, (long long)n * T + key, D3, head * HD + D + d, kv, osplit);
+          dqkv_store4(dqkv, (long long)n * T + key, D3, head * HD + 2 * D + d, make_float4(dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]), osplit);
         }
     }
   }
@@ -451,20 +476,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         pr[qi] = pv;
         dsr[qi] = pv * (dpa - Ds[qi < T ? qi : 0]);
       }
-      float* op = dqkv + ((long long)n * T + ks_) * D3 + head * HD;
       for (int d = lane; d < HD; d += 64) {
         float av = 0.f, ak = 0.f;
         for (int qi = 0; qi < T; ++qi) {
           av = fmaf(pr[qi], Gs[qi * HDP + d], av);
           ak = fmaf(dsr[qi], Qs[qi * HDP + d], ak);
         }
-        op[2 * D + d] = av;
+        dqkv_store1(dqkv, (long long)n * T + ks_, D3, head * HD + 2 * D + d, av, osplit);
         outr[d] = ak;
       }
       for (int d0 = lane * 4; d0 < HD; d0 += 256) {
         float4 v = *reinterpret_cast<const float4*>(outr + d0);
         if (d0 < R) v = rotate4(v, cos_tab, sin_tab, ks_ * rot_half + (d0 >> 1), true);
-        *reinterpret_cast<float4*>(op + D + d0) = v;
+        dqkv_store4(dqkv, (long long)n * T + ks_, D3, head * HD + D + d0, v, osplit);
       }
     }
   }
@@ -474,7 +498,7 @@ static int g_attn_split = -1;   // rgm_set_attn_split: -1 auto, 0 never, 1 alway
 
 template <int HD, int NKT>
 static int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const float* ct,
-                      const float* st, int N, int T, int heads, int rot_half, hipStream_t s) {
+                      const float* st, int N, int T, int heads, int rot_half, hipStream_t s, int osplit) {
   constexpr int TP = NKT * 32, HDP = HD + 4;
   // one workgroup per CU (common.h attn_prepare_kernel): the same single-pass structure as the forward kernels
   const size_t images = (size_t)2 * TP * HDP * sizeof(float);
@@ -495,9 +519,9 @@ static int launch_bwd(const float* qkv, const float* o, const float* d_o, const 
       RGM_TRY(attn_prepare_kernel(kkv, 512, lds_kv, "attn_bwd_dkv_kernel (per key tile)"));
       prepared = true;
     }
-    hipLaunchKernelGGL(kq, dim3(N * heads * nt), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, 0);
+    hipLaunchKernelGGL(kq, dim3(N * heads * nt), dim3(512), lds_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, 0, osplit);
     RGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(kkv, dim3(N * heads * nt), dim3(512), lds_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, 0);
+    hipLaunchKernelGGL(kkv, dim3(N * heads * nt), dim3(512), lds_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, 0, osplit);
     RGM_LAUNCH_CHECK();
     return RGM_OK;
   }
@@ -517,28 +541,29 @@ static int launch_bwd(const float* qkv, const float* o, const float* d_o, const 
   }
   const size_t use_q = lds_q <= 160 * 1024 ? lds_q : attn_lds_one_per_cu(images);
   const size_t use_kv = lds_kv <= 160 * 1024 ? lds_kv : attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float));
-  hipLaunchKernelGGL(kq, dim3(N * heads), dim3(512), use_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, lone);
+  hipLaunchKernelGGL(kq, dim3(N * heads), dim3(512), use_q, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, lone, osplit);
   RGM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(kkv, dim3(N * heads), dim3(512), use_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, lone);
+  hipLaunchKernelGGL(kkv, dim3(N * heads), dim3(512), use_kv, s, qkv, o, d_o, lse, dqkv, ct, st, T, heads, rot_half, lone, osplit);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 
 int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                 const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd, int rot_half,
-                                hipStream_t s) {
+                                hipStream_t s, int osplit) {
+  RGM_REQUIRE(!osplit || (heads * hd) % 32 == 0, "attention backward: split rows need 3 x heads x head_dim in 32-blocks");
   RGM_REQUIRE(hd == 64 || hd == 72, "attention backward: head_dim %d (64 = the S/B family, 72 = XL)", hd);
   RGM_REQUIRE(T > 0 && T <= 288, "attention backward: T=%d", T);
   const int nkt = (T + 31) / 32;
   if (hd == 72) {   // XL eps-network (DPS guidance): Q/dO resp. K/V of one head + lse/D = 157.7 KB of LDS at T = 256
     RGM_REQUIRE(nkt <= 8, "attention backward: head_dim 72 supports T <= 256, got %d", T);
-    if (nkt <= 4) return launch_bwd<72, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
-    return launch_bwd<72, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
+    if (nkt <= 4) return launch_bwd<72, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
+    return launch_bwd<72, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
   }
-  if (nkt <= 4) return launch_bwd<64, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
-  if (nkt <= 5) return launch_bwd<64, 5>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
-  if (nkt <= 8) return launch_bwd<64, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
-  return launch_bwd<64, 9>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s);
+  if (nkt <= 4) return launch_bwd<64, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
+  if (nkt <= 5) return launch_bwd<64, 5>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
+  if (nkt <= 8) return launch_bwd<64, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
+  return launch_bwd<64, 9>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
 }
 
 int attn_split_mode() { return g_attn_split; }
@@ -558,5 +583,5 @@ extern "C" int rgm_rotary_attention_bwd(const float* qkv, const float* o, const 
                                         const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
                                         int rot_half, void* stream) {
   RGM_REQUIRE(qkv && o && d_o && lse && dqkv && cos_tab && sin_tab, "attention backward: null tensor");
-  return rgm::rotary_attention_bwd_launch(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream);
+  return rgm::rotary_attention_bwd_launch(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, hd, rot_half, (hipStream_t)stream, 0);
 }

@@ -244,7 +244,7 @@ int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const
 // attention backward (attention_bwd.hip): dqkv (N*T, 3*heads*hd) from dO, the saved qkv / O / lse
 int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv,
                                 const float* cos_tab, const float* sin_tab, int N, int T, int heads, int hd,
-                                int rot_half, hipStream_t s);
+                                int rot_half, hipStream_t s, int osplit = 0);   // osplit: d(qkv) as split rows (a pre-split dgrad GEMM reads them next)
 int transpose_launch(const float* in, float* out, int R, int Cc, int out_ld, int batch, hipStream_t s);
 int attn_split_mode();   // rgm_set_attn_split (attention_bwd.hip): -1 auto, 0 never, 1 always
 constexpr int ATTN_SPLIT_MAX_PAIRS = 96;   // auto: per-tile attention workgroups up to this many (sample, head) pairs (B <= 16 for the 6-head classifiers)

@@ -902,9 +902,15 @@ static int grad_blocks_backward(rgm_dit* h, const GPlan& p, hipStream_t s) {
         RGM_TRY(gate_rows_launch(p.dx1, m + 2 * D, p.t1, M, D, L, T, s, 1));
       }
       RGM_TRY(dgrad2(h, b + "attn.proj.weight", p.t1, D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
-      RGM_TRY(rotary_attention_bwd_launch(p.qkvs + i * MD * 3, p.aos + i * MD, p.dsmall, p.lses + i * lse_sz, p.dqkv, h->cos_tab,
-                                          h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s));
-      RGM_TRY(split_rows_launch(p.dqkv, p.dbig, M, 3 * D, 3 * D, 3 * D, s));
+      static const int bwd_split = getenv("RGM_ATTN_BWD_SPLIT") ? atoi(getenv("RGM_ATTN_BWD_SPLIT")) : 1;   // 0: fp32 rows + a split pass (A/B runs)
+      if (bwd_split && D % 32 == 0) {   // d(qkv) leaves the attention backward as split rows: the operand of the dgrad GEMM below
+        RGM_TRY(rotary_attention_bwd_launch(p.qkvs + i * MD * 3, p.aos + i * MD, p.dsmall, p.lses + i * lse_sz, p.dbig, h->cos_tab,
+                                            h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s, 1));
+      } else {
+        RGM_TRY(rotary_attention_bwd_launch(p.qkvs + i * MD * 3, p.aos + i * MD, p.dsmall, p.lses + i * lse_sz, p.dqkv, h->cos_tab,
+                                            h->sin_tab, N, T, c.heads, h->hd, h->rot_half, s));
+        RGM_TRY(split_rows_launch(p.dqkv, p.dbig, M, 3 * D, 3 * D, 3 * D, s));
+      }
       RGM_TRY(dgrad2(h, b + "attn.qkv.weight", p.dbig, 3 * D, p.dsmall, D, M, nullptr, 0, 0, 0, s));
       if (gate_fuse && i > 0)     // ... with block i - 1's fc2 gate: the operand of the next iteration's first dgrad
         RGM_TRY(ln_mod_bwd_launch(p.dsmall, xi, p.dx1, p.dx, M, D, 1e-6f, nullptr, m + D, L, T, s, m - 6 * D + 5 * D, p.t1));
