@@ -45,10 +45,16 @@ class CondIndSimple(SimpleWork):
             buf = th.zeros(Bn * xs[0].numel() + Bn * halves[0].numel(), dtype=th.float32, device=long_x.device)
             full_eps = buf[:Bn * xs[0].numel()].view(xs.shape)
             half_eps = buf[Bn * xs[0].numel():].view(halves.shape)
+            # the zero-filled buffers assume eps has its input's shape (a learn_sigma network returns 2C channels: the caller keeps such
+            # models replicated -- gaussian_diffusion._search_partition); checked here so that a mismatch fails at its cause
             if mine_f.numel():
-                full_eps[mine_f] = eps_scalar_t_fn(xs[mine_f].contiguous(), tt[mine_f].contiguous(), y=None if yy is None else yy[mine_f].contiguous()).float()
+                e = eps_scalar_t_fn(xs[mine_f].contiguous(), tt[mine_f].contiguous(), y=None if yy is None else yy[mine_f].contiguous()).float()
+                assert e.shape[1:] == xs.shape[1:], f"window sharding needs eps of the input's shape, got {tuple(e.shape)} for {tuple(xs.shape)}"
+                full_eps[mine_f] = e
             if mine_h.numel():
-                half_eps[mine_h] = eps_scalar_t_fn(halves[mine_h].contiguous(), tt[mine_h].contiguous(), y=None if yy is None else yy[mine_h].contiguous()).float()
+                e = eps_scalar_t_fn(halves[mine_h].contiguous(), tt[mine_h].contiguous(), y=None if yy is None else yy[mine_h].contiguous()).float()
+                assert e.shape[1:] == halves.shape[1:], f"window sharding needs eps of the input's shape, got {tuple(e.shape)} for {tuple(halves.shape)}"
+                half_eps[mine_h] = e
             batch_shard.reduce_windows(buf)
             return merge_windows(full_eps, half_eps, ov, n, circle=False, is_avg=False)
 

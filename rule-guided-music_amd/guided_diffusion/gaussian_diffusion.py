@@ -267,6 +267,18 @@ class GaussianDiffusion:
         sample, x0 = batch_shard.gather_rows([out["sample"].float(), out["pred_xstart"].float()])
         return {"sample": sample, "pred_xstart": x0}
 
+    def _search_partition(self, B, has_cond, record=False):
+        """(rows, roles) of this rank for the per-sample forwards of an SCG search step, (None, None) = replicated.  PREVIOUS_X stays
+        replicated: _model_eps leaves the network's x_{t-1} / x_0 OF THE ROWS IT RAN in self._prevx / self._prevx_x0, and _prevx_fix
+        (p_sample, every rank, full batch) needs them for every row (round-4 advisor finding: the row partition tripped its shape check)."""
+        if not (self.scg_shard and self.batch_shard and self._rows is None and not record and not self._learned()):
+            return None, None
+        if self.model_mean_type == ModelMeanType.PREVIOUS_X:
+            return None, None
+        part = batch_shard.partition_rows(B)
+        roles = batch_shard.partition_roles(B) if (part is not None and has_cond) else None
+        return part, roles
+
     def _search_step_inputs(self, model, cond_fn, x, t, model_kwargs, denoised_fn, edit_kwargs, clip_denoised, record=False,
                             grad_on_edit_rows=True):
         """(eps after the edit replacement, guidance gradient or None) of an SCG search step.  These two forwards are per-sample work
@@ -305,11 +317,7 @@ class GaussianDiffusion:
                 grad = the_grad()
             return eps, grad
 
-        part = roles = None
-        if self.scg_shard and self.batch_shard and self._rows is None and not record and not self._learned():
-            part = batch_shard.partition_rows(B)
-            if cond_fn is not None and self.model_mean_type != ModelMeanType.PREVIOUS_X:
-                roles = batch_shard.partition_roles(B)
+        part, roles = self._search_partition(B, cond_fn is not None, record)
         if part is None:
             return run(x, t, model_kwargs, edit_kwargs)
         if B == 1 and roles is None and cond_fn is None and edit_kwargs is None and batch_shard.window_ranks() > 1:

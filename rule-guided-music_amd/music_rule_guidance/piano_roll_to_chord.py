@@ -77,24 +77,66 @@ class SimpleMIDI:
         return max(ends) if ends else 0.0
 
     # ------------------------------------------------------------------ writer
-    def write(self, filename):
-        tick = lambda t: int(round(t * TICKS_PER_SECOND))  # noqa: E731
-        chunks = [_track([(0, 0, b"\xff\x51\x03" + struct.pack(">I", TEMPO_US)[1:]),
-                          (0, 1, b"\xff\x58\x04\x04\x02\x18\x08")])]
+    # Message stream = what the reference's vendored pretty_midi fork hands to mido (pretty_midi/pretty_midi.py:1341-1520), pinned by
+    # tests/golden/midi_writer.npz (a recording stand-in for mido around the fork's own write()): tick conversion, event order, channels,
+    # track layout, delta ticks.  Only mido's byte serialisation (the SMF standard: _vlq and write() below) is this module's own.
+    MSG_TIME_SIGNATURE, MSG_SET_TEMPO, MSG_PROGRAM, MSG_CONTROL, MSG_NOTE_ON, MSG_END = 0, 1, 2, 3, 4, 5
+
+    def time_to_tick(self, t):
+        """pretty_midi.time_to_tick (:1077-1109) of a freshly built PrettyMIDI: one tempo, so tick = round(t / seconds per tick) with
+        Python's round (halves to even), the division written as the fork writes it."""
+        if t <= 0.0:
+            return 0
+        return int(round(t / (60.0 / (120.0 * self.resolution))))
+
+    def messages(self):
+        """[(track, type, channel, data1, data2, delta_ticks)] in file order (types: MSG_*).  Track 0 = tempo + 4/4; one track per
+        instrument: program change, then all events sorted by (tick, class, data) as the fork's comparator does (:1350-1394) -- at equal
+        ticks control changes by (control, value), then note-ons by (pitch, velocity), a note-off being a note-on of velocity 0 -- and an
+        end-of-track one tick behind the last event.  One deviation, outside what the samplers produce (their notes last >= 1 column =
+        4.4 ticks): a note shorter than a tick ends one tick after it starts (the fork would emit its off BEFORE its on: a stuck note)."""
+        tempo = int(6e7 / (60. / ((60.0 / (120.0 * self.resolution)) * self.resolution)))
+        out = [(0, self.MSG_SET_TEMPO, 0, tempo, 0, 0), (0, self.MSG_TIME_SIGNATURE, 0, 4, 4, 0), (0, self.MSG_END, 0, 0, 0, 1)]
         for k, ins in enumerate(self.instruments):
             ch = 9 if ins.is_drum else (k % 15 if k % 15 < 9 else k % 15 + 1)
-            ev = [(0, 0, bytes([0xC0 | ch, ins.program & 0x7F]))]
-            for c in ins.control_changes:
-                ev.append((tick(c.time), 1, bytes([0xB0 | ch, c.number & 0x7F, c.value & 0x7F])))
+            ev = [(0, 6 << 16, self.MSG_PROGRAM, ins.program & 0x7F, 0)]
             for n in ins.notes:
-                # at equal ticks: note-offs (order 2) before note-ons (order 3), so a repeated pitch re-triggers
-                ev.append((tick(n.start), 3, bytes([0x90 | ch, n.pitch & 0x7F, max(1, n.velocity) & 0x7F])))
-                ev.append((max(tick(n.end), tick(n.start) + 1), 2, bytes([0x90 | ch, n.pitch & 0x7F, 0])))
-            chunks.append(_track(ev))
+                t0 = self.time_to_tick(n.start)
+                t1 = max(self.time_to_tick(n.end), t0 + 1)
+                vel = max(1, n.velocity) & 0x7F
+                ev.append((t0, (10 << 16) + ((n.pitch & 0x7F) << 8) + vel, self.MSG_NOTE_ON, n.pitch & 0x7F, vel))
+                ev.append((t1, (10 << 16) + ((n.pitch & 0x7F) << 8), self.MSG_NOTE_ON, n.pitch & 0x7F, 0))
+            for c in ins.control_changes:
+                ev.append((self.time_to_tick(c.time), (8 << 16) + ((c.number & 0x7F) << 8) + (c.value & 0x7F), self.MSG_CONTROL, c.number & 0x7F, c.value & 0x7F))
+            ev.sort(key=lambda e: (e[0], e[1]))              # stable, like sorted(cmp_to_key(event_compare))
+            last = 0
+            for tick, _, kind, a, b in ev:
+                out.append((k + 1, kind, ch, a, b, tick - last))
+                last = tick
+            out.append((k + 1, self.MSG_END, 0, 0, 0, 1))
+        return out
+
+    def write(self, filename):
+        tracks = {}
+        for trk, kind, ch, a, b, delta in self.messages():
+            body = tracks.setdefault(trk, bytearray())
+            body += _vlq(delta)
+            if kind == self.MSG_SET_TEMPO:
+                body += b"\xff\x51\x03" + struct.pack(">I", a)[1:]
+            elif kind == self.MSG_TIME_SIGNATURE:
+                body += bytes([0xFF, 0x58, 0x04, a, {1: 0, 2: 1, 4: 2, 8: 3, 16: 4}[b], 24, 8])
+            elif kind == self.MSG_PROGRAM:
+                body += bytes([0xC0 | ch, a])
+            elif kind == self.MSG_CONTROL:
+                body += bytes([0xB0 | ch, a, b])
+            elif kind == self.MSG_NOTE_ON:
+                body += bytes([0x90 | ch, a, b])
+            else:
+                body += b"\xff\x2f\x00"
         with open(filename, "wb") as f:
-            f.write(b"MThd" + struct.pack(">IHHH", 6, 1, len(chunks), self.resolution))
-            for c in chunks:
-                f.write(c)
+            f.write(b"MThd" + struct.pack(">IHHH", 6, 1, len(tracks), self.resolution))
+            for trk in sorted(tracks):
+                f.write(b"MTrk" + struct.pack(">I", len(tracks[trk])) + bytes(tracks[trk]))
 
     # ------------------------------------------------------------------ reader (format 0 / 1, tempo map, running status)
     def _read(self, filename):
@@ -281,6 +323,8 @@ def midi_to_full_piano_roll(pm, fs=100):
                     on[n.pitch, min(int(n.start * fs), cols - 1)] = 127
         rolls.append((vel, on))
     T = max([v.shape[1] for v, _ in rolls], default=0)
+    if T == 0:   # no instrument has a note that reaches the first column: the reference's fork raises here; a (3,128,0) roll would fail far from its cause
+        raise ValueError("midi_to_full_piano_roll: no notes (or none lasting one column of 1/fs s) -- the reference cannot build a roll from this file either")
     roll = np.zeros((3, 128, T), dtype=np.float64)
     for v, o in rolls:
         roll[0, :, :v.shape[1]] += v

@@ -1526,6 +1526,90 @@ def g_midi_rolls():
     save("midi_rolls", **out)
 
 
+def g_midi_writer():
+    """The MESSAGE STREAM the reference hands to mido when it saves a sample: save_piano_roll_midi (midi_util.py:67-93) ->
+    piano_roll_to_pretty_midi -> PrettyMIDI.write of the vendored fork (pretty_midi/pretty_midi.py:1341-1520: tick conversion
+    time_to_tick, the event comparator at :1350-1394, track layout, absolute -> delta ticks).  mido is absent here, so the fork's `mido` is
+    replaced FOR THIS CALL by a recording stand-in (Message / MetaMessage / MidiTrack / MidiFile keep what they are given; save() keeps the
+    tracks): everything up to mido's byte serialisation (the SMF standard) is the reference's own code.  Rows of `<tag>.msgs`:
+    (track, type, channel, data1, data2, delta_ticks), type 0 time_signature (numerator, denominator), 1 set_tempo (tempo us, 0),
+    2 program_change (program, 0), 3 control_change (control, value), 4 note_on (note, velocity), 5 end_of_track."""
+    print("[midi writer: the message stream of the reference's pretty_midi fork]")
+    rpm = _ref_pretty_midi()
+    import ref_pretty_midi.pretty_midi as rpm_core
+    from music_rule_guidance import piano_roll_to_chord as rp2c
+    saved = []
+
+    class Msg:
+        def __init__(self, type, time=0, **kw):
+            self.type, self.time = type, time
+            self.__dict__.update(kw)
+
+    class MidiFile:
+        def __init__(self, ticks_per_beat=480, charset="latin1"):
+            self.ticks_per_beat, self.charset, self.tracks = ticks_per_beat, charset, []
+
+        def save(self, filename=None, file=None):
+            saved.append(self)
+    rec = types.SimpleNamespace(Message=Msg, MetaMessage=Msg, MidiTrack=list, MidiFile=MidiFile)
+    code = {"time_signature": 0, "set_tempo": 1, "program_change": 2, "control_change": 3, "note_on": 4, "end_of_track": 5}
+
+    def rows(mid):
+        out = []
+        for k, tr in enumerate(mid.tracks):
+            for e in tr:
+                c = code[e.type]
+                a, b = {0: lambda: (e.numerator, e.denominator), 1: lambda: (e.tempo, 0), 2: lambda: (e.program, 0),
+                        3: lambda: (e.control, e.value), 4: lambda: (e.note, e.velocity), 5: lambda: (0, 0)}[c]()
+                out.append((k, c, getattr(e, "channel", 0), a, b, e.time))
+        return np.array(out, dtype=np.int64)
+    g = np.load(os.path.join(HERE, "midi_events.npz"))
+    out = {}
+    old_pm, old_mido = rp2c.pretty_midi, rpm_core.mido
+    rp2c.pretty_midi, rpm_core.mido = rpm, rec
+    try:
+        for tag in ("r3", "r2", "r1"):
+            pm = rp2c.piano_roll_to_pretty_midi(g[f"{tag}.roll"].astype(F32), fs=100)
+            pm.write("unused.midi")
+            mid = saved.pop()
+            assert not saved and len(mid.tracks) == 2
+            out[f"{tag}.msgs"] = rows(mid)
+            out[f"{tag}.ticks_per_beat"] = np.array(mid.ticks_per_beat)
+            print(f"    {tag}: {len(out[f'{tag}.msgs'])} messages, {mid.ticks_per_beat} ticks per beat")
+        # events chosen for the comparator: equal ticks across pitches / velocities / controls, a re-struck pitch at its own note-off tick,
+        # two instruments + a drum track (channel assignment), times on .5-tick boundaries (rounding)
+        pm = rpm.PrettyMIDI()
+        rng = np.random.RandomState(530)
+        ev = {}
+        for k, drum in enumerate((False, False, True)):
+            ins = rpm.Instrument(program=[0, 41, 0][k], is_drum=drum)
+            notes, ccs = [], []
+            for _ in range(40):
+                a = float(rng.randint(0, 200)) / 100.0                         # many equal start columns
+                d = float(rng.choice([0.01, 0.02, 0.25, 0.5, 1.0]))
+                notes.append((int(rng.randint(1, 128)), int(rng.randint(30, 90)), a, a + d))
+            notes += [(64, 60, 0.5, 1.0), (70, 60, 1.0, 1.5), (1, 61, 1.0, 1.5), (127, 59, 1.0, 1.5)]       # off and on of pitch 60 at one tick
+            notes += [(50, 72, 2.5 / 440.0, 7.5 / 440.0), (50, 73, 0.5 / 440.0, 1.5 / 440.0)]                 # .5-tick times: banker's rounding
+            for _ in range(20):
+                ccs.append((int(rng.choice([64, 7, 1])), int(rng.randint(0, 128)), float(rng.randint(0, 200)) / 100.0))
+            for v, p_, a, b in notes:
+                ins.notes.append(rpm.Note(velocity=v, pitch=p_, start=a, end=b))
+            for nmb, v, tt in ccs:
+                ins.control_changes.append(rpm.ControlChange(number=nmb, value=v, time=tt))
+            pm.instruments.append(ins)
+            ev[f"ev.notes{k}"] = np.array(notes, dtype=np.float64).reshape(-1, 4)
+            ev[f"ev.ccs{k}"] = np.array(ccs, dtype=np.float64).reshape(-1, 3)
+            ev[f"ev.prog{k}"] = np.array([[0, 41, 0][k], int(drum)])
+        pm.write("unused.midi")
+        mid = saved.pop()
+        out.update(ev)
+        out["ev.msgs"] = rows(mid)
+        print(f"    events: {len(out['ev.msgs'])} messages on {len(mid.tracks)} tracks")
+    finally:
+        rp2c.pretty_midi, rpm_core.mido = old_pm, old_mido
+    save("midi_writer", **out)
+
+
 def chord_test_roll(seed):
     """(3,3,128,256) roll with values on both sides of the -0.95 snap, outside [-1,1] and in the non-piano rows (the tests
     rebuild it from the seed: tests/conftest.py chord_test_roll is this function)."""
@@ -1665,7 +1749,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "round4b", "midi_rolls"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "round4b", "midi_rolls", "midi_writer"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1716,6 +1800,8 @@ if __name__ == "__main__":
         g_midi()
     if "midi_rolls" in which:
         g_midi_rolls()
+    if "midi_writer" in which:
+        g_midi_writer()
     if "chordq" in which:
         g_chordq()
     if "cli" in which:

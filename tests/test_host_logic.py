@@ -291,6 +291,111 @@ def test_full_piano_roll_matches_the_references_pretty_midi_fork():
     assert np.array_equal(back, g["r3.reroll"].astype(np.float32))
 
 
+def _smf_messages(path):
+    """decode a Standard MIDI File into the rows of tests/golden/midi_writer.npz: (track, type, channel, data1, data2, delta_ticks) --
+    an independent reader (the product's SimpleMIDI._read turns messages back into notes and would hide their order)"""
+    import struct
+    data = open(path, "rb").read()
+    assert data[:4] == b"MThd"
+    hlen, fmt, ntrk, div = struct.unpack(">IHHH", data[4:14])
+    pos, rows = 8 + hlen, []
+    for k in range(ntrk):
+        assert data[pos:pos + 4] == b"MTrk"
+        end = pos + 8 + struct.unpack(">I", data[pos + 4:pos + 8])[0]
+        p = pos + 8
+        while p < end:
+            d = 0
+            while True:
+                b = data[p]
+                p += 1
+                d = (d << 7) | (b & 0x7F)
+                if not b & 0x80:
+                    break
+            st = data[p]
+            if st == 0xFF:
+                kind, ln = data[p + 1], data[p + 2]
+                body = data[p + 3:p + 3 + ln]
+                p += 3 + ln
+                if kind == 0x51:
+                    rows.append((k, 1, 0, int.from_bytes(body, "big"), 0, d))
+                elif kind == 0x58:
+                    rows.append((k, 0, 0, body[0], 1 << body[1], d))
+                else:
+                    assert kind == 0x2F and ln == 0
+                    rows.append((k, 5, 0, 0, 0, d))
+            else:
+                assert st & 0x80, "the writer uses no running status"
+                hi, ch = st & 0xF0, st & 0x0F
+                if hi == 0xC0:
+                    rows.append((k, 2, ch, data[p + 1], 0, d))
+                    p += 2
+                else:
+                    rows.append((k, {0xB0: 3, 0x90: 4}[hi], ch, data[p + 1], data[p + 2], d))
+                    p += 3
+        assert p == end
+        pos = end
+    return fmt, div, np.array(rows, dtype=np.int64)
+
+
+def test_midi_writer_message_stream_matches_the_references_pretty_midi_fork(tmp_path):
+    """f3: the ordered message stream of SimpleMIDI.write == what the reference's vendored pretty_midi fork hands to mido
+    (pretty_midi/pretty_midi.py:1341-1520 under a recording stand-in for mido; fixture midi_writer.npz by make_golden.py midi_writer):
+    tick conversion incl. half-tick rounding, the comparator's order at equal ticks (controls by number / value, notes by pitch /
+    velocity, offs as velocity-0 note-ons), channels (drums on 9, the others skipping it), program changes, track layout, delta ticks --
+    for the three sample rolls of midi_events.npz through piano_roll_to_pretty_midi (the sampling path, midi_util.py:67-93) and for a
+    three-instrument event list; both as messages() and as decoded back from the written file."""
+    from music_rule_guidance.piano_roll_to_chord import Instrument, Note, ControlChange, SimpleMIDI, piano_roll_to_pretty_midi
+    g = load_golden("midi_writer")
+    ev = load_golden("midi_events")
+    for tag in ("r3", "r2", "r1"):
+        pm = piano_roll_to_pretty_midi(ev[f"{tag}.roll"].astype(np.float32), fs=100)
+        assert pm.resolution == int(g[f"{tag}.ticks_per_beat"]) == 220
+        got = np.array(pm.messages(), dtype=np.int64)
+        assert got.shape == g[f"{tag}.msgs"].shape and np.array_equal(got, g[f"{tag}.msgs"]), tag
+        path = str(tmp_path / f"{tag}.midi")
+        pm.write(path)
+        fmt, div, rows = _smf_messages(path)
+        assert (fmt, div) == (1, 220) and np.array_equal(rows, g[f"{tag}.msgs"])
+    pm = SimpleMIDI()
+    for k in range(3):
+        prog, drum = (int(v) for v in g[f"ev.prog{k}"])
+        ins = Instrument(program=prog, is_drum=bool(drum))
+        for v, p_, a, b in g[f"ev.notes{k}"]:
+            ins.notes.append(Note(velocity=int(v), pitch=int(p_), start=float(a), end=float(b)))
+        for nmb, v, t in g[f"ev.ccs{k}"]:
+            ins.control_changes.append(ControlChange(number=int(nmb), value=int(v), time=float(t)))
+        pm.instruments.append(ins)
+    got = np.array(pm.messages(), dtype=np.int64)
+    assert np.array_equal(got, g["ev.msgs"])
+    assert set(got[got[:, 0] == 3][:, 2]) == {0, 9} and set(got[got[:, 0] == 2][:, 2]) == {0, 1}      # drum track on channel 9
+    path = str(tmp_path / "ev.midi")
+    pm.write(path)
+    assert np.array_equal(_smf_messages(path)[2], g["ev.msgs"])
+    # the one documented deviation: a note shorter than a tick still ends after it starts
+    one = SimpleMIDI()
+    one.instruments.append(Instrument())
+    one.instruments[0].notes.append(Note(velocity=80, pitch=60, start=1.0, end=1.0001))
+    m = [r for r in one.messages() if r[1] == SimpleMIDI.MSG_NOTE_ON]
+    assert [(r[4], r[5]) for r in m] == [(80, 440), (0, 1)]
+
+
+def test_full_piano_roll_of_a_midi_without_notes_raises():
+    """round-4 advisor: a file with no notes (or only notes shorter than a column that end before the first one) gave a (3,128,0) roll that
+    failed far from its cause; the reference's fork raises for such a file, so does the reader now"""
+    from music_rule_guidance.piano_roll_to_chord import Instrument, Note, ControlChange, SimpleMIDI, midi_to_full_piano_roll
+    pm = SimpleMIDI()
+    pm.instruments.append(Instrument())
+    pm.instruments[0].control_changes.append(ControlChange(64, 100, 1.0))
+    with pytest.raises(ValueError, match="no notes"):
+        midi_to_full_piano_roll(pm, fs=100)
+    pm.instruments[0].notes.append(Note(90, 60, 0.001, 0.004))
+    pm.instruments[0].control_changes.clear()
+    with pytest.raises(ValueError, match="no notes"):
+        midi_to_full_piano_roll(pm, fs=100)
+    pm.instruments[0].notes.append(Note(90, 62, 0.0, 0.5))
+    assert midi_to_full_piano_roll(pm, fs=100).shape == (3, 128, 50)
+
+
 def test_midi_file_round_trip_and_default_io(tmp_path):
     """The built-in SMF writer / reader (no pretty_midi): events survive write -> read to the tick (1/440 s), the default
     save_piano_roll_midi writes .midi + .npy under the reference's names, read_midi_piano_roll returns a (3,128,T) roll whose
@@ -561,3 +666,40 @@ def test_role_split_and_window_share_rules():
                 assert abs((len(f) + len(h)) - (n_full + n_half) / R) < 1.0 + 1e-9          # balanced to within one window
             assert sorted(full) == list(range(n_full)) and sorted(half) == list(range(n_half)), (n_full, n_half, R)
     assert bs.window_world() == (1, 0) and bs.WINDOW_SHARD is False
+
+
+def _prevx_partition_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, PKG)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from guided_diffusion import gaussian_diffusion as gd
+    from guided_diffusion.respace import SpacedDiffusion, space_timesteps
+    res = {}
+    for name, mean in (("eps", gd.ModelMeanType.EPSILON), ("x0", gd.ModelMeanType.START_X), ("prev", gd.ModelMeanType.PREVIOUS_X)):
+        d = SpacedDiffusion(use_timesteps=space_timesteps(1000, [1000]), betas=gd.get_named_beta_schedule("linear", 1000),
+                            model_mean_type=mean, model_var_type=gd.ModelVarType.FIXED_LARGE, loss_type=gd.LossType.MSE)
+        res[name] = (d._search_partition(4, True), d._search_partition(4, False), d._search_partition(4, True, record=True))
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_previous_x_search_steps_stay_replicated_two_ranks_gloo():
+    """round-4 advisor (medium): a PREVIOUS_X model's search step ran its forward on this rank's rows only, left x_{t-1} / x_0 of those rows
+    in self._prevx and tripped _prevx_fix's shape check on the full batch.  Under world_size 2 the row partition of an SCG search step is
+    (rank * 2, 2) for EPSILON / START_X and None -- replicated -- for PREVIOUS_X (and for every recording step)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prevx_partition_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p_ in procs:
+        p_.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p_ in procs:
+        p_.join(timeout=60)
+        assert p_.exitcode == 0
+    for rank, r in res:
+        for name in ("eps", "x0"):
+            assert r[name][0] == ((rank * 2, 2), None) and r[name][1] == ((rank * 2, 2), None) and r[name][2] == (None, None)
+        assert r["prev"] == ((None, None),) * 3
