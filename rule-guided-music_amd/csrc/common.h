@@ -85,6 +85,42 @@ __device__ __forceinline__ void static_for(F&& f) {
 }
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------------------------------------
+// Device-coherent ("write-through", sc1) stores: what a workgroup of a persistent launch publishes for ANOTHER workgroup of the same
+// launch (chain.hip).  The bytes leave the XCD's L2 when vmcnt retires the store -- no cache write-back (an agent-scope release fence
+// writes the whole dirty L2 back: MI355X_MICROARCH.md "publish-large", 8.2 against 3.0 us per 64 KB), so the hand-off is
+//   sc1 stores -> s_waitcnt vmcnt(0) -> barrier -> relaxed agent-scope counter add      (producer)
+//   relaxed agent-scope poll -> agent-scope acquire fence (L1 invalidate) -> barrier -> plain loads / LDS-DMA   (consumer).
+// 16 bytes per lane: narrower sc1 stores are one fabric write each (a dwordx2 costs 2.7x per byte) -- 8-byte pieces of split rows are
+// paired over two lanes first (store_split4_pair_sc1).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void store16_sc1(void* p, const f32x4& v) {
+  // "memory": the epilogues count on program order between their LDS-DMA loads and these stores (gemm2_body.h: s_waitcnt vmcnt(<stores of
+  // one slab>)); without the clobber the compiler moved the DMA builtins across the asm and a slab was read before it had landed
+  // s_nop: a store of more than 8 bytes still reads its data registers for a wait state or two after issue, and the compiler's hazard
+  // recogniser does not see a store inside an asm statement -- without it the next VALU write of those registers corrupted the last
+  // four lanes of every 16 (found on the attention output: rows 12-15 / 28-31 of a query tile, run-to-run different)
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+typedef split_t split_x4 __attribute__((ext_vector_type(4)));
+// A lane holds 4 consecutive elements (columns col .. col + 3, col % 4 == 0) of a split row as hi / lo halves; its partner lane
+// (lane ^ XOR) holds the other 4 of the same 8-aligned group.  The lane with (col & 4) == 0 stores the 8 hi halves (16 bytes), the other
+// the 8 lo halves: two 16-byte coherent stores instead of four 8-byte ones.  Both lanes of a pair must call (shuffle inside).
+template <int XOR>
+__device__ __forceinline__ void store_split4_pair_sc1(split_t* rowp, int col, const split_x4& hi, const split_x4& lo) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const bool even = (col & 4) == 0;
+  const u32x2 mine_hi = __builtin_bit_cast(u32x2, hi), mine_lo = __builtin_bit_cast(u32x2, lo);
+  const u32x2 send = even ? mine_lo : mine_hi;           // the even lane needs the partner's hi, the odd lane the partner's lo
+  u32x2 recv;
+  recv[0] = (unsigned)__shfl_xor((int)send[0], XOR, 64);
+  recv[1] = (unsigned)__shfl_xor((int)send[1], XOR, 64);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 out = even ? u32x4{mine_hi[0], mine_hi[1], recv[0], recv[1]} : u32x4{recv[0], recv[1], mine_lo[0], mine_lo[1]};
+  split_t* dst = rowp + split_idx(col & ~7) + (even ? 0 : 32);
+  store16_sc1(dst, __builtin_bit_cast(f32x4, out));
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
@@ -228,6 +264,31 @@ int gemm2_prof_report(int kernel, int* launches, double* total_ms, double* total
 double gemm2_prof_bytes(int kernel);
 int big_tiles_mode();   // rgm_set_big_tiles (gemm2.hip)
 int big_tiles_min();
+
+// ---------------------------------------------------------------------------------------------
+// chain.hip: the blocks of a DiT forward as one persistent launch.  An op = one phase of one block (its tensors); an item = one unit of an
+// op's work for one row group (= the 256 rows of a sample): packed as uint4 { op | group << 16, sub | z << 16, need, 0 } -- `need` = finished
+// items of the group's earlier phases the item waits for.
+// ---------------------------------------------------------------------------------------------
+enum { CHAIN_GEMM = 0, CHAIN_ATTN = 1, CHAIN_LN = 2, CHAIN_REDUCE_LN = 3, CHAIN_REDUCE = 4 };
+constexpr int CHAIN_CTL_HEAD = 0, CHAIN_CTL_ERROR = 1, CHAIN_CTL_PROGRESS = 8, CHAIN_MAX_GROUPS = 4096, CHAIN_MAX_CUS = 512;
+constexpr int CHAIN_CTL_TRACE = CHAIN_CTL_PROGRESS + CHAIN_MAX_GROUPS, CHAIN_CTL_WORDS = CHAIN_CTL_TRACE + 2 * CHAIN_MAX_CUS;
+struct ChainOp {
+  GemmParams g;            // CHAIN_GEMM: the GEMM (whole batch; item = 256x256 tile (group, sub), K slice z)
+                           // CHAIN_ATTN: A = qkv, C = attention output (split rows); item = (sample, head)
+                           // CHAIN_LN: A = x, ln_out / ln_shift / ln_scale / ln_mod_ld / ln_rows_per_batch / ln_eps, N = D, M = rows
+                           // CHAIN_REDUCE(_LN): the K-sliced GEMM's epilogue (bias, gate, res, C) + ln_* of the next LayerNorm
+  int kind = 0;
+  int tiles_n = 0;         // CHAIN_GEMM: column tiles
+  int rows_per_item = 0;   // row ops: rows of one item (4 waves share them)
+  int rows_per_group = 0;  // row ops: rows of a group (T)
+  const float* P = nullptr;   // CHAIN_REDUCE*: the K slices' partial sums [3][M][N]
+  const float* cos_tab = nullptr;
+  const float* sin_tab = nullptr;
+  int T = 0, heads = 0, rot_half = 0;
+};
+int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, unsigned* d_ctl, int n_groups, hipStream_t s);
+long long dit_chain_launch_count();
 
 // elementwise / reductions (elementwise.hip)
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,

@@ -10,6 +10,7 @@
 // All are one pass over their tensor with 16-byte lanes; LN keeps the row in registers (one wave
 // per row, shuffle reductions), so x is read once and the modulated row written once.
 #include "common.h"
+#include "ln_body.h"
 
 namespace rgm {
 
@@ -21,57 +22,7 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
                                                      int out_split) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
-  const int lane = threadIdx.x & 63;
-  const int nv = D >> 2;
-  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * D);
-  float4 v[MAXV];
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
-    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-  }
-  const float mean = wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c < nv) {
-      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
-      q += (a * a + b * b) + (cc * cc + d * d);
-    }
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
-  const long long mo = (long long)(row / rows_per_batch) * mod_ld;
-  float4* orow = reinterpret_cast<float4*>(out + (long long)row * D);
-#pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int c = lane + i * 64;
-    if (c >= nv) continue;
-    float4 y = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
-    if (weight) {
-      const float4 w = reinterpret_cast<const float4*>(weight)[c], b = reinterpret_cast<const float4*>(bias)[c];
-      y = make_float4(y.x * w.x + b.x, y.y * w.y + b.y, y.z * w.z + b.z, y.w * w.w + b.w);
-    }
-    if (scale) {
-      const float4 sc = reinterpret_cast<const float4*>(scale + mo)[c], sh = reinterpret_cast<const float4*>(shift + mo)[c];
-      y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
-    }
-    if (out_split) {   // split-row format (common.h split_idx) for the pre-split GEMM path
-      typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
-      bf16x4 hi, lo;
-      hi[0] = (split_t)y.x; hi[1] = (split_t)y.y; hi[2] = (split_t)y.z; hi[3] = (split_t)y.w;
-      lo[0] = (split_t)(y.x - (float)hi[0]); lo[1] = (split_t)(y.y - (float)hi[1]);
-      lo[2] = (split_t)(y.z - (float)hi[2]); lo[3] = (split_t)(y.w - (float)hi[3]);
-      split_t* rp = reinterpret_cast<split_t*>(out + (long long)row * D);
-      const int si = split_idx(c * 4);
-      *reinterpret_cast<bf16x4*>(rp + si) = hi;
-      *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
-    } else {
-      orow[c] = y;
-    }
-  }
+  ln_mod_row<MAXV>(x, out, row, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
 }
 
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight, const float* bias,

@@ -1,0 +1,166 @@
+// ln_body.h -- the row bodies of the DiT forward's two LayerNorm kernels as device functions: ln_mod_kernel (dit_kernels.hip) and
+// splitk_reduce_ln_kernel (gemm2.hip) wrap them one row per wave; chain.hip runs them as work items of the persistent forward.
+#pragma once
+#include "common.h"
+
+namespace rgm {
+
+// one wave = one row of ln_mod_kernel (dit_kernels.hip).  COH = 1 (chain.hip; split output, D % 8 == 0): device-coherent 16-byte stores
+template <int MAXV, int COH = 0>
+__device__ __forceinline__ void ln_mod_row(const float* __restrict__ x, float* __restrict__ out, const int row, int D,
+                                           float eps, const float* __restrict__ weight,
+                                           const float* __restrict__ bias, const float* __restrict__ shift,
+                                           const float* __restrict__ scale, int mod_ld, int rows_per_batch,
+                                           int out_split) {
+  const int lane = threadIdx.x & 63;
+  const int nv = D >> 2;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long long)row * D);
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = c < nv ? xr[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  const long long mo = (long long)(row / rows_per_batch) * mod_ld;
+  float4* orow = reinterpret_cast<float4*>(out + (long long)row * D);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c >= nv) continue;
+    float4 y = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+    if (weight) {
+      const float4 w = reinterpret_cast<const float4*>(weight)[c], b = reinterpret_cast<const float4*>(bias)[c];
+      y = make_float4(y.x * w.x + b.x, y.y * w.y + b.y, y.z * w.z + b.z, y.w * w.w + b.w);
+    }
+    if (scale) {
+      const float4 sc = reinterpret_cast<const float4*>(scale + mo)[c], sh = reinterpret_cast<const float4*>(shift + mo)[c];
+      y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
+    }
+    if (out_split) {   // split-row format (common.h split_idx) for the pre-split GEMM path
+      typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 hi, lo;
+      hi[0] = (split_t)y.x; hi[1] = (split_t)y.y; hi[2] = (split_t)y.z; hi[3] = (split_t)y.w;
+      lo[0] = (split_t)(y.x - (float)hi[0]); lo[1] = (split_t)(y.y - (float)hi[1]);
+      lo[2] = (split_t)(y.z - (float)hi[2]); lo[3] = (split_t)(y.w - (float)hi[3]);
+      split_t* rp = reinterpret_cast<split_t*>(out + (long long)row * D);
+      if constexpr (COH) {
+        store_split4_pair_sc1<1>(rp, c * 4, hi, lo);       // lanes (2k, 2k+1) hold chunks (2j, 2j+1): one 8-aligned group
+      } else {
+        const int si = split_idx(c * 4);
+        *reinterpret_cast<bf16x4*>(rp + si) = hi;
+        *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
+      }
+    } else {
+      orow[c] = y;
+    }
+  }
+}
+
+
+// one wave = one row of splitk_reduce_ln_kernel (gemm2.hip).  LN = 0: the reduce alone (the last block of a forward has no next LayerNorm).
+// COH = 1 (chain.hip): the reduced row and the LayerNorm row are stored device-coherent, 16 bytes per lane.
+template <int MAXV, int S, int COH = 0, int LN = 1>
+__device__ __forceinline__ void splitk_reduce_ln_row(const float* __restrict__ P, const GemmParams& p, const int row) {
+  const int lane = threadIdx.x & 63;
+  const int nv = p.N >> 2;
+  const long long MN = (long long)p.M * p.N;
+  // one wave holds the row and there are only M waves (1024 at B = 4): every load of the row -- S partial sums, bias, gate, residual
+  // per chunk -- is issued before the first sum (compile-time S and MAXV), or the wave walks through 5 S dependent round trips
+  float4 part[MAXV][S], bq[MAXV], gq[MAXV], rq[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    const int col = c * 4;
+    const bool ok = c < nv;
+#pragma unroll
+    for (int sidx = 0; sidx < S; ++sidx)
+      part[i][sidx] = ok ? *reinterpret_cast<const float4*>(P + sidx * MN + (long long)row * p.N + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    bq[i] = (ok && p.bias) ? *reinterpret_cast<const float4*>(p.bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    gq[i] = (ok && p.gate) ? *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col) : make_float4(1.f, 1.f, 1.f, 1.f);
+    rq[i] = (ok && p.res) ? *reinterpret_cast<const float4*>(p.res + (long long)row * p.ldres + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 v[MAXV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nv) {
+      const int col = c * 4;
+      float4 a = part[i][0];
+#pragma unroll
+      for (int sidx = 1; sidx < S; ++sidx) {
+        const float4 b = part[i][sidx];
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      float w[4] = {a.x * p.alpha, a.y * p.alpha, a.z * p.alpha, a.w * p.alpha};
+      if (p.bias) { w[0] += bq[i].x; w[1] += bq[i].y; w[2] += bq[i].z; w[3] += bq[i].w; }
+      if (p.gate) { w[0] *= gq[i].x; w[1] *= gq[i].y; w[2] *= gq[i].z; w[3] *= gq[i].w; }
+      if (p.res) { w[0] += rq[i].x; w[1] += rq[i].y; w[2] += rq[i].z; w[3] += rq[i].w; }
+      v[i] = make_float4(w[0], w[1], w[2], w[3]);
+      if constexpr (COH) {
+        const f32x4 wv = {w[0], w[1], w[2], w[3]};
+        store16_sc1(p.C + (long long)row * p.ldc + col, wv);
+      } else {
+        *reinterpret_cast<float4*>(p.C + (long long)row * p.ldc + col) = v[i];
+      }
+    }
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  if constexpr (!LN) return;
+  const float D = (float)p.N;
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c < nv) {
+      const float a = v[i].x - mean, b = v[i].y - mean, cc = v[i].z - mean, d = v[i].w - mean;
+      q += (a * a + b * b) + (cc * cc + d * d);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + p.ln_eps);
+  const long long mo = (long long)(row / p.ln_rows_per_batch) * p.ln_mod_ld;
+  float4* orow = reinterpret_cast<float4*>(p.ln_out + (long long)row * p.N);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int c = lane + i * 64;
+    if (c >= nv) continue;
+    float4 y = make_float4((v[i].x - mean) * rstd, (v[i].y - mean) * rstd, (v[i].z - mean) * rstd, (v[i].w - mean) * rstd);
+    const float4 sc = reinterpret_cast<const float4*>(p.ln_scale + mo)[c], sh = reinterpret_cast<const float4*>(p.ln_shift + mo)[c];
+    y = make_float4(y.x * (1.f + sc.x) + sh.x, y.y * (1.f + sc.y) + sh.y, y.z * (1.f + sc.z) + sh.z, y.w * (1.f + sc.w) + sh.w);
+    if (p.ln_out_split) {
+      typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 hi, lo;
+      hi[0] = (split_t)y.x; hi[1] = (split_t)y.y; hi[2] = (split_t)y.z; hi[3] = (split_t)y.w;
+      lo[0] = (split_t)(y.x - (float)hi[0]); lo[1] = (split_t)(y.y - (float)hi[1]);
+      lo[2] = (split_t)(y.z - (float)hi[2]); lo[3] = (split_t)(y.w - (float)hi[3]);
+      split_t* rp = reinterpret_cast<split_t*>(p.ln_out + (long long)row * p.N);
+      if constexpr (COH) {
+        store_split4_pair_sc1<1>(rp, c * 4, hi, lo);
+      } else {
+        const int si = split_idx(c * 4);
+        *reinterpret_cast<bf16x4*>(rp + si) = hi;
+        *reinterpret_cast<bf16x4*>(rp + si + 32) = lo;
+      }
+    } else {
+      orow[c] = y;
+    }
+  }
+}
+
+
+}  // namespace rgm

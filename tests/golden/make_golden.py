@@ -421,6 +421,7 @@ FIXTURE_SEEDS = {
     "next2": {"dpsscg.noise_seed": 1910, "dpsscg_off.noise_seed": 2410},
     "round3": {"lsig.seed": 21},
     "round4": {"c4.noise_seed": 4102, "c4.x_seed": 4101, "c5.w_seed": 4201, "prevx_lr.seed": 21, "xl28_b32.x_seed": 4001},
+    "round5": {"c5.noise_seed": 5102, "c5.x_seed": 5101},
     "round4b": {"c2.noise_seed": 4402, "c2.x_seed": 4401, "c3.noise_seed": 4302, "c3.x_seed": 4301},
     "seg": {"noise_seed": 1451},
     "steps2": {"circ.noise_seed": 1415, "dcg.noise_seed": 1411, "dscg.noise_seed": 1412, "dscgc.noise_seed": 1413},
@@ -1158,6 +1159,69 @@ def g_round4b():
     save("round4b", **out)
 
 
+def g_round5(vae):
+    """Round-5 pin: ONE guided step of BASELINE config 5 as the reference runs it -- a 4 x 512 x 16 latent through
+    CondIndSimple(7 windows, overlap 64) of DiTRotary_XL_8 (depth 28): 13 window forwards at x_t, then SCG with n = 16 candidates
+    (16 x 13 window forwards, 16 x 32 = 512 decoder squares), selection PER SEGMENT of dc.base = 128 latent rows
+    (gaussian_diffusion.py:562-592; diff_collage/condind_long.py:24-51), B = 1.  Stored: the four (16, 1) log-probability tables the
+    reference hands its per-segment argmax (:587) as (16, 4, 1), the winners (4, 1), the selected sample and x_t / noise seeds."""
+    print("[round5: C5 guided step at its size: XL-28 collage eps + segment-wise SCG n=16, B=1]")
+    from functools import partial
+    from types import SimpleNamespace
+    sk = FIXTURE_SEEDS["round5"]
+    t0 = time.time()
+    m, _ = ref_dit(XL28, 1, final_std=0.3 / 1152 ** 0.5)
+
+    def eps_fn(xx, tt, y=None):
+        return m(xx.permute(0, 1, 3, 2), tt, y=y).permute(0, 1, 3, 2)
+    lin = rdc.CondIndSimple((4, 16, 128), eps_fn, 7, overlap_size=64)
+    B, n, S = 1, 16, 4
+    x = np.random.RandomState(sk["c5.x_seed"]).randn(B, 4, 512, 16).astype(F32)
+    nz = np.random.RandomState(sk["c5.noise_seed"]).randn(n, B, 4, 512, 16).astype(F32)
+    y = np.ones((B,), dtype=np.int64)
+    tgt = {"pitch_hist": np.tile(np.array([0.5, 0, 0, 0, 0.25, 0, 0, 0.25, 0, 0, 0, 0], dtype=F32), (B, 1)),
+           "note_density": np.tile(np.array([3.] * 64, dtype=F32), (B, 1))}
+    tgt["note_density"][:, ::5] = 6.                                     # not one flat target: the segments score against different slices
+    ttgt = {k: torch.from_numpy(v) for k, v in tgt.items()}
+    mf = partial(rcf.dc_model_fn, model=lin.eps_scalar_t_fn, num_classes=3, class_cond=True, cfg=False, w=0.)
+    gk = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance", dc=SimpleNamespace(base=128))
+    scg = {"num_samples": n, "pitch_hist": 40., "note_density": 1.}
+    d = make_diffusion("")
+    d.t_end = 0
+    tc = np.full((B,), 500, dtype=np.int64)
+    NQ.push(nz)
+
+    class ChunkedVAE:                      # the reference's _decode hands all 512 squares over at once: same values, 32 at a time
+        def decode(self, z):
+            return torch.cat([vae.decode(z[i:i + 32]) for i in range(0, z.shape[0], 32)])
+    seen = []
+    orig_argmax = torch.Tensor.argmax
+
+    def spy(self, *a, **k):
+        if self.dim() == 2 and self.shape == (n, B):
+            seen.append(self.detach().clone().numpy())
+        return orig_argmax(self, *a, **k)
+    torch.Tensor.argmax = spy
+    try:
+        r = d.p_sample(mf, torch.from_numpy(x), torch.from_numpy(tc), clip_denoised=False,
+                       model_kwargs={"y": torch.from_numpy(y), "rule": ttgt}, embed_model=ChunkedVAE(), scale_factor=1.2465,
+                       guidance_kwargs=gk, scg_kwargs=scg)
+    finally:
+        torch.Tensor.argmax = orig_argmax
+        NQ.q.clear()
+    assert len(seen) == S, len(seen)
+    table = np.stack(seen, axis=1)                                        # (n, S, B)
+    mi = np.argmax(table, axis=0)                                         # (S, B)
+    samp = r["sample"].detach().numpy()
+    srt = np.sort(table, axis=0)
+    gap = (srt[-1] - srt[-2]) / (srt[-1] - srt[0])
+    print(f"    C5 step: {time.time() - t0:.0f} s; winners {mi.reshape(-1)}; (best - second) / spread per segment {gap.reshape(-1)}")
+    save("round5", **{"c5.x_seed": np.array(sk["c5.x_seed"]), "c5.noise_seed": np.array(sk["c5.noise_seed"]), "c5.t": tc,
+                      "c5.sample": samp, "c5.pred_xstart": r["pred_xstart"].detach().numpy(), "c5.max_ind": mi.astype(np.int64),
+                      "c5.total_log_prob": table.astype(F32), "c5.target.pitch_hist": tgt["pitch_hist"],
+                      "c5.target.note_density": tgt["note_density"]})
+
+
 def g_configs():
     """Every YAML of the reference's scripts/configs tree, parsed (yaml.safe_load) -> one JSON fixture: the config-fidelity test
     checks the shipped tree against these VALUES (file names + guidance / scg / sampling / dc / edit / target_rules)."""
@@ -1749,7 +1813,7 @@ def g_cli():
 
 
 if __name__ == "__main__":
-    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "round4b", "midi_rolls", "midi_writer"}
+    which = set(sys.argv[1:]) or {"schedule", "dit", "xl28", "cls", "vae", "rules", "steps", "collage", "cli", "e2e", "edit", "dps", "dpsrule", "midi", "chordq", "steps2", "seg", "cli2", "next2", "hooks", "cfgdps", "learned", "configs", "round3", "round4", "round4b", "round5", "midi_rolls", "midi_writer"}
     torch.set_num_threads(8)
     vae = None
     if "schedule" in which:
@@ -1760,7 +1824,7 @@ if __name__ == "__main__":
         g_dit("xl_d28", XL28, 1)
     if "cls" in which:
         g_cls()
-    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e", "round3", "round4"}:
+    if which & {"vae", "steps", "steps2", "seg", "cli2", "e2e", "round3", "round4", "round5"}:
         vae = g_vae() if "vae" in which else RefVAE(2)
     if "rules" in which:
         g_rules()
@@ -1786,6 +1850,8 @@ if __name__ == "__main__":
         g_round4(vae)
     if "round4b" in which:
         g_round4b()
+    if "round5" in which:
+        g_round5(vae)
     if "configs" in which:
         g_configs()
     if "collage" in which:

@@ -3,7 +3,7 @@
 // wrong rows at T = 128?  The probe launches the library's own kernel (this file includes attention_x3.hip) with an explicit block
 // size and LDS request, records per workgroup where it ran (HW_ID, LDS_ALLOC, XCC_ID), when, and what its staging barrier saw.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRGM_ATTN_HAZARD_DBG -I../../rule-guided-music_amd/csrc -o attn_hazard attn_hazard.hip
-//        ... -DRGM_ATTN_HAZARD_TWO_PHASE -o attn_hazard_two_phase   (the Q prologue with every load retired before the first use)
+//        ... (no flag: the product kernel since round 5) -o attn_hazard_two_phase   (the Q prologue with every load retired before the first use)
 //        ... -DRGM_ATTN_HAZARD_DUMP -o attn_hazard_dump             (+ the Q fragments of every lane; tools/ubench/attn_hazard.sh builds all three)
 // run:   ./attn_hazard [launches per experiment, default 40] [N, default 48] [substring of the experiment names to run]
 // Whether the failure shows depends on the exact instruction schedule of the kernel: a build reproduces it in about half of its launches
