@@ -161,6 +161,11 @@ int rgm_dit_chain_status(rgm_dit* h, int* status);
 /* debugging: `words` control words of the handle's persistent forward -- [0] items claimed, [1] error, [8 + g] finished items of sample g,
  * [8 + 4096 + 2 w] { item + 1, state } of workgroup w when RGM_CHAIN_TRACE=1 -- copied on a private stream without waiting for the launch */
 int rgm_dit_chain_peek(rgm_dit* h, unsigned* out, int words);
+/* measurement (RGM_CHAIN_TIMES=1 in the environment before the first forward): per work item of the handle's last persistent forward --
+ * out_times (8 words) { claimed, dependencies met, finished, workgroup, wave 0 left the body, wave 0's stores retired, -, - } on the
+ * 100 MHz clock, out_items (4 words) { op | sample << 16,
+ * sub | K slice << 16, need, 0 } (op = 7 * block + phase); both optional; *n_items = number of items; synchronises the device */
+int rgm_dit_chain_times(rgm_dit* h, unsigned long long* out_times, unsigned* out_items, int cap_items, int* n_items);
 /* Deterministic split-K of the pre-split GEMM (csrc/gemm2.hip: K slices as a batch + one fixed-order reduce kernel, which for the fc2
  * of a DiT block also writes the next adaLN-LayerNorm): the scratch is caller memory like every other workspace,
  * rgm_gemm_scratch_bytes(M, N) bytes for GEMMs of up to M rows and N columns, 16-byte aligned, no initialisation.  tile 0 lets the

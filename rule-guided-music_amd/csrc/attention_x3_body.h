@@ -49,7 +49,7 @@ __device__ float* g_attn_dump = nullptr;    // [grid][waves][ATTN_DUMP_ITEMS][64
 template <int HD, int NKT, int COH = 0>
 __device__ __forceinline__ void attn_x3_body(char* smem3, const float* __restrict__ qkv, float* __restrict__ o,
                                              const float* __restrict__ cos_tab, const float* __restrict__ sin_tab, int T, int heads,
-                                             int rot_half, float* __restrict__ lse, int out_split, int qgroups, const int bidx) {
+                                             int rot_half, float* __restrict__ lse, int out_split, int qgroups, const int bidx, const int tid_in = -1) {
   constexpr int KP = (HD + 15) / 16 * 16;   // padded contraction length of QK^T
   constexpr int KS = KP / 16;               // k16 steps of QK^T
   constexpr int DT = (HD + 31) / 32;        // 32-wide output-channel tiles
@@ -66,7 +66,7 @@ __device__ __forceinline__ void attn_x3_body(char* smem3, const float* __restric
   const int n = bh / heads, head = bh - n * heads;
   const int D = heads * HD, D3 = 3 * D;
   const float* base = qkv + (long long)n * T * D3 + head * HD;
-  const int tid = threadIdx.x;
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;
   const int R = 2 * rot_half;
   typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
 
@@ -87,44 +87,68 @@ __device__ __forceinline__ void attn_x3_body(char* smem3, const float* __restric
   // The workgroup is 64 * (query tiles, at most 8) threads: every wave owns a query tile (launch_attn_x3).
   const int nthr = blockDim.x;
   constexpr int CPR = KP / 4;               // float4 chunks per padded K row
-  for (int c = tid; c < TP * CPR; c += nthr) {
-    const int key = c / CPR, ch = c - key * CPR, d0 = ch * 4;   // consecutive lanes -> one row's chunks (coalesced global reads)
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (key < T && d0 < HD) {
-      const float* rowp = base + (long long)key * D3;
-      kv = *reinterpret_cast<const float4*>(rowp + D + d0);
-      vv = *reinterpret_cast<const float4*>(rowp + 2 * D + d0);
-      if (d0 < R) {
-        const int pi = key * rot_half + (d0 >> 1);
-        const float c0 = cos_tab[pi], s0 = sin_tab[pi], c1 = cos_tab[pi + 1], s1 = sin_tab[pi + 1];
+  // U chunks per thread and iteration, every load of the U (K, V and the rotary factors) requested before the first is used: with one
+  // chunk per iteration a 256-thread workgroup (chain.hip: nobody else on the CU) walked 20 dependent round trips -- 35 of the 52 us of a
+  // (sample, head) item (tools/chain_spans.py)
+  constexpr int U = 5;
+  for (int c0 = tid; c0 < TP * CPR; c0 += U * nthr) {
+    float4 kvs[U], vvs[U];
+    float2 cfs[U][2];     // (c0, c1), (s0, s1)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nthr;
+      const int key = c / CPR, ch = c - key * CPR, d0 = ch * 4;   // consecutive lanes -> one row's chunks (coalesced global reads)
+      kvs[u] = vvs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cfs[u][0] = make_float2(1.f, 1.f);
+      cfs[u][1] = make_float2(0.f, 0.f);
+      if (c < TP * CPR && key < T && d0 < HD) {
+        const float* rowp = base + (long long)key * D3;
+        kvs[u] = ldg16(rowp + D + d0);
+        vvs[u] = ldg16(rowp + 2 * D + d0);
+        if (d0 < R) {
+          const int pi = key * rot_half + (d0 >> 1);
+          cfs[u][0] = make_float2(ldg4(cos_tab + pi), ldg4(cos_tab + pi + 1));
+          cfs[u][1] = make_float2(ldg4(sin_tab + pi), ldg4(sin_tab + pi + 1));
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = c0 + u * nthr;
+      if (c >= TP * CPR) continue;
+      const int key = c / CPR, ch = c - key * CPR, d0 = ch * 4;
+      float4 kv = kvs[u];
+      const float4 vv = vvs[u];
+      if (key < T && d0 < HD && d0 < R) {
+        const float c0f = cfs[u][0].x, c1 = cfs[u][0].y, s0 = cfs[u][1].x, s1 = cfs[u][1].y;
         const float x0 = kv.x, x1 = kv.y, x2 = kv.z, x3 = kv.w;
-        kv.x = x0 * c0 - x1 * s0;
-        kv.y = x1 * c0 + x0 * s0;
+        kv.x = x0 * c0f - x1 * s0;
+        kv.y = x1 * c0f + x0 * s0;
         kv.z = x2 * c1 - x3 * s1;
         kv.w = x3 * c1 + x2 * s1;
       }
-    }
-    {
-      bf16x4 hi, lo;
-      hi[0] = (split_t)kv.x; hi[1] = (split_t)kv.y; hi[2] = (split_t)kv.z; hi[3] = (split_t)kv.w;
-      lo[0] = (split_t)(kv.x - (float)hi[0]); lo[1] = (split_t)(kv.y - (float)hi[1]);
-      lo[2] = (split_t)(kv.z - (float)hi[2]); lo[3] = (split_t)(kv.w - (float)hi[3]);
-      char* kr = Ks + key * KROW + d0 * 2;
-      *reinterpret_cast<bf16x4*>(kr) = hi;
-      *reinterpret_cast<bf16x4*>(kr + KP * 2) = lo;
-    }
-    if (d0 < HD) {
-      // key -> position inside its 32-group: key = (j&3) + 8*(2*h2 + (j>>2)) + 4*half  <->  pos = 16*h2 + 8*half + j
-      const int k32 = key & 31;
-      const int half = (k32 >> 2) & 1, blk = k32 >> 3;                 // blk = 2*h2 + (j>>2)
-      const int pos = (key & ~31) + 16 * (blk >> 1) + 8 * half + 4 * (blk & 1) + (k32 & 3);
-      const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
+      {
+        bf16x4 hi, lo;
+        hi[0] = (split_t)kv.x; hi[1] = (split_t)kv.y; hi[2] = (split_t)kv.z; hi[3] = (split_t)kv.w;
+        lo[0] = (split_t)(kv.x - (float)hi[0]); lo[1] = (split_t)(kv.y - (float)hi[1]);
+        lo[2] = (split_t)(kv.z - (float)hi[2]); lo[3] = (split_t)(kv.w - (float)hi[3]);
+        char* kr = Ks + key * KROW + d0 * 2;
+        *reinterpret_cast<bf16x4*>(kr) = hi;
+        *reinterpret_cast<bf16x4*>(kr + KP * 2) = lo;
+      }
+      if (d0 < HD) {
+        // key -> position inside its 32-group: key = (j&3) + 8*(2*h2 + (j>>2)) + 4*half  <->  pos = 16*h2 + 8*half + j
+        const int k32 = key & 31;
+        const int half = (k32 >> 2) & 1, blk = k32 >> 3;                 // blk = 2*h2 + (j>>2)
+        const int pos = (key & ~31) + 16 * (blk >> 1) + 8 * half + 4 * (blk & 1) + (k32 & 3);
+        const float vs[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const split_t hi = (split_t)vs[i];
-        char* vr = Vt + (d0 + i) * VROW + pos * 2;
-        *reinterpret_cast<split_t*>(vr) = hi;
-        *reinterpret_cast<split_t*>(vr + TP * 2) = (split_t)(vs[i] - (float)hi);
+        for (int i = 0; i < 4; ++i) {
+          const split_t hi = (split_t)vs[i];
+          char* vr = Vt + (d0 + i) * VROW + pos * 2;
+          *reinterpret_cast<split_t*>(vr) = hi;
+          *reinterpret_cast<split_t*>(vr + TP * 2) = (split_t)(vs[i] - (float)hi);
+        }
       }
     }
   }
@@ -173,11 +197,11 @@ __device__ __forceinline__ void attn_x3_body(char* smem3, const float* __restric
           qraw[j][u] = make_float4(0.f, 0.f, 0.f, 0.f);
           cf[j][u][0] = cf[j][u][1] = make_float2(1.f, 1.f);
           if (d0 < HD) {
-            qraw[j][u] = *reinterpret_cast<const float4*>(qp + d0);
+            qraw[j][u] = ldg16(qp + d0);
             if (d0 < R) {
               const int pi = qc * rot_half + (d0 >> 1);
-              cf[j][u][0] = *reinterpret_cast<const float2*>(cos_tab + pi);
-              cf[j][u][1] = *reinterpret_cast<const float2*>(sin_tab + pi);
+              cf[j][u][0] = ldg8(cos_tab + pi);
+              cf[j][u][1] = ldg8(sin_tab + pi);
             }
           }
         }

@@ -33,28 +33,61 @@ constexpr int CHAIN_LDS = 160 * 1024;             // all of a CU's LDS: one work
 constexpr int CHAIN_CTRL = CHAIN_LDS - 64;        // the claimed item, behind the largest image an item body keeps (attention: 160 896 B)
 constexpr unsigned long long CHAIN_WAIT_TICKS = 50000000ull;   // 0.5 s of the 100 MHz clock: a dependency that never arrives ends the launch
 
-template <int ROWS_MAXV>
-__device__ __forceinline__ void chain_rows(const ChainOp& op, int kind, int row0, int wave) {
-  const GemmParams& g = op.g;
+// Row items (LayerNorm / K-slice reduce + LayerNorm): the item's rows are dealt to the four waves, row0 + wave + 4 j.  A wave requests
+// several rows before it finishes the first -- one row at a time a 16-row item took 21 us (LayerNorm) / 31 us (reduce): four round trips
+// of a lone wave in series (tools/chain_spans.py, profiles/r05_chain_spans_v1.txt).  All rows of an item belong to one sample.
+template <int MAXV>
+__device__ __forceinline__ void chain_rows(const GemmParams& g, const float* __restrict__ P, int rows_per_item, int kind, int row0, int wave, int lane) {
+  LnMod<MAXV> md;                  // the sample's modulation row (shift, scale): once per item
+  if (kind != CHAIN_REDUCE) ln_mod_load_mod<MAXV>(md, g.ln_shift, g.ln_scale, g.N, (long long)(row0 / g.ln_rows_per_batch) * g.ln_mod_ld, lane);
+  if (kind == CHAIN_LN) {
+    constexpr int R = 4;
 #pragma unroll 1
-  for (int r = wave; r < op.rows_per_item; r += 4) {
-    const int row = row0 + r;
-    if (row >= g.M) break;
-    if (kind == CHAIN_LN) {
-      ln_mod_row<ROWS_MAXV, 1>(g.A, g.ln_out, row, g.N, g.ln_eps, nullptr, nullptr, g.ln_shift, g.ln_scale, g.ln_mod_ld, g.ln_rows_per_batch, 1);
-    } else if (kind == CHAIN_REDUCE_LN) {
-      splitk_reduce_ln_row<ROWS_MAXV, 3, 1, 1>(op.P, g, row);
-    } else {
-      splitk_reduce_ln_row<ROWS_MAXV, 3, 1, 0>(op.P, g, row);
+    for (int r = wave; r < rows_per_item; r += 4 * R) {
+      LnRow<MAXV> st[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) ln_mod_load<MAXV>(st[j], g.A, min(row0 + r + 4 * j, g.M - 1), g.N, lane);
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (r + 4 * j < rows_per_item && row0 + r + 4 * j < g.M)
+          ln_mod_finish<MAXV, 1, 1>(st[j], g.ln_out, row0 + r + 4 * j, g.N, g.ln_eps, nullptr, nullptr, g.ln_shift, g.ln_scale, g.ln_mod_ld, g.ln_rows_per_batch, 1, md, lane);
+    }
+  } else {
+    RedShared<MAXV> sh;
+    splitk_reduce_shared<MAXV>(sh, g, row0, lane);
+#pragma unroll 1
+    for (int r = wave; r < rows_per_item; r += 4) {
+      const int row = row0 + r;
+      if (row >= g.M) break;
+      RedRow<MAXV, 3> st;
+      splitk_reduce_load<MAXV, 3>(st, P, g, row, lane);
+      if (kind == CHAIN_REDUCE_LN) splitk_reduce_ln_finish<MAXV, 3, 1, 1, 1>(st, sh, g, row, md, lane);
+      else splitk_reduce_ln_finish<MAXV, 3, 1, 0>(st, sh, g, row, LnMod<MAXV>{}, lane);
     }
   }
 }
 
+// a pointer read from a descriptor in memory is a generic pointer to the compiler (flat loads, lgkmcnt + vmcnt waits); through address
+// space 1 and back the address-space inference sees global memory, as it does for kernel arguments
+template <class Tp>
+__device__ __forceinline__ Tp* as_global(Tp* q) {
+  return (Tp*)(__attribute__((address_space(1))) Tp*)q;
+}
+// the descriptor's GemmParams as a LOCAL copy (uniform scalar loads, once per item; unused fields fall away) with global pointers
+__device__ __forceinline__ GemmParams chain_params(const GemmParams& m) {
+  GemmParams g = m;
+  g.A = as_global(g.A); g.B = as_global(g.B); g.C = as_global(g.C); g.bias = as_global(g.bias); g.gate = as_global(g.gate);
+  g.res = as_global(g.res); g.ln_out = as_global(g.ln_out); g.ln_shift = as_global(g.ln_shift); g.ln_scale = as_global(g.ln_scale);
+  g.aux = nullptr; g.C2 = nullptr; g.stats = nullptr; g.gn_count = nullptr; g.gn_fail = nullptr; g.gn_gamma = nullptr; g.gn_beta = nullptr;
+  g.ln_done = nullptr; g.sk_ws = nullptr; g.aload = 0; g.conv_kmajor = 0;
+  return g;
+}
+
 __global__ __launch_bounds__(256) void dit_chain_kernel(const ChainOp* __restrict__ ops, const uint4* __restrict__ items, const int n_items,
-                                                        unsigned* __restrict__ ctl, const char* __restrict__ zero_page, const int trace) {
+                                                        unsigned* __restrict__ ctl, const char* __restrict__ zero_page, const int trace,
+                                                        unsigned long long* __restrict__ times) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
   volatile int* ctrl = reinterpret_cast<volatile int*>(ring + CHAIN_CTRL);
-  const int tid = threadIdx.x;
   unsigned* progress = ctl + CHAIN_CTL_PROGRESS;
   // trace (rgm_dit_chain_peek, debugging): where every workgroup is -- { item index + 1, 1 waiting / 2 running / 3 publishing / 4 left }
   unsigned* tr = ctl + CHAIN_CTL_TRACE + 2 * blockIdx.x;
@@ -62,10 +95,21 @@ __global__ __launch_bounds__(256) void dit_chain_kernel(const ChainOp* __restric
   // compiler split the loop in two (one per back edge) and parked lane 0 -- masked, waiting for the other lanes to leave the inner loop --
   // in front of the counter update for ever, while the rest of the workgroup re-ran its item (the first run of this kernel hung that way).
   int prev_grp = -1;                                 // the item this workgroup finished last: published at the top of the next iteration
+  unsigned prev_idx = 0;
   for (;;) {
+    // the thread index behind an opaque copy, once per item: everything an item body derives from it is then computed inside the iteration.
+    // Derived from threadIdx.x directly, the loop-invariant part of every body's index arithmetic was hoisted in front of the loop, had to
+    // live through the 512-register GEMM body in scratch, and every reload (a VMEM load: s_waitcnt vmcnt(0)) sat between the row items'
+    // global loads -- five serial round trips where one was written (a 16-row LayerNorm item: 15 us)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     if (tid == 0) {
       if (prev_grp >= 0) __hip_atomic_fetch_add(progress + prev_grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // times (rgm_dit_chain_times, tools/chain_spans.py): per item { claimed, dependencies met, finished, workgroup } on the 100 MHz clock
+      if (times && prev_grp >= 0) times[8 * (size_t)prev_idx + 2] = __builtin_amdgcn_s_memrealtime();
+      const unsigned long long t_claim = times ? __builtin_amdgcn_s_memrealtime() : 0ull;
       const unsigned idx = __hip_atomic_fetch_add(&ctl[CHAIN_CTL_HEAD], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      prev_idx = idx;
       int w0 = -1, w1 = 0;
       if (trace) {
         __hip_atomic_store(tr, idx + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -96,6 +140,11 @@ __global__ __launch_bounds__(256) void dit_chain_kernel(const ChainOp* __restric
       }
       ctrl[0] = w0;
       ctrl[1] = w1;
+      if (times && w0 >= 0) {
+        times[8 * (size_t)idx] = t_claim;
+        times[8 * (size_t)idx + 1] = __builtin_amdgcn_s_memrealtime();
+        times[8 * (size_t)idx + 3] = blockIdx.x;
+      }
       if (trace) __hip_atomic_store(tr + 1, w0 < 0 ? 4u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
@@ -105,16 +154,24 @@ __global__ __launch_bounds__(256) void dit_chain_kernel(const ChainOp* __restric
     const int opi = w0 & 0xffff, grp = (w0 >> 16) & 0xffff, sub = w1 & 0xffff, z = (w1 >> 16) & 0xffff;
     const ChainOp& op = ops[opi];
     const int kind = __builtin_amdgcn_readfirstlane(op.kind);
+    const GemmParams gp = chain_params(op.g);
     if (kind == CHAIN_GEMM) {
-      gemm2_body<256, 256, 2, 2, 0, 2, 0, 5, 1>(op.g, zero_page, 0, op.tiles_n, 0, nullptr, grp * op.tiles_n + sub, z, -1);
+      const int tn = op.tiles_n;
+      gemm2_body<256, 256, 2, 2, 0, 2, 0, 5, 1>(gp, zero_page, 0, tn, 0, nullptr, grp * tn + sub, z, -1, tid);
     } else if (kind == CHAIN_ATTN) {
-      attn_x3_body<72, 8, 1>(ring, op.g.A, op.g.C, op.cos_tab, op.sin_tab, op.T, op.heads, op.rot_half, nullptr, 1, 1, grp * op.heads + sub);
+      const int heads = op.heads;
+      attn_x3_body<72, 8, 1>(ring, gp.A, gp.C, as_global(op.cos_tab), as_global(op.sin_tab), op.T, heads, op.rot_half, nullptr, 1, 1, grp * heads + sub, tid);
     } else {
-      chain_rows<5>(op, kind, grp * op.rows_per_group + sub * op.rows_per_item, tid >> 6);
+      const int rpi = op.rows_per_item;
+      chain_rows<5>(gp, as_global(op.P), rpi, kind, grp * op.rows_per_group + sub * rpi, tid >> 6, tid & 63);
     }
     // publish: the item's stores are device-coherent and complete when vmcnt retires them; only then may the sample's counter move
     // (lane 0 adds to it first thing behind this barrier, at the top of the next iteration)
+    int tid_b = threadIdx.x;                           // (a second opaque copy: nothing of the first lives through the body)
+    asm volatile("" : "+v"(tid_b));
+    if (times && tid_b == 0) times[8 * (size_t)prev_idx + 4] = __builtin_amdgcn_s_memrealtime();     // wave 0 left the body
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (times && tid_b == 0) times[8 * (size_t)prev_idx + 5] = __builtin_amdgcn_s_memrealtime();     // ... and its stores have retired
     __syncthreads();
     prev_grp = grp;
   }
@@ -123,7 +180,8 @@ __global__ __launch_bounds__(256) void dit_chain_kernel(const ChainOp* __restric
 static char* g_chain_zero_page = nullptr;
 static long long g_chain_launches = 0;
 
-int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, unsigned* d_ctl, int n_groups, hipStream_t s) {
+int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, unsigned* d_ctl, int n_groups, hipStream_t s,
+                     unsigned long long* d_times) {
   RGM_REQUIRE(d_ops && d_items && d_ctl && n_items > 0 && n_groups > 0 && n_groups <= CHAIN_MAX_GROUPS, "dit_chain: bad arguments");
   if (!g_chain_zero_page) {
     RGM_CHECK_HIP(hipMalloc(&g_chain_zero_page, 4096));
@@ -141,7 +199,7 @@ int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, un
   static const int trace = getenv("RGM_CHAIN_TRACE") ? atoi(getenv("RGM_CHAIN_TRACE")) : 0;
   RGM_REQUIRE(cus <= CHAIN_MAX_CUS, "dit_chain: %d CUs", cus);
   RGM_CHECK_HIP(hipMemsetAsync(d_ctl, 0, sizeof(unsigned) * (trace ? CHAIN_CTL_WORDS : CHAIN_CTL_PROGRESS + n_groups), s));
-  hipLaunchKernelGGL(dit_chain_kernel, dim3(cus), dim3(256), CHAIN_LDS, s, d_ops, d_items, n_items, d_ctl, (const char*)g_chain_zero_page, trace);
+  hipLaunchKernelGGL(dit_chain_kernel, dim3(cus), dim3(256), CHAIN_LDS, s, d_ops, d_items, n_items, d_ctl, (const char*)g_chain_zero_page, trace, d_times);
   RGM_LAUNCH_CHECK();
   ++g_chain_launches;
   return RGM_OK;

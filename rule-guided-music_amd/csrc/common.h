@@ -95,12 +95,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // paired over two lanes first (store_split4_pair_sc1).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void store16_sc1(void* p, const f32x4& v) {
-  // "memory": the epilogues count on program order between their LDS-DMA loads and these stores (gemm2_body.h: s_waitcnt vmcnt(<stores of
-  // one slab>)); without the clobber the compiler moved the DMA builtins across the asm and a slab was read before it had landed
   // s_nop: a store of more than 8 bytes still reads its data registers for a wait state or two after issue, and the compiler's hazard
   // recogniser does not see a store inside an asm statement -- without it the next VALU write of those registers corrupted the last
-  // four lanes of every 16 (found on the attention output: rows 12-15 / 28-31 of a query tile, run-to-run different)
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+  // four lanes of every 16 (found on the attention output: rows 12-15 / 28-31 of a query tile, run-to-run different).
+  // No "memory" clobber: a clobber pins every load behind the previous store (the row items of chain.hip walked one round trip per
+  // 16-byte chunk that way); volatile asm statements keep their order among themselves, and where an epilogue counts on the order of its
+  // LDS-DMA loads against these stores (gemm2_body.h staged_dma_res) it fences the loads with compiler barriers of its own.
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v));
 }
 typedef split_t split_x4 __attribute__((ext_vector_type(4)));
 // A lane holds 4 consecutive elements (columns col .. col + 3, col % 4 == 0) of a split row as hi / lo halves; its partner lane
@@ -119,6 +120,21 @@ __device__ __forceinline__ void store_split4_pair_sc1(split_t* rowp, int col, co
   const u32x4 out = even ? u32x4{mine_hi[0], mine_hi[1], recv[0], recv[1]} : u32x4{recv[0], recv[1], mine_lo[0], mine_lo[1]};
   split_t* dst = rowp + split_idx(col & ~7) + (even ? 0 : 32);
   store16_sc1(dst, __builtin_bit_cast(f32x4, out));
+}
+
+// 16-byte load from GLOBAL memory, said so: a pointer that reaches a device function through a descriptor in memory (chain.hip) is a
+// generic pointer to the compiler -- flat loads, which count on lgkmcnt as well and serialise against the LDS traffic around them
+__device__ __forceinline__ float4 ldg16(const float* q) {
+  const f32x4 v = *(const __attribute__((address_space(1))) f32x4*)q;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float2 ldg8(const float* q) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t v = *(const __attribute__((address_space(1))) f32x2_t*)q;
+  return make_float2(v[0], v[1]);
+}
+__device__ __forceinline__ float ldg4(const float* q) {
+  return *(const __attribute__((address_space(1))) float*)q;
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -287,7 +303,8 @@ struct ChainOp {
   const float* sin_tab = nullptr;
   int T = 0, heads = 0, rot_half = 0;
 };
-int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, unsigned* d_ctl, int n_groups, hipStream_t s);
+int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, unsigned* d_ctl, int n_groups, hipStream_t s,
+                     unsigned long long* d_times = nullptr);
 long long dit_chain_launch_count();
 
 // elementwise / reductions (elementwise.hip)

@@ -107,6 +107,8 @@ struct rgm_dit {
   unsigned* chain_ctl = nullptr;
   size_t chain_ops_cap = 0, chain_items_cap = 0;
   int chain_N = 0, chain_H = 0, chain_n_items = 0, chain_order = -1;
+  unsigned long long* chain_times = nullptr;   // RGM_CHAIN_TIMES=1: per-item time stamps of the last persistent forward
+  size_t chain_times_cap = 0;
   const void* chain_ws = nullptr;
 
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
@@ -280,6 +282,7 @@ extern "C" void rgm_dit_destroy(rgm_dit* h) {
   if (h->chain_ops) (void)hipFree(h->chain_ops);
   if (h->chain_items) (void)hipFree(h->chain_items);
   if (h->chain_ctl) (void)hipFree(h->chain_ctl);
+  if (h->chain_times) (void)hipFree(h->chain_times);
   delete h;
 }
 
@@ -560,7 +563,13 @@ int run_chain(rgm_dit* h, const Plan& p, const void* ws, hipStream_t s) {
     }
     h->chain_N = N; h->chain_H = p.H; h->chain_ws = ws;
   }
-  return dit_chain_launch(h->chain_ops, h->chain_items, h->chain_n_items, h->chain_ctl, N, s);
+  static const int want_times = getenv("RGM_CHAIN_TIMES") ? atoi(getenv("RGM_CHAIN_TIMES")) : 0;
+  if (want_times && h->chain_times_cap < (size_t)h->chain_n_items) {
+    if (h->chain_times) RGM_CHECK_HIP(hipFree(h->chain_times));
+    RGM_CHECK_HIP(hipMalloc(&h->chain_times, (size_t)h->chain_n_items * 8 * sizeof(unsigned long long)));
+    h->chain_times_cap = (size_t)h->chain_n_items;
+  }
+  return dit_chain_launch(h->chain_ops, h->chain_items, h->chain_n_items, h->chain_ctl, N, s, want_times ? h->chain_times : nullptr);
 }
 
 // embedders + blocks; leaves the residual stream in plan.x and SiLU(c) modulation in plan.mod
@@ -1205,6 +1214,23 @@ extern "C" int rgm_dit_chain_peek(rgm_dit* h, unsigned* out, int words) {
   if (!ps) RGM_CHECK_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
   RGM_CHECK_HIP(hipMemcpyAsync(out, h->chain_ctl, sizeof(unsigned) * words, hipMemcpyDeviceToHost, ps));
   RGM_CHECK_HIP(hipStreamSynchronize(ps));
+  return RGM_OK;
+}
+
+// debugging / measurement (RGM_CHAIN_TIMES=1): per item of the handle's last persistent forward { claimed, dependencies met, finished,
+// workgroup, wave 0 left the body, wave 0's stores retired, -, - } (8 words) on the 100 MHz clock, and the item list itself { op | group << 16, sub | z << 16, need, 0 }; synchronises the device.
+// *n_items receives the item count; out_times / out_items (optional) take 4 words per item.
+extern "C" int rgm_dit_chain_times(rgm_dit* h, unsigned long long* out_times, unsigned* out_items, int cap_items, int* n_items) {
+  RGM_REQUIRE(h && n_items, "dit_chain_times: null argument");
+  *n_items = h->chain_n_items;
+  if (!out_times && !out_items) return RGM_OK;
+  RGM_REQUIRE(cap_items >= h->chain_n_items, "dit_chain_times: room for %d items, %d needed", cap_items, h->chain_n_items);
+  RGM_CHECK_HIP(hipDeviceSynchronize());
+  if (out_times) {
+    RGM_REQUIRE(h->chain_times, "dit_chain_times: no time stamps (RGM_CHAIN_TIMES=1 before the first forward)");
+    RGM_CHECK_HIP(hipMemcpy(out_times, h->chain_times, (size_t)h->chain_n_items * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  }
+  if (out_items) RGM_CHECK_HIP(hipMemcpy(out_items, h->chain_items, (size_t)h->chain_n_items * sizeof(uint4), hipMemcpyDeviceToHost));
   return RGM_OK;
 }
 

@@ -21,7 +21,7 @@ __device__ __forceinline__ void dma16(const void* gsrc, void* lds_dst) {
 // (gemm2_dual_kernel below); gemm2_kernel is the plain one-shape wrapper.
 template <int BM, int BN, int WM, int WN, int ALOAD, int NSTAGE, int DBG = 0, int PIPE = 0, int COH = 0>
 __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __restrict__ zero_page, int tiles_m, int tiles_n, int exp,
-                                           long long* __restrict__ dbg, const int bid, const int z, const int rec_bid) {
+                                           long long* __restrict__ dbg, const int bid, const int z, const int rec_bid, const int tid_in = -1) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int STAGE = (BM + BN) * 128;        // bytes per ring stage: BM A rows then BN B rows, one 128-B line each
@@ -49,7 +49,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   const int m0 = COH ? (bid / tiles_n) * BM : (first_m + in_g % gsz) * BM;
   const int n0 = COH ? (bid % tiles_n) * BN : (in_g / gsz) * BN;
 
-  const int tid = threadIdx.x;
+  const int tid = tid_in >= 0 ? tid_in : (int)threadIdx.x;      // (chain.hip hands in an opaque copy: see there)
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
 
@@ -776,7 +776,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     const int col = n0 + bcol0 + lc;
     const bool col_ok = col < p.N;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (biasb && col_ok) bv = *reinterpret_cast<const float4*>(biasb + col);
+    if (biasb && col_ok) bv = ldg16(biasb + col);
     double gs[8] = {0., 0., 0., 0., 0., 0., 0., 0.};   // p.stats: this lane's column sums / sums of squares (fp64: see common.h)
     constexpr int NJ = 32 / RPI;
     auto write_slab = [&](auto im_c, float* slab) {
@@ -921,11 +921,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
               for (int q4 = 0; q4 < 4; ++q4) v[q4] *= (p.act == 3 ? gelu_tanh_grad_f(xs[q4]) : silu_grad_f(xs[q4]));
             }
             if (p.gate) {
-              const float4 g = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+              const float4 g = ldg16(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
               v[0] *= g.x; v[1] *= g.y; v[2] *= g.z; v[3] *= g.w;
             }
             if (resb) {
-              const float4 rr = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+              const float4 rr = ldg16(resb + (long long)row * p.ldres + col);
               v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
             }
             if (p.stats) {
@@ -948,8 +948,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         g4[j] = make_float4(1.f, 1.f, 1.f, 1.f);
         r4[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (row < p.M && col_ok) {
-          if (p.gate) g4[j] = *reinterpret_cast<const float4*>(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
-          if (resb && exp != 8) r4[j] = *reinterpret_cast<const float4*>(resb + (long long)row * p.ldres + col);
+          if (p.gate) g4[j] = ldg16(p.gate + (long long)(row / p.rows_per_gate) * p.gate_ld + col);
+          if (resb && exp != 8) r4[j] = ldg16(resb + (long long)row * p.ldres + col);
         }
       }
 #pragma unroll
@@ -985,6 +985,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // one slab>) and never waits for a store.  With the residual loads behind the previous slab's stores (linear_rows) every slab
     // sat out its own round trip AND the previous slab's last store: 15-19 k cycles per slab (tools/conv_stamp.py).
     auto staged_dma_res = [&](int row0, float* rslab) {
+      if constexpr (COH) asm volatile("" ::: "memory");   // (COH stores are asm statements: keep the DMA where the counted waits expect it)
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int row = row0 + j * RPI;
@@ -992,6 +993,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                                                                       : reinterpret_cast<const float*>(zero_page) + lc;
         dma16(src, reinterpret_cast<char*>(rslab) + j * 1024);
       }
+      if constexpr (COH) asm volatile("" ::: "memory");
     };
     auto staged_pass1 = [&](float* slab, const float* rslab, int row0, float4 g_lo, float4 g_hi, int bnd) {
       constexpr int U = 4;
@@ -1232,8 +1234,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
               const int g0 = (m0 + arow0 + im * 32) / p.rows_per_gate, glast = (p.M - 1) / p.rows_per_gate;
               bnd[im] = (g0 + 1) * p.rows_per_gate;
               if (col_ok) {
-                g_lo[im] = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0, glast) * p.gate_ld + col);
-                g_hi[im] = *reinterpret_cast<const float4*>(p.gate + (long long)min(g0 + 1, glast) * p.gate_ld + col);
+                g_lo[im] = ldg16(p.gate + (long long)min(g0, glast) * p.gate_ld + col);
+                g_hi[im] = ldg16(p.gate + (long long)min(g0 + 1, glast) * p.gate_ld + col);
               }
             }
           });

@@ -86,6 +86,7 @@ def _load():
         "rgm_dit_chain_launches": (C.c_longlong, []),
         "rgm_dit_chain_status": (C.c_int, [vp, vp]),
         "rgm_dit_chain_peek": (C.c_int, [vp, vp, i32]),
+        "rgm_dit_chain_times": (C.c_int, [vp, vp, vp, i32, vp]),
         "rgm_set_gn_fuse": (C.c_int, [i32, vp]),
         "rgm_gn_fused_launches": (C.c_longlong, []),
         "rgm_split_dtype": (C.c_int, []),
