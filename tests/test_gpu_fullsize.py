@@ -630,7 +630,7 @@ def test_eight_rank_long_sequence_bench_control_flow_on_one_device():
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RGM_BENCH_ONE_DEVICE="1")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-extras", "--workload", "long", "--steps", "1",
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-extras", "--workload", "long", "--batch", "1", "--steps", "1",
                           "--warmup", "1", "--repeats", "1"], capture_output=True, text=True, timeout=2400, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
