@@ -142,6 +142,10 @@ int rgm_set_adaln_overlap(int on);
  * receives the previous mode; rgm_gn_fused_launches() counts the launches that took the route. */
 int rgm_set_gn_fuse(int mode, int* prev);
 long long rgm_gn_fused_launches(void);
+/* Tiles of those fused launches whose bounded wait (1 ms) for the image's other tiles ran out -- they write raw rows and a fix-up pass
+ * converts them, same values -- since the last reset; synchronises the device; reset != 0 zeroes the counter.  0 on an idle device:
+ * a non-zero count says another stream held CUs while a decode ran (each such tile costs up to 1 ms). */
+long long rgm_gn_fallback_tiles(int reset);
 /* Blocks of an eps-network forward (ref guided_diffusion/dit.py:618-634: samples are independent inside a block) as TWO half batches, the
  * second on a side stream owned by the handle, forked from and joined to the caller's stream by events (stream-ordered for the caller):
  * one half's kernels fill the CUs the other half's last round of one-workgroup-per-CU tiles leaves idle.  Batches of at least

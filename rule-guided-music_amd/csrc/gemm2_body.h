@@ -1127,7 +1127,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                 ok = 1;
                 break;
               }
-              if (__builtin_amdgcn_s_memrealtime() - t0 > 400000ull) break;     // 4 ms of the 100 MHz clock: a sibling tile is not resident
+              // 1 ms of the 100 MHz clock (a handful of tile times: 36-K-tile conv tiles run 100-200 us): a sibling tile is not resident --
+              // another stream holds its CU.  Every such tile is counted by gn_fixup_kernel (rgm_gn_fallback_tiles); round 4 waited 4 ms.
+              if (__builtin_amdgcn_s_memrealtime() - t0 > 100000ull) break;
               __builtin_amdgcn_s_sleep(16);
             }
           }

@@ -284,9 +284,11 @@ __global__ __launch_bounds__(256) void gn_apply8_kernel(const float* __restrict_
 // eight lanes read it before any of them writes.  One workgroup per tile; it leaves at once when the flag is down (the normal case).
 __global__ __launch_bounds__(256) void gn_fixup_kernel(float* __restrict__ y, const int* __restrict__ fail, const double* __restrict__ tp,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int tiles_n,
-                                                       int rows, int bn, int C, int tiles_per_img, double count, float eps, int swish) {
+                                                       int rows, int bn, int C, int tiles_per_img, double count, float eps, int swish,
+                                                       unsigned long long* __restrict__ fallbacks) {
   const int tile = blockIdx.x;
   if (!fail[tile]) return;
+  if (threadIdx.x == 0) atomicAdd(fallbacks, 1ull);      // rgm_gn_fallback_tiles: a tile whose wait ran out is otherwise only visible as lost time
   typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
   const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
   const int qpr = bn >> 2;                               // column quads per tile row: 32 or 64
@@ -1068,6 +1070,7 @@ VPlan vplan(int M, void* ws) {
 // every tile forced onto the fallback (tests of gn_fixup_kernel)
 static int g_gn_fuse = getenv("RGM_GN_FUSE") ? atoi(getenv("RGM_GN_FUSE")) : 1;
 static long long g_gn_fused_launches = 0;
+static unsigned long long* g_gn_fallbacks = nullptr;      // device counter: tiles that took the raw-row fallback (gn_fixup_kernel)
 
 struct Ctx {
   rgm_vae* h;
@@ -1195,9 +1198,13 @@ int conv3(Ctx& c, const float* in, float* out, int H, int Cin, int Cout, const s
         g.gn_swish = 1;
         g.gn_force_fail = g_gn_fuse == 2 ? 1 : 0;
         g.out_split = 1;
+        if (!g_gn_fallbacks) {
+          RGM_CHECK_HIP(hipMalloc(&g_gn_fallbacks, sizeof(unsigned long long)));
+          RGM_CHECK_HIP(hipMemset(g_gn_fallbacks, 0, sizeof(unsigned long long)));
+        }
         RGM_TRY(gemm2_launch(g, c.s));
         hipLaunchKernelGGL(gn_fixup_kernel, dim3((unsigned)(tm * tn)), dim3(256), 0, c.s, out, (const int*)g.gn_fail, (const double*)c.p.tpart,
-                           g.gn_gamma, g.gn_beta, (int)tn, rows, bn, Cout, (int)tpi, g.gn_n, g.gn_eps, 1);
+                           g.gn_gamma, g.gn_beta, (int)tn, rows, bn, Cout, (int)tpi, g.gn_n, g.gn_eps, 1, g_gn_fallbacks);
         RGM_LAUNCH_CHECK();
         *fused = 1;
         ++g_gn_fused_launches;
@@ -1308,6 +1315,17 @@ extern "C" int rgm_set_gn_fuse(int mode, int* prev) {
   return RGM_OK;
 }
 extern "C" long long rgm_gn_fused_launches(void) { return g_gn_fused_launches; }
+// tiles of fused GroupNorm launches that gave up waiting for their image's other tiles and took the raw-row fallback since the last reset
+// (synchronises the device; reset != 0 zeroes the counter afterwards).  0 on an idle device; forced-fallback launches (rgm_set_gn_fuse(2))
+// count every tile.  -1 on a HIP error.
+extern "C" long long rgm_gn_fallback_tiles(int reset) {
+  if (!g_gn_fallbacks) return 0;
+  unsigned long long v = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&v, g_gn_fallbacks, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  if (reset && hipMemset(g_gn_fallbacks, 0, sizeof(v)) != hipSuccess) return -1;
+  return (long long)v;
+}
 
 extern "C" size_t rgm_vae_workspace_bytes(const rgm_vae* h, int M) {
   if (!h || M <= 0) return 0;

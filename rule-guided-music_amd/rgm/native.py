@@ -89,6 +89,7 @@ def _load():
         "rgm_dit_chain_times": (C.c_int, [vp, vp, vp, i32, vp]),
         "rgm_set_gn_fuse": (C.c_int, [i32, vp]),
         "rgm_gn_fused_launches": (C.c_longlong, []),
+        "rgm_gn_fallback_tiles": (C.c_longlong, [i32]),
         "rgm_split_dtype": (C.c_int, []),
         "rgm_set_attn_split": (C.c_int, [i32]),
         "rgm_fused_reduce_ln_launches": (C.c_longlong, []),

@@ -811,10 +811,13 @@ def test_groupnorm_inside_the_conv_launch_equals_the_separate_pass(n):
         apart = _decode(z, vae, 1.0).clone()
         assert R.lib.rgm_gn_fused_launches() == n0
         R.check(R.lib.rgm_set_gn_fuse(1, None))
+        R.lib.rgm_gn_fallback_tiles(1)
         fused = [_decode(z, vae, 1.0).clone() for _ in range(2)]
         launches = R.lib.rgm_gn_fused_launches() - n0
+        assert R.lib.rgm_gn_fallback_tiles(1) == 0               # an idle device: no tile ever gives up its wait
         R.check(R.lib.rgm_set_gn_fuse(2, None))
         fallback = _decode(z, vae, 1.0).clone()
+        assert R.lib.rgm_gn_fallback_tiles(1) > 0                # forced: every tile of every fused launch is counted
     finally:
         R.check(R.lib.rgm_set_gn_fuse(prev.value, None))
         R.set_gemm_precision("fp32")
@@ -823,6 +826,59 @@ def test_groupnorm_inside_the_conv_launch_equals_the_separate_pass(n):
     assert torch.equal(fused[0], fused[1])
     assert torch.equal(fused[0], apart), float((fused[0] - apart).abs().max())
     assert torch.equal(fallback, apart), float((fallback - apart).abs().max())
+
+
+def test_fused_groupnorm_decode_beside_a_stream_that_holds_cus():
+    """The image-level wait of the fused GroupNorm assumes an image's tiles are resident together; another stream can take CUs away
+    (the library itself runs classifier chains and half batches on side streams).  64 latents are decoded while a second stream runs
+    XL-28 forwards at B = 16 back to back: the rolls must equal the quiet decode bit for bit (a tile whose 1 ms wait runs out takes the
+    raw-row fallback: same values), rgm_gn_fallback_tiles reports how many did, and the pair may not take longer than 1.5 x the two
+    run one after the other (a stalled decode would: every fallback tile costs up to 1 ms)."""
+    import time
+    from gpu_util import dev
+    from rgm import native as R
+    from guided_diffusion.gaussian_diffusion import _decode
+    R.set_gemm_precision("bf16x3_presplit")
+    try:
+        vae = _vae()
+        m = _dit(dict(XL2, depth=28), 1)
+        z = dev(np.random.RandomState(64).randn(64, 4, 128, 16).astype(F32))
+        rng = np.random.RandomState(3)
+        x = dev(rng.randn(16, 4, 128, 16).astype(F32))
+        t = dev(rng.randint(0, 1000, size=16).astype(np.int64))
+        y = dev(rng.randint(0, 3, size=16).astype(np.int64))
+        quiet = _decode(z, vae, 1.0).clone()
+        m(x, t, y)
+        torch.cuda.synchronize()
+
+        def timed(fn):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            return time.perf_counter() - t0
+        NF = 12                                                      # ~12 x 12.8 ms of foreign forwards beside a ~165 ms decode
+        t_dec = min(timed(lambda: _decode(z, vae, 1.0)) for _ in range(2))
+        t_for = min(timed(lambda: [m(x, t, y) for _ in range(NF)]) for _ in range(2))
+        side = torch.cuda.Stream()
+        R.lib.rgm_gn_fallback_tiles(1)
+        outs = []
+
+        def both():
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(NF):
+                    m(x, t, y)
+            outs.append(_decode(z, vae, 1.0))
+            torch.cuda.current_stream().wait_stream(side)
+        t_both = timed(both)
+        fallbacks = R.lib.rgm_gn_fallback_tiles(1)
+        print(f"decode {t_dec * 1e3:.1f} ms, {NF} forwards {t_for * 1e3:.1f} ms, together {t_both * 1e3:.1f} ms, fallback tiles {fallbacks}")
+        assert fallbacks >= 0
+        assert torch.equal(outs[0], quiet)
+        assert t_both < 1.5 * (t_dec + t_for), (t_dec, t_for, t_both, fallbacks)
+    finally:
+        R.set_gemm_precision("fp32")
 
 
 def test_vae_decoder_golden_through_the_big_tile_conv_kernels():
