@@ -151,3 +151,14 @@ def test_chain_only_takes_the_shapes_it_was_built_for():
     with _Chain(8) as ch:
         m(x, t, y)                                     # 4 < min_batch
     assert ch.launches == 0
+
+
+def test_kernels_with_the_load_wait_use_pattern_are_bit_stable():
+    """tools/isa_lint.py finds the instruction pattern of the round-4 attention hazard in most kernels -- it is the plain way to
+    consume a vector load.  Those that share their CUs with lock-step twins of themselves are soaked here: 12 runs per case on fixed
+    inputs (tools/hazard_soak.py; the round's record holds 100), every run bit-identical to the first."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hazard_soak
+    lines = []
+    assert hazard_soak.soak(12, log=lines.append) == 0, lines

@@ -1,6 +1,7 @@
 #!/bin/bash
 # End-of-round evidence in ONE gpurun call: the default bench line, rocprofv3 kernel stats of every BASELINE workload and the small batches.
-#   gpurun --timeout 3000 -- tools/end_of_round.sh r04
+#   gpurun --timeout 3000 -- tools/end_of_round.sh r05
+# (tools/isa_lint.py runs HERE, on the CPU -- it only compiles: python tools/isa_lint.py > profiles/r05_isa_lint.txt)
 set -u
 R=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
@@ -17,6 +18,8 @@ tools/prof_bench.sh ${R}_c2_b4 --no-extras --batch 4 --steps 20 --warmup 5 > /de
 tools/prof_bench.sh ${R}_c2_b8 --no-extras --batch 8 --steps 20 --warmup 5 > /dev/null 2>&1
 python tools/batch_sweep.py > gpurun_out/${R}_batch_sweep.txt 2>&1
 python tools/cls_time.py 1 4 8 16 32 > gpurun_out/${R}_cls_time.txt 2>&1
+python tools/hazard_soak.py 100 > gpurun_out/${R}_hazard_soak.txt 2>&1
+RGM_CHAIN_TIMES=1 python tools/chain_spans.py 16 28 > gpurun_out/${R}_chain_spans.txt 2>&1
 for f in gpurun_out/${R}_*_bench_under_rocprof.json gpurun_out/${R}_bench_default_n1.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:
