@@ -159,6 +159,11 @@ int rgm_set_dit_halves(int min_batch, int* prev);
  * arithmetic, 256 tokens per sample, head_dim 72) take it; 0 = never; -1 = the batch sizes where it measured ahead.  *prev (optional)
  * receives the previous setting.  rgm_dit_chain_launches: persistent launches so far (tests).  rgm_dit_chain_status: synchronises the
  * device; *status = 0 when every item of the handle's last persistent forward ran, k > 0 when item k - 1 gave up its bounded wait. */
+/* Short-sequence attention of the bf16x3 modes at head_dim 72 (T <= 128: C5's half windows; ref guided_diffusion/dit.py:263-288) with TWO
+ * workgroups per CU (four waves and 79 KiB of LDS each) instead of the one-per-CU guard of round 3: the guard answered a hazard of the
+ * interleaved Q prologue, which the two-phase prologue removed (profiles/r05_attn_hazard_two_phase_n96.txt).  1 = on,
+ * 0 = guard (default).  Returns the previous setting. */
+int rgm_set_attn_pairs(int on);
 int rgm_set_dit_chain(int min_batch, int* prev);
 long long rgm_dit_chain_launches(void);
 int rgm_dit_chain_status(rgm_dit* h, int* status);

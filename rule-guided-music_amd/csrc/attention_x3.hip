@@ -29,6 +29,8 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_kernel(const float* _
   attn_x3_body<HD, NKT>(smem3, qkv, o, cos_tab, sin_tab, T, heads, rot_half, lse, out_split, qgroups, (int)blockIdx.x);
 }
 
+static int g_attn_pairs = getenv("RGM_ATTN_PAIRS") ? atoi(getenv("RGM_ATTN_PAIRS")) : 0;   // rgm_set_attn_pairs
+
 template <int HD, int NKT>
 static int launch_attn_x3(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,
                           float* lse, int out_split, hipStream_t s) {
@@ -39,6 +41,19 @@ static int launch_attn_x3(const float* qkv, float* o, const float* ct, const flo
   // which this kernel returned wrong rows in round 3 (1 launch in ~10 at N = 48, T = 128).
   static const int allow_two = RGM_EXP_ENV("RGM_ATTN_TWO_PER_CU");      // experiments only (common.h): reproduce the hazard
   auto kern = rotary_attention_x3_kernel<HD, NKT>;
+  // Round 5: with the two-phase Q prologue (attention_x3_body.h) the probe of DESIGN 4h stays clean at TWO workgroups per CU -- 0 wrong
+  // workgroups of 4.6 million (3 x 1000 launches x 1536, profiles/r05_attn_hazard_two_phase_n96.txt; the interleaved prologue on the same
+  // box: 22 of 40 launches wrong).  rgm_set_attn_pairs(1) lifts the guard for THIS instantiation only (hd = 72, T <= 128: C5's half
+  // windows): four waves (one per query tile) and the exact 79 KiB, so that two workgroups share a CU.
+  if (HD == 72 && NKT == 4 && g_attn_pairs && !allow_two) {
+    static bool attr_p = false;
+    if (!attr_p) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_p = true;
+    const int nqt_p = (T + 31) / 32;
+    hipLaunchKernelGGL(kern, dim3(N * heads), dim3(64 * nqt_p), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split, 1);
+    RGM_LAUNCH_CHECK();
+    return RGM_OK;
+  }
   if (allow_two) {
     static bool attr2 = false;
     if (!attr2) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -433,6 +448,12 @@ int rotary_attention_fwd(const float* qkv, float* o, const float* cos_tab, const
   return rotary_attention_launch(qkv, o, cos_tab, sin_tab, N, T, heads, hd, rot_half, s, lse, out_split);
 }
 
+int attn_pairs_set(int on) {
+  const int prev = g_attn_pairs;
+  g_attn_pairs = on;
+  return prev;
+}
+
 #ifdef RGM_ATTN_STAMPS
 int attn_stamps_copy(long long* out) {
   RGM_CHECK_HIP(hipDeviceSynchronize());
@@ -446,3 +467,6 @@ int attn_stamps_copy(long long* out) {
 #ifdef RGM_ATTN_STAMPS
 extern "C" int rgm_attn_stamps(long long* out128)  /* 128 phase stamps + 2048 entry/exit real-time stamps */ { return rgm::attn_stamps_copy(out128); }
 #endif
+// Two workgroups per CU for the short-sequence attention at head_dim 72 (T <= 128): 1 = on, 0 = one per CU (the round-3 guard; default).
+// Returns the previous setting.
+extern "C" int rgm_set_attn_pairs(int on) { return rgm::attn_pairs_set(on != 0); }

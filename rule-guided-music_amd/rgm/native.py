@@ -83,6 +83,7 @@ def _load():
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
         "rgm_set_dit_halves": (C.c_int, [i32, vp]),
         "rgm_set_dit_chain": (C.c_int, [i32, vp]),
+        "rgm_set_attn_pairs": (C.c_int, [i32]),
         "rgm_dit_chain_launches": (C.c_longlong, []),
         "rgm_dit_chain_status": (C.c_int, [vp, vp]),
         "rgm_dit_chain_peek": (C.c_int, [vp, vp, i32]),

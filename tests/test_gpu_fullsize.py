@@ -732,6 +732,40 @@ def test_every_attention_launcher_keeps_one_workgroup_per_cu(N, T, heads, hd, ro
     assert bool(torch.isfinite(dq).all())
 
 
+@pytest.mark.parametrize("N,T", [(96, 128), (48, 128), (40, 96), (13, 128)])
+def test_short_sequence_attention_with_two_workgroups_per_cu(N, T):
+    """rgm_set_attn_pairs(1): the head_dim-72 attention at T <= 128 with TWO workgroups per CU -- the co-residency under which the round-3
+    kernel returned wrong rows and which the two-phase Q prologue of round 5 makes safe (tools/ubench/attn_hazard: 0 wrong
+    workgroups of 4.6 million).  30 launches per shape, every one bit-identical to the guarded (one per CU) launch."""
+    from gpu_util import dev
+    from rgm import native as R
+    from rgm.synth import rotary_freqs
+    from oracle import dit_np as odit
+    R.set_gemm_precision("bf16x3_presplit")
+    try:
+        heads, hd, rot = 16, 72, 36
+        rng = np.random.RandomState(N + T)
+        D = heads * hd
+        qd = dev((rng.randn(N * T, 3 * D) * 1.2).astype(F32))
+        cos, sin = odit.rotary_tables(rotary_freqs(rot), T)
+        cd, sd_ = dev(cos), dev(sin)
+
+        def run():
+            od = torch.full((N * T, D), float("nan"), device="cuda")
+            R.check(R.lib.rgm_rotary_attention(R.ptr(qd), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, rot // 2, R.current_stream()))
+            return od
+        guarded = run()
+        prev = R.lib.rgm_set_attn_pairs(1)
+        try:
+            assert prev == 0
+            for k in range(30):
+                assert torch.equal(run(), guarded), k
+        finally:
+            R.lib.rgm_set_attn_pairs(prev)
+    finally:
+        R.set_gemm_precision("fp32")
+
+
 @pytest.mark.parametrize("N,T,heads,hd", [(4, 257, 6, 64), (32, 257, 6, 64), (3, 256, 16, 72), (5, 128, 16, 72), (2, 161, 6, 64)])
 def test_per_tile_attention_workgroups_match_the_per_head_ones(N, T, heads, hd, precision):
     """rgm_set_attn_split: the classifier path's attention (257 tokens = 9 tiles on 8 waves, 6 x B (sample, head) pairs on 256 CUs) runs

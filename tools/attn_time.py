@@ -12,7 +12,7 @@ from rgm.synth import rotary_freqs  # noqa: E402
 
 R.set_gemm_precision("bf16x3_presplit")
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-T, heads, hd = 256, 16, 72
+T, heads, hd = int(os.environ.get('ATTN_T', 256)), 16, 72
 D = heads * hd
 rot = hd // 2
 ang = torch.arange(T, dtype=torch.float32)[:, None] * torch.from_numpy(rotary_freqs(rot))[None]
