@@ -596,7 +596,7 @@ def test_forward_time_has_no_cliff_between_neighbouring_batch_sizes():
     per = {B: rows[B] / B for B in Bs}
     for a, b in zip(Bs[:-1], Bs[1:]):
         ratio = per[b] / per[a]
-        for _ in range(2):              # a pair over the bar is measured again, twice if need be (a box right after other tests drifts by a few percent)
+        for _ in range(4):              # a pair over the bar is measured again, up to four times (a box right after other tests drifts by a few percent: round 5 saw one in-suite failure of a pair that reads x1.00 alone)
             if ratio <= 1.10:
                 break
             again = dict(batch_sweep.sweep([a, b], reps=15))
