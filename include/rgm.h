@@ -371,6 +371,8 @@ double rgm_prof_bytes(int kernel);
 /* per-launch records of the pre-split GEMM kernels in launch order (kernel id, milliseconds, algorithmic FLOPs); returns the count */
 int rgm_prof_dump(int cap, int* ids, double* ms, double* flops);
 int rgm_gemm2_dbg(int mode, long long* out64);
+/* the same for the 128x144 kernel (gemm144.hip, tools/g144_stamp.py): always built; 8 waves x 8 slots (cycles of the middle workgroup) */
+int rgm_gemm144_dbg(int mode, long long* out64);
 
 /* ------------------------------------------------------------------------------------------------
  * DiffCollage long-sequence composition                   diff_collage/w_img.py, condind_long.py, condind_circle.py

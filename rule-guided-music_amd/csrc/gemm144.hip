@@ -38,15 +38,32 @@ constexpr int STAGE = ROWS * 128;             // 36 KiB
 constexpr int LSEG = ROWS / 8 / 4;            // 1-KiB pieces per loader wave and K-tile: 9
 constexpr int TM = 2, TN = 9;                 // 16x16 accumulator tiles per consumer wave (32 rows x 144 columns)
 
-template <int NSTAGE>
-__global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m, int tiles_n) {
+// DBG: s_memtime stamps of the middle workgroup (tools/g144_stamp.py; rgm_gemm144_dbg), 8 slots per wave:
+//   consumers: 0 barrier wait (arrival -> release), 1 whole K loop, 2 prologue (entry -> K loop), 3 epilogue, 7 K-tiles
+//   loaders:   0 barrier wait, 1 whole K loop, 2 prologue, 4 piece issue, 5 landing wait, 7 K-tiles
+template <int NSTAGE, int DBG = 0, int EXP = 0, int PF = 0>
+__global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* __restrict__ zero_page, int tiles_m, int tiles_n,
+                                                      long long* __restrict__ dbg = nullptr, int pf_a = 1) {
   extern __shared__ __attribute__((aligned(16))) char ring[];
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_entry = 0;
+  auto now = [&]() {
+    const unsigned long long t = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    return t;
+  };
+  if (DBG) t_entry = now();
   const int z = blockIdx.z;
   // XCD-contiguous raster, row tiles fastest: an XCD's tiles are a few column panels of B (weights: read once, by one L2) x all row tiles
   const int bid = blockIdx.x, nb = tiles_m * tiles_n;
   const int xcd = bid & 7, loc = bid >> 3, q = nb >> 3, r = nb & 7;
   const int sid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  const int m0 = (sid % tiles_m) * BM, n0 = (sid / tiles_m) * BN;
+  // sweeps of G row tiles (p.raster_group, host: min(tiles_m, 8)): an XCD's 32 consecutive tiles are G row tiles x 32 / G column panels -- at
+  // M = 4096 (32 x 8 tiles) 8 x 4, i.e. a quarter of A and half of B through each L2 where whole columns (G = tiles_m) pull ALL of A through
+  // every one of the eight (in situ, proj at B = 16: 151 MB of fills for 24 MB of operands)
+  const int G = p.raster_group > 0 ? p.raster_group : tiles_m;
+  const int per_group = G * tiles_n, grp = sid / per_group, first_m = grp * G;
+  const int gsz = min(tiles_m - first_m, G), in_g = sid - grp * per_group;
+  const int m0 = (first_m + in_g % gsz) * BM, n0 = (in_g / gsz) * BN;
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lane = tid & 63;
@@ -88,11 +105,31 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     wait_flying(min(NSTAGE - 2, KT - 1));
     __builtin_amdgcn_s_barrier();                       // barrier P: tile 0 is in LDS
     int s2 = NSTAGE - 1;
+    unsigned long long t0 = 0;
+    if (DBG) {
+      t0 = now();
+      tacc[2] = t0 - t_entry;
+    }
     for (int kt = 0; kt + 1 < KT; ++kt) {
-      if (kt + NSTAGE - 1 < KT) issue_tile(ring + s2 * STAGE);   // into tile kt-1's stage: every consumer read it before barrier kt-1
+      unsigned long long ta = 0, tb = 0, tc = 0;
+      if (DBG) ta = now();
+      if (kt + NSTAGE - 1 < KT && !(EXP & 4)) issue_tile(ring + s2 * STAGE);   // into tile kt-1's stage: every consumer read it before barrier kt-1
+      if (DBG) tb = now();
       wait_flying(min(NSTAGE - 2, KT - 2 - kt));
-      __builtin_amdgcn_s_barrier();                     // barrier kt: tile kt+1 is in LDS
+      if (DBG) tc = now();
+      if constexpr (!(EXP & 1)) __builtin_amdgcn_s_barrier();   // barrier kt: tile kt+1 is in LDS
+      if (DBG) {
+        tacc[4] += tb - ta;
+        tacc[5] += tc - tb;
+        tacc[0] += now() - tc;
+      }
       s2 = s2 == NSTAGE - 1 ? 0 : s2 + 1;
+    }
+    if (DBG) {
+      tacc[1] = now() - t0;
+      tacc[7] = KT;
+      if (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && lane == 0)
+        for (int i = 0; i < 8; ++i) dbg[wave * 8 + i] = (long long)tacc[i];
     }
     return;
   }
@@ -131,12 +168,12 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
       if constexpr (T == 0) acc[im][in] = RGM_MFMA_SPLIT_16x16x32(hi.b[in], lo.a[im], acc[im][in], 0, 0, 0);
       if constexpr (T == 1) acc[im][in] = RGM_MFMA_SPLIT_16x16x32(lo.b[in], hi.a[im], acc[im][in], 0, 0, 0);
       if constexpr (T == 2) acc[im][in] = RGM_MFMA_SPLIT_16x16x32(hi.b[in], hi.a[im], acc[im][in], 0, 0, 0);
-      if constexpr (PRE && T == 1) {
+      if constexpr (PRE && T == 1 && !(EXP & 2)) {
         if constexpr (m < TM) rd(lo.a[m], nst, ar + m * 16, 1);
         else if constexpr (m < 2 * TM) rd(nhi.a[m - TM], nst, ar + (m - TM) * 16, 0);
         else if constexpr (m < 2 * TM + TN) rd(nhi.b[m - 2 * TM], nst, br + (m - 2 * TM) * 16, 0);
       }
-      if constexpr (PRE && T == 2) {
+      if constexpr (PRE && T == 2 && !(EXP & 2)) {
         // b.lo[in] is free once the LAST row tile's term-1 MFMA has used it: all of term 1 is behind us
         if constexpr (m < TN) rd(lo.b[m], nst, br + m * 16, 1);
       }
@@ -148,6 +185,53 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
   using I2 = std::integral_constant<int, 2>;
   static_assert(2 * TM + TN <= NT && TN <= NT, "the next tile's reads fit between the MFMAs of terms 1 and 2");
   Half h0, h1, lo;
+  // ---- PF: operand lines of K-tile kt + PF pulled into this XCD's L2 ahead of the loaders (round 5).  In the forward the loaders' LDS-DMA
+  // requests miss L2 (weights from HBM, A from the Infinity Cache) and their ISSUE backs up behind the outstanding misses -- 950-1300 cycles
+  // per K-tile against 420 on warm operands (tools/g144_insitu_stamp.py), the consumers wait 370-710 at every barrier.  A request that
+  // costs nothing to wait for hides it: one 4-byte LDS-DMA per line into a scratch KiB behind the ring, issued by the consumer waves (their
+  // vmcnt is otherwise unused) PF K-tiles ahead.  The tiles of an XCD share panels (raster above): the gsz row tiles of a sweep share a B
+  // panel, the XCD's column panels share an A panel; each takes its share of the rows, so a line is requested once per XCD.
+  const char* pf_src = zero_page;
+  int pf_inc = 0, pf_left = 0;
+  char* pf_dst = ring + NSTAGE * STAGE + wave * 256;
+  if constexpr (PF > 0) {
+    const int q8 = nb >> 3;                                  // tiles per XCD (r == 0)
+    const bool aligned = r == 0 && q8 % gsz == 0 && (per_group % q8 == 0 || q8 % per_group == 0);
+    int nA = aligned ? min(q8 / gsz, tiles_n) : 1;
+    nA = nA >= 8 ? 8 : nA >= 4 ? 4 : nA >= 2 ? 2 : 1;
+    const int nB = aligned ? gsz : 1;
+    const int iA = (in_g / gsz) % nA, iB = in_g % gsz % nB;
+    // A only where the XCD's tiles share it (a K slice's row panel is read once per XCD: nothing to share, and 128 more requests per K-tile
+    // overload the L1 fill path: 1793 -> 2243 cycles per K-tile on fc2's slices at B = 4) and when asked for (p.tile_flags bit 0: A/B runs)
+    const int a_cnt = (nA > 1 && pf_a) ? BM / nA : 0, b_cnt = (BN + nB - 1) / nB;
+    const int slot = wave * 64 + lane;
+    if (slot < a_cnt) {
+      const int row = m0 + iA * a_cnt + slot;
+      if (row < p.M) { pf_src = Ab + (long long)row * p.lda * 4; pf_inc = 128; }
+    } else if (slot < a_cnt + b_cnt) {
+      const int rl = iB * b_cnt + slot - a_cnt, row = n0 + rl;
+      if (rl < BN && row < p.N) { pf_src = Bb + (long long)row * p.ldb * 4; pf_inc = 128; }
+    }
+    // K-tiles NSTAGE - 1 .. PF - 1 while the loaders fetch the first ones; from then on one per K-tile
+    pf_src += (long long)pf_inc * (NSTAGE - 1);
+    pf_left = KT - (NSTAGE - 1);
+    for (int i = NSTAGE - 1; i < PF; ++i) {
+      if (pf_left > 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+        pf_src += pf_inc;
+      }
+      --pf_left;
+    }
+  }
+  auto prefetch_next = [&]() {
+    if constexpr (PF > 0) {
+      if (pf_left > 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+        pf_src += pf_inc;
+      }
+      --pf_left;
+    }
+  };
   __builtin_amdgcn_s_barrier();                         // barrier P (loaders: tile 0 landed)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -165,9 +249,13 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
   auto iter_more = [&](Half& cur, Half& nxt) {
     term(I0{}, cur, lo, nxt, nullptr, I0{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                       // tile kt+1 in LDS; every consumer read tile kt during tile kt-1
+    unsigned long long ta = 0;
+    if (DBG) ta = now();
+    if constexpr (!(EXP & 1)) __builtin_amdgcn_s_barrier();   // tile kt+1 in LDS; every consumer read tile kt during tile kt-1
+    if (DBG) tacc[0] += now() - ta;
     __builtin_amdgcn_sched_barrier(0);
     const char* nst = ring + s1 * STAGE;
+    prefetch_next();
     term(I1{}, cur, lo, nxt, nst, I1{});
     term(I2{}, cur, lo, nxt, nst, I1{});
     s1 = s1 == NSTAGE - 1 ? 0 : s1 + 1;
@@ -177,6 +265,11 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     term(I1{}, cur, lo, cur, nullptr, I0{});
     term(I2{}, cur, lo, cur, nullptr, I0{});
   };
+  unsigned long long t_loop = 0;
+  if (DBG) {
+    t_loop = now();
+    tacc[2] = t_loop - t_entry;
+  }
   int kt = 0;
   for (; kt + 2 < KT; kt += 2) {
     iter_more(h0, h1);
@@ -187,6 +280,11 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     iter_last(h1);
   } else {
     iter_last(h0);
+  }
+  if (DBG) {
+    const unsigned long long t = now();
+    tacc[1] = t - t_loop;
+    t_loop = t;
   }
 
   // ---- epilogue, straight from the accumulators: acc[im][in][e] = C[m0 + arow0 + 16 im + l15][n0 + 16 in + 4 kb + e]
@@ -245,9 +343,17 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
       }
     }
   }
+  if (DBG) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    tacc[3] = now() - t_loop;
+    tacc[7] = KT;
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && lane == 0)
+      for (int i = 0; i < 8; ++i) dbg[wave * 8 + i] = (long long)tacc[i];
+  }
 }
 
 char* g_zero144 = nullptr;
+long long* g_dbg144 = nullptr;
 }  // namespace
 
 // shapes and epilogues this kernel carries (gemm2_launch asks before it picks tile 81)
@@ -267,18 +373,61 @@ int gemm144_launch(const GemmParams& p, hipStream_t s) {
     RGM_CHECK_HIP(hipMemset(g_zero144, 0, 4096));
   }
   constexpr int NSTAGE = 4;      // 144 KiB of the 160: one workgroup per CU (profiler id 135)
+  constexpr int PFD = 8;         // L2 prefetch distance in K-tiles (kernel: PF)
+  static const int pf_on = getenv("RGM_G144_PF") ? atoi(getenv("RGM_G144_PF")) : 3;   // bit 0: prefetch, bit 1: A panels too (where shared)
   const int tm = cdiv(p.M, BM), tn = p.N / BN;
-  const size_t lds = (size_t)NSTAGE * STAGE;
-  auto k = gemm144_kernel<NSTAGE>;
+  const size_t lds = (size_t)NSTAGE * STAGE + 1024;      // + the prefetch's scratch KiB
+  GemmParams pr = p;
+  if (pr.raster_group <= 0) {
+    static const int fixed = getenv("RGM_G144_RASTER") ? atoi(getenv("RGM_G144_RASTER")) : 0;   // A/B runs
+    pr.raster_group = fixed > 0 ? (fixed < tm ? fixed : tm) : (tm < 8 ? tm : 8);
+  }
+  auto k = pf_on ? gemm144_kernel<NSTAGE, 0, 0, PFD> : gemm144_kernel<NSTAGE>;
   static bool attr = false;
   if (!attr) {
-    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm144_kernel<NSTAGE, 0, 0, PFD>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm144_kernel<NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr = true;
   }
+  if (g_dbg144) {                // stamped variant (tools/g144_stamp.py)
+    static const int exp = getenv("RGM_G144_EXP") ? atoi(getenv("RGM_G144_EXP")) : 0;   // timing only (wrong results): 1 no barriers, 2 no fragment reads, 4 no DMA
+    auto launch_dbg = [&](auto kd) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipLaunchKernelGGL(kd, dim3((unsigned)(tm * tn), 1, (unsigned)p.batch), dim3(512), lds, s, pr, (const char*)g_zero144, tm, tn, g_dbg144, pf_on >> 1);
+    };
+    switch (exp) {
+      case 1: launch_dbg(gemm144_kernel<NSTAGE, 1, 1>); break;
+      case 2: launch_dbg(gemm144_kernel<NSTAGE, 1, 2>); break;
+      case 4: launch_dbg(gemm144_kernel<NSTAGE, 1, 4>); break;
+      case 7: launch_dbg(gemm144_kernel<NSTAGE, 1, 7>); break;
+      default:
+        if (pf_on) launch_dbg(gemm144_kernel<NSTAGE, 1, 0, PFD>);
+        else launch_dbg(gemm144_kernel<NSTAGE, 1, 0>);
+    }
+    RGM_LAUNCH_CHECK();
+    return RGM_OK;
+  }
   const int pi = gemm2_prof_begin(135, 2.0 * p.M * (double)p.N * p.K * p.batch, s);
-  hipLaunchKernelGGL(k, dim3((unsigned)(tm * tn), 1, (unsigned)p.batch), dim3(512), lds, s, p, (const char*)g_zero144, tm, tn);
+  hipLaunchKernelGGL(k, dim3((unsigned)(tm * tn), 1, (unsigned)p.batch), dim3(512), lds, s, pr, (const char*)g_zero144, tm, tn, (long long*)nullptr, pf_on >> 1);
   gemm2_prof_end(pi, s);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }
 }  // namespace rgm
+
+// tools/g144_stamp.py: mode 1 arms the stamped kernel, 2 copies the 64 slots out, 0 disarms
+extern "C" int rgm_gemm144_dbg(int mode, long long* out64) {
+  using namespace rgm;
+  if (mode == 1) {
+    if (!g_dbg144) RGM_CHECK_HIP(hipMalloc(&g_dbg144, 64 * sizeof(long long)));
+    RGM_CHECK_HIP(hipMemset(g_dbg144, 0, 64 * sizeof(long long)));
+  } else if (mode == 2) {
+    RGM_REQUIRE(g_dbg144 && out64, "gemm144_dbg: not armed");
+    RGM_CHECK_HIP(hipDeviceSynchronize());
+    RGM_CHECK_HIP(hipMemcpy(out64, g_dbg144, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+  } else {
+    if (g_dbg144) (void)hipFree(g_dbg144);
+    g_dbg144 = nullptr;
+  }
+  return RGM_OK;
+}

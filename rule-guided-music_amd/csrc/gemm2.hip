@@ -121,7 +121,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     RGM_CHECK_HIP(hipEventRecord(rec.a, s));
   }
 #ifdef RGM_GEMM2_STAMPS   // make CXXFLAGS+=-DRGM_GEMM2_STAMPS: also build the s_memtime-stamped kernels (tools/gemm_stamp.py)
-  if (p.aload == 0 && g_dbg) {
+  static const int dbg_tile = getenv("RGM_GEMM2_DBG_TILE") ? atoi(getenv("RGM_GEMM2_DBG_TILE")) : 0;   // stamp launches of this tile id only (in-situ stamps)
+  if (p.aload == 0 && g_dbg && (dbg_tile == 0 || dbg_tile == tile_id)) {
     auto kd = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 1, PIPE>;
     static bool attrd = false;
     if (lds > 65536 && !attrd) {
@@ -266,7 +267,7 @@ static int splitk_factor(const GemmParams& p) {
   return best;
 }
 
-static int g_t144 = getenv("RGM_T144") ? atoi(getenv("RGM_T144")) : 9;   // which grids take the 128x144 tiles (bit mask, gemm2_launch)
+static int g_t144 = getenv("RGM_T144") ? atoi(getenv("RGM_T144")) : 15;   // which grids take the 128x144 tiles (bit mask, gemm2_launch)
 static int g_co_min = getenv("RGM_CO_MIN_TILES") ? atoi(getenv("RGM_CO_MIN_TILES")) : 100;   // co-scheduled launches (GemmParams::co_sched)
 static int g_co_kt = getenv("RGM_CO_KT") ? atoi(getenv("RGM_CO_KT")) : 36;
 static int g_fuse_reduce_ln = getenv("RGM_FUSE_REDUCE_LN") ? atoi(getenv("RGM_FUSE_REDUCE_LN")) : 1;
@@ -315,13 +316,29 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   if (p.tile == 0 && g_t144 && p.batch == 1 && p.M < 2048 && gemm144_supports(p)) {
     const long long t144 = (long long)cdiv(p.M, 128) * (p.N / 144);
     const long long t128 = (long long)cdiv(p.M, 128) * cdiv(p.N, 128);
-    const int KT = p.K >> 5;
     if ((g_t144 & 1) && t144 >= 224 && t144 <= 256 && t128 > 256) {
       GemmParams q = p;
       q.tile = 81;
       q.ln_out = nullptr;
       return gemm2_launch(q, s);
     }
+  }
+  // bits 2 / 4 (round 5, experiments until measured in the forward): ONE round of 144-column tiles at M >= 2048 -- proj at B = 16 (bit 2: K-tiles < 72)
+  // and fc2 at B = 16 unsliced (bit 4: its LayerNorm then runs as its own kernel)
+  static const int t144_co = getenv("RGM_T144_CO") ? atoi(getenv("RGM_T144_CO")) : 0;   // also beside a second stream's launches (half batches): A/B runs
+  if (p.tile == 0 && (g_t144 & 6) && p.batch == 1 && p.M >= 2048 && (!p.co_sched || t144_co) && gemm144_supports(p)) {
+    const long long t144 = (long long)cdiv(p.M, 128) * (p.N / 144);
+    const int KT = p.K >> 5;
+    if (t144 >= 224 && t144 <= 256 && (long long)cdiv(p.M, 256) * cdiv(p.N, 256) < 140 && ((KT < 72 && (g_t144 & 2)) || (KT >= 72 && (g_t144 & 4)))) {
+      GemmParams q = p;
+      q.tile = 81;
+      q.ln_out = nullptr;
+      return gemm2_launch(q, s);
+    }
+  }
+  if (p.tile == 0 && g_t144 && p.batch == 1 && p.M < 2048 && gemm144_supports(p)) {
+    const long long t144 = (long long)cdiv(p.M, 128) * (p.N / 144);
+    const int KT = p.K >> 5;
     if ((g_t144 & 8) && p.sk_ws && t144 <= 64 && KT >= 72 && p.act == 0 && !p.out_split) {
       int best = 1;
       for (int c = 2; c <= 8; ++c) {

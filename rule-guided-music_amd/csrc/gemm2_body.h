@@ -790,7 +790,6 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // Output stores.  The one-wave-per-SIMD kernels (PIPE 5) finish a whole round of 256 KB tiles at the same moment and their
     // epilogue runs at the chip's write rate: non-temporal stores (the 57-76 MB of a qkv / fc1 output pass through the 32 MB of L2
     // anyway) take 1.7-4.4 % off those launches (tools/which_kernel.py, same box: 86.9 -> 85.4 us at 224 tiles, 98.3 -> 94.0 at 256).
-    typedef split_t bf16x4_t __attribute__((ext_vector_type(4)));
     auto out16 = [&](float* dst, const float (&v)[4]) {
       if constexpr (COH) {
         const f32x4 nv = {v[0], v[1], v[2], v[3]};
@@ -801,10 +800,6 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       } else {
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
-    };
-    auto out8 = [&](split_t* dst, const bf16x4_t& v) {
-      if constexpr (PIPE == 5) __builtin_nontemporal_store(v, reinterpret_cast<bf16x4_t*>(dst));
-      else *reinterpret_cast<bf16x4_t*>(dst) = v;
     };
     auto store_row = [&](int row, const float (&v)[4]) {
       if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
@@ -819,8 +814,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         if constexpr (COH) {
           store_split4_pair_sc1<1>(rowp, col, hi, lo);      // lanes (2k, 2k+1) own columns 8k' .. 8k'+7 of the same row
         } else {
-          out8(rowp + split_idx(col), hi);
-          out8(rowp + split_idx(col) + 32, lo);
+          store_split4_pair<PIPE == 5>(rowp, col, hi, lo);   // lanes (2k, 2k+1): one 16-byte store each (hi halves / lo halves of 8 columns)
         }
       } else if (exp != 4) {
         out16(Cb + (long long)row * p.ldc + col, v);
@@ -878,8 +872,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                   if constexpr (COH) {
                     store_split4_pair_sc1<1>(rowp, col, hi, lo);
                   } else {
-                    out8(rowp + split_idx(col), hi);
-                    out8(rowp + split_idx(col) + 32, lo);
+                    store_split4_pair<PIPE == 5>(rowp, col, hi, lo);
                   }
                 } else {
                   if (exp != 4) out16(Cb + (long long)row * p.ldc + col, v);
@@ -1250,10 +1243,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
               estamp(1);
             }
             // this slab's residual rows have landed: only the stores of the previous slab's pass 2 were issued after their DMA
-            // (the counted waits below assume exactly ONE store per row and lane for fp32 rows and TWO for split rows -- store_row's out16 /
-            // out8 pair -- behind the DMA; the experiment variants that drop stores wait for everything)
+            // (the counted wait below assumes exactly ONE store per row and lane -- store_row's out16, or its 16-byte half of a lane pair's
+            // split row -- behind the DMA; the experiment variants that drop stores wait for everything)
             if (im == 0 || !full || exp != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (p.out_split) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
             staged_pass1(stg, rslab, row_w + im * 32, g_lo[im], g_hi[im], bnd[im]);
             if constexpr (im + 1 < TM) {

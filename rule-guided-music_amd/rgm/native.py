@@ -106,6 +106,7 @@ def _load():
         "rgm_prof_bytes": (C.c_double, [i32]),
         "rgm_prof_dump": (C.c_int, [i32, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rgm_gemm2_dbg": (C.c_int, [i32, C.POINTER(C.c_longlong)]),
+        "rgm_gemm144_dbg": (C.c_int, [i32, C.POINTER(C.c_longlong)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)            # AttributeError here == header/library mismatch: fail loudly

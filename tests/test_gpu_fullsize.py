@@ -62,7 +62,7 @@ class _Recorded:
         from rgm import native as R
         torch.cuda.synchronize()
         R.check(R.lib.rgm_prof_enable(0))
-        self.n = _launches([83, 84, 111, 112, 113, 121, 122])
+        self.n = _launches([83, 84, 111, 112, 113, 121, 122, 135])
         self.big = self.n[111] + self.n[112] + self.n[113]
         R.check(R.lib.rgm_prof_reset())
 
@@ -109,12 +109,14 @@ def test_big_tile_kernels_gate_and_residual_in_place(tile, M, N, K, T):
 
 
 @pytest.mark.parametrize("M,N,K,T", [(1024, 4608, 1152, 256), (1000, 1152, 1152, 128), (512, 3456, 1152, 256), (768, 1152, 4608, 256),
-                                     (4096, 1152, 1152, 256)])
+                                     (4096, 1152, 1152, 256), (4096, 1152, 4608, 256),      # proj / fc2 at B = 16: one round, 8-row sweeps
+                                     (2500, 1152, 1152, 128), (1300, 4608, 64, 128)])        # ragged last sweep; fewer K-tiles than the prefetch distance
 def test_tile_144_kernel_epilogues_and_its_place_in_the_heuristic(M, N, K, T):
     """csrc/gemm144.hip (tile 81: 128x144 output tiles on v_mfma_f32_16x16x32, the product computed transposed so that a lane owns four
     consecutive columns): proj / fc2's gated in-place residual and fc1's GELU + split-row output against the fp64 product on the shapes of
     B = 2 .. 4 (one ragged M), bit-identical run to run; and through the heuristic (tile 0) -- fc1 at B = 4 is one round of 256 of
-    these tiles, fc2 at B = 3 / 4 runs as K slices ON them -- the launch records prove the kernel took the call."""
+    these tiles, fc2 at B = 3 / 4 runs as K slices ON them, proj and fc2 at B = 16 are one round each (round 5: 8-row sweeps of the raster,
+    operand lines prefetched into L2 by the consumer waves) -- the launch records prove the kernel took the call."""
     from gpu_util import dev, rel
     from rgm import native as R
     rng = np.random.RandomState(M + N + K + 81)
@@ -143,7 +145,7 @@ def test_tile_144_kernel_epilogues_and_its_place_in_the_heuristic(M, N, K, T):
         assert rel(outs[0], want) < 3e-5, (tile, rel(outs[0], want))
         if tile == 81:
             assert n144 == 1
-        elif (M, N, K) in ((1024, 4608, 1152), (768, 1152, 4608)):
+        elif (M, N, K) in ((1024, 4608, 1152), (768, 1152, 4608), (4096, 1152, 1152), (4096, 1152, 4608)):
             assert n144 == 1, n144                                   # the heuristic's choice: one round / K slices of 128x144 tiles
     R.check(R.lib.rgm_prof_reset())
     h = torch.zeros(M, N, device="cuda")
@@ -184,7 +186,9 @@ def test_heuristic_decompositions_of_the_big_tile_kernel(M, N, K, T):
             R.check(R.lib.rgm_gemm_split_epi(R.ptr(As), K, R.ptr(Bs), K, R.ptr(x), N, M, N, K, R.ptr(bd), 0, 0.7, R.ptr(gd), N + 64, T,
                                              R.ptr(x), N, 0, 0, R.ptr(ws), need, st))
         outs.append(x.cpu().numpy())
-    if (M, N, K) not in ((7168, 1152, 4608), (2304, 3456, 1152)):   # (those two stay on the 128-row kernels: no full round of 256x256 tiles)
+    if (M, N, K) == (4096, 1152, 4608):                             # fc2 at B = 16 (round 5): ONE round of 256 tiles of 128 x 144, unsliced
+        assert rec.n[135] == 1 and rec.n[111] == 0, rec.n
+    elif (M, N, K) not in ((7168, 1152, 4608), (2304, 3456, 1152)):   # (those two stay on the 128-row kernels: no full round of 256x256 tiles)
         assert rec.n[111] >= 1, rec.n                               # the 256x256 kernel took part
     assert np.array_equal(outs[0], outs[1])
     err = rel(outs[0], _ref(A, B, bias, 0, 0.7, gate[:, :N], T, res))

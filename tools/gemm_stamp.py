@@ -17,6 +17,7 @@ from rgm import native as R  # noqa: E402
 
 M, N, K = (int(x) for x in sys.argv[1:4])
 tiles = [int(x) for x in sys.argv[4:]]
+ACT, SPLIT = int(os.environ.get("ACT", "0")), int(os.environ.get("SPLIT", "0"))   # epilogue variant: activation (1 SiLU, 2 GELU), split-row output
 a = torch.randn(M, K, device="cuda")
 b = torch.randn(N, K, device="cuda") * 0.03
 c = torch.empty(M, N, device="cuda")
@@ -31,12 +32,12 @@ names = ["dma_wait", "barrier", "dma_iss", "read0", "mfma0", "read1", "mfma1"]
 print(f"{M}x{N}x{K}  cycles per K-tile (s_memtime ticks = shader cycles)")
 for t in tiles:
     for _ in range(3):
-        R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), 0, t, 0, st))
+        R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), ACT, t, SPLIT, st))
     torch.cuda.synchronize()
     R.check(dbg(1, None))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), 0, t, 0, st))
+    R.check(R.lib.rgm_gemm_split(R.ptr(a2), R.ptr(b2), R.ptr(c), M, N, K, R.ptr(bias), ACT, t, SPLIT, st))
     e1.record()
     out = (C.c_longlong * 64)()
     R.check(dbg(2, out))
