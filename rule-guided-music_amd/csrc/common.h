@@ -126,7 +126,7 @@ __device__ __forceinline__ void store_split4_pair_sc1(split_t* rowp, int col, co
 // An 8-byte store costs an issue slot like a 16-byte one, and a write-bound epilogue is store-ISSUE-bound: the 256x256 tile's epilogue takes
 // 33.8 k cycles with split-row output as 2 x 8 bytes per lane against 25.5 k for the same bytes as fp32 rows (tools/gemm_stamp.py, SPLIT=1).
 // NT: non-temporal (the one-wave-per-SIMD kernels' 57-76 MB outputs).  Both lanes of a pair must call.
-template <bool NT>
+template <bool NT, int XOR = 1>
 __device__ __forceinline__ void store_split4_pair(split_t* rowp, int col, const split_x4& hi, const split_x4& lo) {
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -134,8 +134,13 @@ __device__ __forceinline__ void store_split4_pair(split_t* rowp, int col, const 
   const u32x2 mine_hi = __builtin_bit_cast(u32x2, hi), mine_lo = __builtin_bit_cast(u32x2, lo);
   const u32x2 send = even ? mine_lo : mine_hi;
   u32x2 recv;
-  recv[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)send[0], 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]: lane ^ 1
-  recv[1] = (unsigned)__builtin_amdgcn_mov_dpp((int)send[1], 0xB1, 0xF, 0xF, true);
+  if constexpr (XOR == 1) {
+    recv[0] = (unsigned)__builtin_amdgcn_mov_dpp((int)send[0], 0xB1, 0xF, 0xF, true);   // quad_perm [1, 0, 3, 2]: lane ^ 1
+    recv[1] = (unsigned)__builtin_amdgcn_mov_dpp((int)send[1], 0xB1, 0xF, 0xF, true);
+  } else {                                                                              // partner in another DPP row (gemm144: lane ^ 16)
+    recv[0] = (unsigned)__shfl_xor((int)send[0], XOR, 64);
+    recv[1] = (unsigned)__shfl_xor((int)send[1], XOR, 64);
+  }
   const u32x4 out = even ? u32x4{mine_hi[0], mine_hi[1], recv[0], recv[1]} : u32x4{recv[0], recv[1], mine_lo[0], mine_lo[1]};
   f32x4* dst = reinterpret_cast<f32x4*>(rowp + split_idx(col & ~7) + (even ? 0 : 32));
   if constexpr (NT) __builtin_nontemporal_store(__builtin_bit_cast(f32x4, out), dst);

@@ -327,8 +327,7 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
         v[0] = v[0] * g4[in].x + r4[in].x; v[1] = v[1] * g4[in].y + r4[in].y;
         v[2] = v[2] * g4[in].z + r4[in].z; v[3] = v[3] * g4[in].w + r4[in].w;
       }
-      if (!ok) continue;
-      if (p.out_split) {
+      if (p.out_split) {     // (before the row guard: both lanes of a pair -- same row, kb ^ 1 -- take part in the exchange)
         bf16x4 hi, lo;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -336,9 +335,11 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
           lo[e] = (split_t)(v[e] - (float)hi[e]);
         }
         split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
-        *reinterpret_cast<bf16x4*>(rowp + split_idx(col)) = hi;
-        *reinterpret_cast<bf16x4*>(rowp + split_idx(col) + 32) = lo;
-      } else {
+        if (ok) store_split4_pair<false, 16>(rowp, col, hi, lo);     // 16 bytes per lane: the hi halves of 8 columns (kb even) / their lo halves
+        continue;
+      }
+      if (!ok) continue;
+      {
         *reinterpret_cast<float4*>(Cb + (long long)row * p.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
