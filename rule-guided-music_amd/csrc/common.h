@@ -243,6 +243,8 @@ struct GemmParams {
   // gemm2 raster: row-tiles per column sweep of the XCD-contiguous grouped raster (0 = 8).  The one-wave-per-SIMD kernels set it to
   // ~sqrt(tiles per XCD): an XCD's tiles then form a near-square block and its L2 fetches the fewest operand panels
   int raster_group = 0;
+  // one-wave-per-SIMD tiles: ordinary instead of non-temporal output stores (set by launch2 from RGM_ST_PLAIN: bit 0 fp32 rows, bit 1 split rows)
+  int st_plain = 0;
   // K-slice launches of gemm2_launch (fc2 of a DiT block): the reduce kernel holds whole output rows, so it can also write the NEXT
   // adaLN-LayerNorm of that row -- LN(row, ln_eps) * (1 + ln_scale) + ln_shift, the arithmetic of ln_mod_kernel, to ln_out -- and
   // save that kernel's launch and its read of the row.  Optional: *ln_done (host) is set to 1 only when the launch took this route.

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     const int iA = (in_g / gsz) % nA, iB = in_g % gsz % nB;
     // A only where the XCD's tiles share it (a K slice's row panel is read once per XCD: nothing to share, and 128 more requests per K-tile
     // overload the L1 fill path: 1793 -> 2243 cycles per K-tile on fc2's slices at B = 4) and when asked for (p.tile_flags bit 0: A/B runs)
-    const int a_cnt = (nA > 1 && pf_a) ? BM / nA : 0, b_cnt = (BN + nB - 1) / nB;
+    const int a_cnt = (nA > 1 && (pf_a & 1)) ? BM / nA : 0, b_cnt = (BN + nB - 1) / nB;
     const int slot = wave * 64 + lane;
     if (slot < a_cnt) {
       const int row = m0 + iA * a_cnt + slot;
@@ -223,9 +223,19 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
       --pf_left;
     }
   }
+  // ... and, once the operands are all requested (the last PF K-tiles), the tile's RESIDUAL lines: 32 rows per wave x 576 bytes = five lines per
+  // row, one line index per K-tile (lanes 32-63 repeat lanes 0-31).  The epilogue's residual reads then hit L2 instead of queueing 73 KB per
+  // CU of HBM / Infinity Cache reads in front of its stores (in situ: 23-25 k cycles of epilogue on proj at B = 16 against 12 k warm).
+  const float* res_pf = (p.res && (pf_a & 2)) ? p.res + (long long)z * p.sRes : nullptr;
   auto prefetch_next = [&]() {
     if constexpr (PF > 0) {
-      if (pf_left > 0) {
+      if (pf_left == 0 && res_pf) {
+        const int row = m0 + arow0 + (lane & 31);
+        const bool ok = row < p.M;
+        pf_src = ok ? reinterpret_cast<const char*>(res_pf + (long long)row * p.ldres + n0) : zero_page;
+        pf_inc = ok ? 128 : 0;
+      }
+      if (pf_left > (res_pf ? -5 : 0)) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
         pf_src += pf_inc;
       }
@@ -374,8 +384,8 @@ int gemm144_launch(const GemmParams& p, hipStream_t s) {
     RGM_CHECK_HIP(hipMemset(g_zero144, 0, 4096));
   }
   constexpr int NSTAGE = 4;      // 144 KiB of the 160: one workgroup per CU (profiler id 135)
-  constexpr int PFD = 8;         // L2 prefetch distance in K-tiles (kernel: PF)
-  static const int pf_on = getenv("RGM_G144_PF") ? atoi(getenv("RGM_G144_PF")) : 3;   // bit 0: prefetch, bit 1: A panels too (where shared)
+  constexpr int PFD = 8;         // L2 prefetch distance in K-tiles (kernel: PF).  Same box, C2 step / B = 4 forward: 4 -> 12.58 / 5.50 ms, 8 -> 12.12 / 5.30, 16 -> 12.32 / 5.40
+  static const int pf_on = getenv("RGM_G144_PF") ? atoi(getenv("RGM_G144_PF")) : 3;   // bit 0: prefetch, bit 1: A panels too (where shared), bit 2: the residual's lines in the last K-tiles (measured: no change, off)
   const int tm = cdiv(p.M, BM), tn = p.N / BN;
   const size_t lds = (size_t)NSTAGE * STAGE + 1024;      // + the prefetch's scratch KiB
   GemmParams pr = p;

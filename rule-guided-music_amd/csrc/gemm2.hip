@@ -97,6 +97,10 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   }
   dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64 * (PIPE == 4 ? 2 : 1));
   GemmParams pr = p;
+  if (PIPE == 5) {
+    static const int st_plain = getenv("RGM_ST_PLAIN") ? atoi(getenv("RGM_ST_PLAIN")) : 0;
+    pr.st_plain = p.out_split ? (st_plain >> 1) & 1 : st_plain & 1;
+  }
   if (PIPE == 5 && p.raster_group == 0) {
     // every XCD computes tm * tn / 8 contiguous tiles of the raster: a gm x gn block of them reads gm A panels and gn B panels
     // through that XCD's L2 -- fewest for gm ~ gn (weighted by the tile sides).  In-situ PMC, C2 step: 2.9x the algorithmic bytes

@@ -796,7 +796,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         store16_sc1(dst, nv);
       } else if constexpr (PIPE == 5) {
         const f32x4 nv = {v[0], v[1], v[2], v[3]};
-        __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(dst));
+        if (p.st_plain) *reinterpret_cast<f32x4*>(dst) = nv;          // (A/B runs: RGM_ST_PLAIN, launch2)
+        else __builtin_nontemporal_store(nv, reinterpret_cast<f32x4*>(dst));
       } else {
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
@@ -814,7 +815,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         if constexpr (COH) {
           store_split4_pair_sc1<1>(rowp, col, hi, lo);      // lanes (2k, 2k+1) own columns 8k' .. 8k'+7 of the same row
         } else {
-          store_split4_pair<PIPE == 5>(rowp, col, hi, lo);   // lanes (2k, 2k+1): one 16-byte store each (hi halves / lo halves of 8 columns)
+          if (PIPE == 5 && !p.st_plain) store_split4_pair<true>(rowp, col, hi, lo);   // lanes (2k, 2k+1): one 16-byte store each (hi halves / lo halves of 8 columns)
+          else store_split4_pair<false>(rowp, col, hi, lo);
         }
       } else if (exp != 4) {
         out16(Cb + (long long)row * p.ldc + col, v);
@@ -872,7 +874,8 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                   if constexpr (COH) {
                     store_split4_pair_sc1<1>(rowp, col, hi, lo);
                   } else {
-                    store_split4_pair<PIPE == 5>(rowp, col, hi, lo);
+                    if (PIPE == 5 && !p.st_plain) store_split4_pair<true>(rowp, col, hi, lo);
+                    else store_split4_pair<false>(rowp, col, hi, lo);
                   }
                 } else {
                   if (exp != 4) out16(Cb + (long long)row * p.ldc + col, v);
