@@ -245,6 +245,8 @@ struct GemmParams {
   int raster_group = 0;
   // one-wave-per-SIMD tiles: ordinary instead of non-temporal output stores (set by launch2 from RGM_ST_PLAIN: bit 0 fp32 rows, bit 1 split rows)
   int st_plain = 0;
+  // loader/consumer tiles (PIPE 4): L2 prefetch distance of the B panel in K-tiles, 0 = off (set by launch2: RGM_P4_PF, and only where the scratch KiB fits)
+  int pf_kt = 0;
   // K-slice launches of gemm2_launch (fc2 of a DiT block): the reduce kernel holds whole output rows, so it can also write the NEXT
   // adaLN-LayerNorm of that row -- LN(row, ln_eps) * (1 + ln_scale) + ln_shift, the arithmetic of ln_mod_kernel, to ln_out -- and
   // save that kernel's launch and its read of the row.  Optional: *ln_done (host) is set to 1 only when the launch took this route.

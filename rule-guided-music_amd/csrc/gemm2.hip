@@ -77,26 +77,33 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     RGM_CHECK_HIP(hipMemset(g_zero_page, 0, 4096));
   }
   const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
-  const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+  size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+  // (measured, round 5: XL-28 forward at B = 2 / 3 / 4 / 6 / 8 4.10 / 4.73 / 5.30 / 6.34 / 7.86 ms without, 4.22 / 4.69 / 5.29 / 6.60 / 7.82 with a
+  // distance of 8 -- unlike the 144-column kernel, whose loaders were the in-situ bottleneck, these tiles do not gain: off)
+  static const int p4_pf = getenv("RGM_P4_PF") ? atoi(getenv("RGM_P4_PF")) : 0;
+  const bool pf4 = PIPE == 4 && p4_pf > 0 && lds + 1024 <= 160 * 1024 && p.batch == 1;
+  if (pf4) lds += 1024;                        // the consumers' prefetch scratch (gemm2_body.h)
+  const size_t lds_attr = (PIPE == 4 && (size_t)NSTAGE * (BM + BN) * 128 + 1024 <= 160 * 1024) ? (size_t)NSTAGE * (BM + BN) * 128 + 1024 : lds;   // the attribute is set once
   static bool attr0 = false, attr1 = false;
   auto k0 = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 0, PIPE>;
   auto k1 = gemm2_kernel<BM, BN, WM, WN, PIPE == 4 ? 0 : 1, NSTAGE, 0, PIPE>;
   auto k2 = gemm2_kernel<BM, BN, WM, WN, PIPE == 5 ? 2 : 0, NSTAGE, 0, PIPE>;   // implicit conv with channel-block-major K (PIPE 5 only)
   RGM_REQUIRE(!p.conv_kmajor || (p.aload == 1 && p.Cin % 32 == 0), "gemm2: conv_kmajor is a property of the implicit 3x3 conv (aload == 1)");
   RGM_REQUIRE(PIPE != 4 || p.aload == 0, "gemm2: the loader/consumer kernels take dense operands only");
-  if (lds > 65536) {
+  if (lds_attr > 65536) {
     if (p.aload == 0 && !attr0) {
-      RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
       attr0 = true;
     }
     if (p.aload == 1 && !attr1) {
-      RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      if (PIPE == 5) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
+      if (PIPE == 5) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_attr));
       attr1 = true;
     }
   }
   dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64 * (PIPE == 4 ? 2 : 1));
   GemmParams pr = p;
+  pr.pf_kt = pf4 ? p4_pf : 0;
   if (PIPE == 5) {
     static const int st_plain = getenv("RGM_ST_PLAIN") ? atoi(getenv("RGM_ST_PLAIN")) : 0;
     pr.st_plain = p.out_split ? (st_plain >> 1) & 1 : st_plain & 1;
@@ -327,9 +334,11 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
       return gemm2_launch(q, s);
     }
   }
-  // bits 2 / 4 (round 5, experiments until measured in the forward): ONE round of 144-column tiles at M >= 2048 -- proj at B = 16 (bit 2: K-tiles < 72)
-  // and fc2 at B = 16 unsliced (bit 4: its LayerNorm then runs as its own kernel)
-  static const int t144_co = getenv("RGM_T144_CO") ? atoi(getenv("RGM_T144_CO")) : 0;   // also beside a second stream's launches (half batches): A/B runs
+  // bits 2 / 4 (round 5): ONE round of 144-column tiles at M >= 2048 -- proj at B = 16 (bit 2: K-tiles < 72) and fc2 at B = 16 unsliced (bit 4:
+  // its LayerNorm then runs as its own kernel).  With 8-row raster sweeps and the L2 prefetch (gemm144.hip) they are 43 / 115 us in the forward
+  // against 49 (128x64 tiles) / 109 + 28 (256x256 K slices + reduce-LayerNorm): C2 12.83 -> 11.97 ms per step on one box.  Also for each
+  // of two half batches in flight (co_sched; RGM_T144_CO=0 for A/B runs): C3 28.86 -> 28.27 ms, B = 32 forward 22.55 -> 22.25.
+  static const int t144_co = getenv("RGM_T144_CO") ? atoi(getenv("RGM_T144_CO")) : 1;
   if (p.tile == 0 && (g_t144 & 6) && p.batch == 1 && p.M >= 2048 && (!p.co_sched || t144_co) && gemm144_supports(p)) {
     const long long t144 = (long long)cdiv(p.M, 128) * (p.N / 144);
     const int KT = p.K >> 5;

@@ -286,6 +286,31 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       });
     };
     Frags f0, f1;
+    // B-panel lines of K-tile kt + p.pf_kt requested into this XCD's L2 ahead of the loaders (as gemm144.hip's PF: in the forward the weights
+    // come from HBM and the loaders' issue backs up behind their own outstanding misses).  The row tiles of a raster sweep share a B panel and
+    // sit on one XCD: each requests its share of the BN rows -- one 4-byte LDS-DMA per line into a scratch KiB behind the ring (launch2 adds
+    // it where it fits), by the consumer waves, whose vmcnt is otherwise unused.
+    const char* pf_src = zero_page;
+    int pf_inc = 0, pf_left = 0;
+    char* pf_dst = ring + NSTAGE * STAGE + wave * 256;
+    bool pf_wave = false;
+    if (p.pf_kt > 0 && !COH) {
+      const int b_cnt = (BN + gsz - 1) / gsz;
+      const int slot = wave * 64 + lane, rl = (in_g % gsz) * b_cnt + slot, row = n0 + rl;
+      pf_wave = wave * 64 < b_cnt;
+      if (slot < b_cnt && rl < BN && row < p.N) {
+        pf_src = Bb + (long long)row * p.ldb * 4 + (long long)(NSTAGE - 1) * 128;
+        pf_inc = 128;
+      }
+      pf_left = pf_wave ? KT - (NSTAGE - 1) : 0;
+      for (int i = NSTAGE - 1; i < p.pf_kt; ++i) {
+        if (pf_left > 0) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+          pf_src += pf_inc;
+        }
+        --pf_left;
+      }
+    }
     __builtin_amdgcn_s_barrier();                         // barrier P (loader: tile 0 landed)
     static_for<0, NRD>([&](auto jc) { read_one(f0, ring, jc); });
     int s1 = 1;
@@ -303,6 +328,11 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         RGM_STAMP(0)
         __builtin_amdgcn_s_barrier();                     // tile kt+1 in LDS; every consumer is done reading tile kt
         RGM_STAMP(1)
+        if (pf_left > 0) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+          pf_src += pf_inc;
+        }
+        --pf_left;
       }
       __builtin_amdgcn_sched_barrier(0);
       mfma_step(cur, std::integral_constant<int, 1>{}, more1, nxt, ring + s1 * STAGE);
