@@ -405,6 +405,24 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         src[i] = ((a_y[i] >> t.tap) & 1) ? Ab + a_img[i] + t.line + d : zero_page + csrc[i];
       }
     };
+    // the same in two halves for the gaps behind two consecutive MFMAs: one piece's 12 VALU instructions in ONE gap take longer than the MFMA
+    // they hide behind (stamps in the decode, 512x128 tile: phase A 2170 cycles against 1618 on dense operands; the ISA shows 16 gaps of 12
+    // fillers each beside 32 gaps of 0-2).  aim_a: the tap's source-pixel offset and whether the neighbour exists; aim_b: the address.
+    int aim_d[APIECES > 0 ? APIECES : 1], aim_ok[APIECES > 0 ? APIECES : 1];
+    const char* aim_p[APIECES > 0 ? APIECES : 1];
+    auto aim_a = [&](auto ic, const TapStep& t) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < APIECES) {
+        aim_d[i] = ((a_x[i] & 1) ? t.row_o : t.row_e) + ((a_x[i] & 2) ? t.col_o : t.col_e);
+        aim_ok[i] = (a_y[i] >> t.tap) & 1;
+        aim_p[i] = Ab + a_img[i] + t.line;
+        asm volatile("" : "+v"(aim_d[i]), "+v"(aim_ok[i]), "+v"(aim_p[i]));      // computed HERE: the compiler otherwise sinks all of it into aim_b's gap
+      }
+    };
+    auto aim_b = [&](auto ic, const TapStep& t) {
+      constexpr int i = decltype(ic)::value;
+      if constexpr (i < APIECES) src[i] = aim_ok[i] ? aim_p[i] + aim_d[i] : zero_page + csrc[i];
+    };
     auto aim_all = [&](int tap, int kc) {
       const TapStep t = tap_step(tap, kc);
       static_for<0, APIECES>([&](auto ic) { aim_piece(ic, t); });
@@ -422,7 +440,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
         acc[im][in] = RGM_MFMA_SPLIT_32x32x16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
         if constexpr (READ && m % EV == 0 && m / EV < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / EV>{});
-        if constexpr (AIM && m % EV == 1 && m / EV < APIECES) aim_piece(std::integral_constant<int, m / EV>{}, aim);
+        if constexpr (AIM && EV == 3) {
+          if constexpr (m % 3 == 1 && m / 3 < APIECES) aim_a(std::integral_constant<int, m / 3>{}, aim);
+          if constexpr (m % 3 == 2 && m / 3 < APIECES) aim_b(std::integral_constant<int, m / 3>{}, aim);
+        } else if constexpr (AIM && m % EV == 1 && m / EV < APIECES) {
+          aim_piece(std::integral_constant<int, m / EV>{}, aim);
+        }
         if constexpr (DMA && m % EV == 1 && m / EV < SPW) {
           constexpr int i = m / EV;
           dma16(src[i], dst + (wave + i * NW) * 1024);
