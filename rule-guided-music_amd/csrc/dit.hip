@@ -51,13 +51,15 @@ static int g_adaln_overlap = getenv("RGM_ADALN_OVERLAP") ? atoi(getenv("RGM_ADAL
 // The blocks of an eps-network forward as TWO half batches on two streams (rows of different samples never meet inside a block): one
 // half's kernels fill the CUs the other half's last tile round leaves idle, and their write-bound epilogues fall under the other half's
 // K loops.  g_dit_halves (rgm_set_dit_halves / RGM_DIT_HALVES): -1 = where the same-box sweep of tools/halves_exp.py found it ahead
-// (profiles/r04_halves_sweep.txt: B = 2, 5..9, 17..39 and from 57 up -- 2..8 % -- but behind at 10..14 and 40..56, and even at 16, where
+// (profiles/r04_halves_sweep.txt, r05_halves_sweep.txt: B = 2, 4..9 and from 17 up -- 2..14 % -- but behind at 3 and 10..14, and even at 16, where
 // ONE round of 256x256 tiles per GEMM leaves nothing to overlap); 0 = never; n > 0 = every batch of at least n samples.
 static int g_dit_halves = getenv("RGM_DIT_HALVES") ? atoi(getenv("RGM_DIT_HALVES")) : -1;
 static bool dit_halves_for(int N) {
   if (g_dit_halves == 0 || N < 2) return false;
   if (g_dit_halves > 0) return N >= g_dit_halves;
-  return N == 2 || (N >= 5 && N <= 9) || (N >= 17 && N <= 39) || N >= 57;
+  // (round 5, after the 144-column tiles' raster / prefetch: profiles/r05_halves_sweep.txt -- B = 4 1.7 % and B = 40 / 48 / 56 4.4 / 2.7 / 3.3 % ahead
+  // as halves now, 10 .. 16 still 5-7 % behind, 3 behind)
+  return N == 2 || (N >= 4 && N <= 9) || N >= 17;
 }
 // parts of a split forward (2 .. 4; read once: the workspace plan depends on it).  Three and four parts measured behind two at every batch
 // size but B = 112 (profiles/r04_halves_parts.txt): the parts of a forward re-read the weights and shrink the tile grids
