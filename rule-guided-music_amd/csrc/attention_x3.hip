@@ -85,7 +85,7 @@ template <int HD>
 __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const float* __restrict__ qkv, float* __restrict__ o,
                                                                           const float* __restrict__ cos_tab,
                                                                           const float* __restrict__ sin_tab, int T, int heads, int rot_half,
-                                                                          float* __restrict__ lse, int out_split, int stagger) {
+                                                                          float* __restrict__ lse, int out_split, int stagger, int qsplit) {
   constexpr int KP = (HD + 15) / 16 * 16;
   constexpr int KS = KP / 16;
   constexpr int DT = (HD + 31) / 32;
@@ -99,7 +99,11 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
   static_assert((KROW / 16) % 2 == 1 && (VROW / 16) % 2 == 1, "slot strides must be odd");
   extern __shared__ __attribute__((aligned(16))) char smem3[];
 
-  const int n = blockIdx.x / heads, head = blockIdx.x - n * heads;
+  // qsplit (1, 2, 4; round 5): the 256 queries of a (sample, head) over qsplit workgroups -- every one stages all of K / V (its eight waves
+  // share that work as before), its first 8 / qsplit waves own 32 queries each and the others skip the MFMA sections.  Small batches leave
+  // most CUs without a (sample, head) otherwise (B = 4: 64 workgroups).  Per query the arithmetic and its order are unchanged: identical rows.
+  const int pair = blockIdx.x / qsplit, qs = blockIdx.x - pair * qsplit;
+  const int n = pair / heads, head = pair - n * heads;
   const int D = heads * HD, D3 = 3 * D;
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
@@ -202,7 +206,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
   // ---- Q fragments of this wave's 32 queries (8 waves x 32 = 256 >= T): lane (query l31, half hh) holds Q[q][16j + 8hh .. +7].
   // Requested HERE, before the table loop: that loop's LDS writes wait for its own loads and, loads returning in order, for block 0's
   // as well -- Q requested after it was a second full round trip of every workgroup of the launch at the same moment.
-  const int q = wave * 32 + l31;
+  const int wq = 8 / qsplit;
+  const bool active = wave < wq;                               // wave-uniform
+  const int q = active ? (qs * wq + wave) * 32 + l31 : T;
   const int qc = min(q, T - 1);
   float4 qraw[KS][2];
   {
@@ -280,6 +286,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
   for (int b = 0; b < nb; ++b) {
     const char* Ks = smem3 + (b & 1) * BUF;
     const char* Vt = Ks + KBYTES;
+    if (active) {
     // ---- S^T of the block's two key tiles
     f32x16 sacc[2];
 #pragma unroll
@@ -352,6 +359,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
         }
       }
     }
+    }   // active
     __builtin_amdgcn_sched_barrier(0);
     if (b < 4) { ATTN_STAMP(5 + 3 * b) }
     // ---- the next block (requested one iteration ago) goes to the other buffer -- last read in iteration b-1, behind a barrier;
@@ -395,6 +403,9 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
 #endif
 }
 
+}  // namespace rgm
+int g_attn_co_sched = 0;   // dit.hip: the launches of a forward run as two half batches are being issued
+namespace rgm {
 template <int HD>
 static int launch_attn_x3_blocked(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,
                                   float* lse, int out_split, hipStream_t s) {
@@ -408,7 +419,16 @@ static int launch_attn_x3_blocked(const float* qkv, float* o, const float* ct, c
   if (prepared_lds != lds) RGM_TRY(attn_prepare_kernel(kern, 512, lds, "rotary_attention_x3_blocked_kernel"));
   prepared_lds = lds;
   static const int stagger = RGM_EXP_ENV("RGM_ATTN_STAGGER");
-  hipLaunchKernelGGL(kern, dim3(N * heads), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split, stagger);
+  // query split: as many workgroups per (sample, head) -- 4, 2 or 1 -- as keep the launch within one round of the 256 CUs (RGM_ATTN_QSPLIT: A/B runs)
+  const char* qs_str = getenv("RGM_ATTN_QSPLIT");            // read per launch: the parity test switches it inside one process
+  const int qs_env = qs_str ? atoi(qs_str) : 0;
+  // Measured (tools/attn_time.py, identical outputs): B = 1 / 2 / 4 / 8 launches 21.6 / 21.9 / 22.9 / 25.2 us unsplit, 15.6 / 16.8 / 18.6 / 23.7
+  // at the best split -- up to 128 workgroups; 256 lose again (B = 4 x 4: 19.4, B = 8 x 4: 36.9).  Beside a second stream's launches (the
+  // forward as two half batches: g_attn_co_sched, set by dit.hip) the CUs a small attention launch leaves are what the other half's GEMMs
+  // run on: splitting to 128 workgroups there made the B = 4 / 8 forwards 7-8 % slower, so at most 64.
+  const int pairs = N * heads, cap = g_attn_co_sched ? 64 : 128;
+  int qsplit = qs_env == 1 || qs_env == 2 || qs_env == 4 ? qs_env : (pairs * 4 <= cap ? 4 : pairs * 2 <= cap ? 2 : 1);
+  hipLaunchKernelGGL(kern, dim3(pairs * qsplit), dim3(512), lds, s, qkv, o, ct, st, T, heads, rot_half, lse, out_split, stagger, qsplit);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -19,6 +19,7 @@
 #include <math.h>
 #include "common.h"
 
+extern int g_attn_co_sched;   // attention_x3.hip
 namespace rgm {
 int patchify_launch(const float* x, float* tok, int N, int C, int H, int W, int P, hipStream_t s);
 int unpatchify_launch(const float* tok, float* out, int N, int OC, int H, int W, hipStream_t s);
@@ -51,15 +52,16 @@ static int g_adaln_overlap = getenv("RGM_ADALN_OVERLAP") ? atoi(getenv("RGM_ADAL
 // The blocks of an eps-network forward as TWO half batches on two streams (rows of different samples never meet inside a block): one
 // half's kernels fill the CUs the other half's last tile round leaves idle, and their write-bound epilogues fall under the other half's
 // K loops.  g_dit_halves (rgm_set_dit_halves / RGM_DIT_HALVES): -1 = where the same-box sweep of tools/halves_exp.py found it ahead
-// (profiles/r04_halves_sweep.txt, r05_halves_sweep.txt: B = 2, 4..9 and from 17 up -- 2..14 % -- but behind at 3 and 10..14, and even at 16, where
+// (profiles/r04_halves_sweep.txt, r05_halves_sweep.txt: B = 2, 5..9 and from 17 up -- 2..14 % -- but behind at 10..14, and even at 16, where
 // ONE round of 256x256 tiles per GEMM leaves nothing to overlap); 0 = never; n > 0 = every batch of at least n samples.
 static int g_dit_halves = getenv("RGM_DIT_HALVES") ? atoi(getenv("RGM_DIT_HALVES")) : -1;
 static bool dit_halves_for(int N) {
   if (g_dit_halves == 0 || N < 2) return false;
   if (g_dit_halves > 0) return N >= g_dit_halves;
-  // (round 5, after the 144-column tiles' raster / prefetch: profiles/r05_halves_sweep.txt -- B = 4 1.7 % and B = 40 / 48 / 56 4.4 / 2.7 / 3.3 % ahead
-  // as halves now, 10 .. 16 still 5-7 % behind, 3 behind)
-  return N == 2 || (N >= 4 && N <= 9) || N >= 17;
+  // (round 5, after the 144-column tiles' raster / prefetch: profiles/r05_halves_sweep.txt -- B = 40 / 48 / 56 4.4 / 2.7 / 3.3 % ahead as halves
+  // now, 10 .. 16 still 5-7 % behind; with a (sample, head)'s queries split over workgroups (attention_x3.hip) B = 4 is 5.12 ms as ONE batch
+  // against 5.30 as halves, B = 2 / 3 are level: profiles/r05_halves_sweep_small.txt)
+  return N == 2 || (N >= 5 && N <= 9) || N >= 17;
 }
 // parts of a split forward (2 .. 4; read once: the workspace plan depends on it).  Three and four parts measured behind two at every batch
 // size but B = 112 (profiles/r04_halves_parts.txt): the parts of a forward re-read the weights and shrink the tile grids
@@ -704,7 +706,10 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
         q.xm_ready = 0;
         RGM_TRY(lin2(xm, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), qkv, 3 * D, D, 0, 0, nullptr, nullptr, RGM_EXP_ENV("RGM_QKV_TILE")));
         RGM_TRY(release(i, k, 1));
-        RGM_TRY(rotary_attention_fwd(qkv, ao, h->cos_tab, h->sin_tab, q.n, T, c.heads, h->hd, h->rot_half, q.st, 1));
+        g_attn_co_sched = halves ? 1 : 0;          // attention_x3.hip: how far to split a (sample, head) over workgroups
+        const int attn_rc = rotary_attention_fwd(qkv, ao, h->cos_tab, h->sin_tab, q.n, T, c.heads, h->hd, h->rot_half, q.st, 1);
+        g_attn_co_sched = 0;
+        RGM_TRY(attn_rc);
         RGM_TRY(release(i, k, 2));
         RGM_TRY(lin2(ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x, D, D, 0, 0, m + 2 * D, x, 0));
         RGM_TRY(release(i, k, 3));

@@ -122,6 +122,47 @@ def test_rotary_attention(N, T, heads, hd):
     assert rel(od.cpu().numpy(), ref) < 3e-6
 
 
+@pytest.mark.parametrize("N,T", [(1, 256), (2, 256), (4, 256), (3, 200), (8, 256)])
+def test_attention_queries_split_over_workgroups_give_identical_rows(N, T):
+    """csrc/attention_x3.hip, key-blocked kernel (128 < T <= 256; ref guided_diffusion/dit.py:263-288): at small batches the queries of a
+    (sample, head) are split over 2 or 4 workgroups (each stages all of K / V, its first 8 / qsplit waves own 32 queries each) so that
+    the launch is not 16 N workgroups on 256 CUs.  Per query nothing changes -- the rows must be IDENTICAL to the unsplit launch, for
+    every split (RGM_ATTN_QSPLIT is read per launch) and for the heuristic's own choice; a ragged T leaves the last waves without queries."""
+    import os
+    from gpu_util import dev
+    from rgm import native as R
+    from rgm.synth import rotary_freqs
+    heads, hd = 16, 72
+    rng = np.random.RandomState(N * 1000 + T)
+    D = heads * hd
+    rot = hd // 2
+    qkv = dev((rng.randn(N * T, 3 * D) * 1.5).astype(F32))
+    cos, sin = odit.rotary_tables(rotary_freqs(rot), T)
+    cd, sd_ = dev(cos), dev(sin)
+    R.set_gemm_precision("bf16x3_presplit")
+    outs = {}
+    old = os.environ.get("RGM_ATTN_QSPLIT")
+    try:
+        for qs in ("1", "2", "4", None):
+            if qs is None:
+                os.environ.pop("RGM_ATTN_QSPLIT", None)
+            else:
+                os.environ["RGM_ATTN_QSPLIT"] = qs
+            od = torch.full((N * T, D), float("nan"), device="cuda")
+            R.check(R.lib.rgm_rotary_attention(R.ptr(qkv), R.ptr(od), R.ptr(cd), R.ptr(sd_), N, T, heads, hd, rot // 2, R.current_stream()))
+            torch.cuda.synchronize()
+            outs[qs] = od
+    finally:
+        if old is None:
+            os.environ.pop("RGM_ATTN_QSPLIT", None)
+        else:
+            os.environ["RGM_ATTN_QSPLIT"] = old
+        R.set_gemm_precision("fp32")
+    assert bool(torch.isfinite(outs["1"]).all())
+    for qs in ("2", "4", None):
+        assert torch.equal(outs[qs], outs["1"]), qs
+
+
 def _split(x):
     """numpy fp32 (R,K) -> split-row image via the device kernel, returned as a device tensor of the same shape."""
     from gpu_util import dev

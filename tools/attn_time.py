@@ -18,6 +18,7 @@ rot = hd // 2
 ang = torch.arange(T, dtype=torch.float32)[:, None] * torch.from_numpy(rotary_freqs(rot))[None]
 cs, sn = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda()
 # 8 different qkv buffers in turn (8 x 57 MB at B = 16): no launch finds its input in L2
+torch.manual_seed(7)
 bufs = [torch.randn(N * T, 3 * D, device="cuda") for _ in range(8)]
 o = torch.empty(N * T, D, device="cuda")
 
@@ -34,4 +35,8 @@ for i in range(200):
     run(i)
 e1.record()
 torch.cuda.synchronize()
-print(f"rotary attention B={N}: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us per launch ({os.environ.get('RGM_LIB_PATH', 'librgm_hip.so')})")
+import hashlib  # noqa: E402
+run(0)
+torch.cuda.synchronize()
+digest = hashlib.sha1(o.cpu().numpy().tobytes()).hexdigest()[:12]
+print(f"rotary attention B={N} RGM_ATTN_QSPLIT={os.environ.get('RGM_ATTN_QSPLIT', 'auto')} output sha1 {digest}: {e0.elapsed_time(e1) / 200 * 1e3:.1f} us per launch ({os.environ.get('RGM_LIB_PATH', 'librgm_hip.so')})")
