@@ -143,6 +143,58 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // ---- PF: operand lines of K-tile kt + PF pulled into this XCD's L2 ahead of the loaders (round 5).  In the forward the loaders' LDS-DMA
+  // requests miss L2 (weights from HBM, A from the Infinity Cache) and their ISSUE backs up behind the outstanding misses -- 950-1300 cycles
+  // per K-tile against 420 on warm operands (tools/g144_insitu_stamp.py), the consumers wait 370-710 at every barrier.  A request that
+  // costs nothing to wait for hides it: one 4-byte LDS-DMA per line into a scratch KiB behind the ring, issued by the consumer waves (their
+  // vmcnt is otherwise unused) PF K-tiles ahead.  The tiles of an XCD share panels (raster above): the gsz row tiles of a sweep share a B
+  // panel, the XCD's column panels share an A panel; each takes its share of the rows, so a line is requested once per XCD.
+  const char* pf_src = zero_page;
+  int pf_inc = 0, pf_left = 0;
+  char* pf_dst = ring + NSTAGE * STAGE + wave * 256;
+  if constexpr (PF > 0) {
+    const int q8 = nb >> 3;                                  // tiles per XCD (r == 0)
+    const bool aligned = r == 0 && q8 % gsz == 0 && (per_group % q8 == 0 || q8 % per_group == 0);
+    int nA = aligned ? min(q8 / gsz, tiles_n) : 1;
+    nA = nA >= 8 ? 8 : nA >= 4 ? 4 : nA >= 2 ? 2 : 1;
+    const int nB = aligned ? gsz : 1;
+    const int iA = (in_g / gsz) % nA, iB = in_g % gsz % nB;
+    // A only where the XCD's tiles share it (a K slice's row panel is read once per XCD: nothing to share, and 128 more requests per K-tile
+    // overload the L1 fill path: 1793 -> 2243 cycles per K-tile on fc2's slices at B = 4) and when asked for (p.tile_flags bit 0: A/B runs)
+    const int a_cnt = (nA > 1 && pf_a) ? BM / nA : 0, b_cnt = (BN + nB - 1) / nB;
+    const int slot = wave * 64 + lane;
+    if (slot < a_cnt) {
+      const int row = m0 + iA * a_cnt + slot;
+      if (row < p.M) { pf_src = Ab + (long long)row * p.lda * 4; pf_inc = 128; }
+    } else if (slot < a_cnt + b_cnt) {
+      const int rl = iB * b_cnt + slot - a_cnt, row = n0 + rl;
+      if (rl < BN && row < p.N) { pf_src = Bb + (long long)row * p.ldb * 4; pf_inc = 128; }
+    }
+    // K-tiles NSTAGE - 1 .. PF - 1 while the loaders fetch the first ones; from then on one per K-tile
+    pf_src += (long long)pf_inc * (NSTAGE - 1);
+    pf_left = KT - (NSTAGE - 1);
+    for (int i = NSTAGE - 1; i < PF; ++i) {
+      if (pf_left > 0) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+        pf_src += pf_inc;
+      }
+      --pf_left;
+    }
+  }
+  // (Requesting the tile's RESIDUAL lines in the last K-tiles as well was measured -- 12.10 vs 12.10 ms per C2 step, the epilogue is bound by its
+  // stores -- and removed.)  Two halves for two MFMA gaps: the request, then the pointer.
+  auto prefetch_issue = [&]() {
+    if constexpr (PF > 0) {
+      if (pf_left > 0)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+    }
+  };
+  auto prefetch_advance = [&]() {
+    if constexpr (PF > 0) {
+      pf_src += pf_inc;
+      --pf_left;
+    }
+  };
   // Fragments of one K-tile: row l15 of the 16-row tile, k = 8 kb .. 8 kb + 7.  Term t of an accumulator (t-major MFMA order) multiplies
   //   t = 0: a.lo x b.hi     t = 1: a.hi x b.lo     t = 2: a.hi x b.hi
   // so the lo halves are dead after their term and are overwritten with the NEXT tile's while the tile is still being multiplied; only
@@ -177,6 +229,10 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
         // b.lo[in] is free once the LAST row tile's term-1 MFMA has used it: all of term 1 is behind us
         if constexpr (m < TN) rd(lo.b[m], nst, br + m * 16, 1);
       }
+      // the L2 prefetch of this K-tile rides in a gap that carries nothing else (behind the barrier it was 10 more instructions in the one
+      // gap where the MFMA pipe drains anyway: waitcnt + barrier)
+      if constexpr (PRE && T == 2 && m == TN + 2) prefetch_issue();
+      if constexpr (PRE && T == 2 && m == TN + 5) prefetch_advance();
       __builtin_amdgcn_sched_barrier(0);
     });
   };
@@ -185,63 +241,6 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
   using I2 = std::integral_constant<int, 2>;
   static_assert(2 * TM + TN <= NT && TN <= NT, "the next tile's reads fit between the MFMAs of terms 1 and 2");
   Half h0, h1, lo;
-  // ---- PF: operand lines of K-tile kt + PF pulled into this XCD's L2 ahead of the loaders (round 5).  In the forward the loaders' LDS-DMA
-  // requests miss L2 (weights from HBM, A from the Infinity Cache) and their ISSUE backs up behind the outstanding misses -- 950-1300 cycles
-  // per K-tile against 420 on warm operands (tools/g144_insitu_stamp.py), the consumers wait 370-710 at every barrier.  A request that
-  // costs nothing to wait for hides it: one 4-byte LDS-DMA per line into a scratch KiB behind the ring, issued by the consumer waves (their
-  // vmcnt is otherwise unused) PF K-tiles ahead.  The tiles of an XCD share panels (raster above): the gsz row tiles of a sweep share a B
-  // panel, the XCD's column panels share an A panel; each takes its share of the rows, so a line is requested once per XCD.
-  const char* pf_src = zero_page;
-  int pf_inc = 0, pf_left = 0;
-  char* pf_dst = ring + NSTAGE * STAGE + wave * 256;
-  if constexpr (PF > 0) {
-    const int q8 = nb >> 3;                                  // tiles per XCD (r == 0)
-    const bool aligned = r == 0 && q8 % gsz == 0 && (per_group % q8 == 0 || q8 % per_group == 0);
-    int nA = aligned ? min(q8 / gsz, tiles_n) : 1;
-    nA = nA >= 8 ? 8 : nA >= 4 ? 4 : nA >= 2 ? 2 : 1;
-    const int nB = aligned ? gsz : 1;
-    const int iA = (in_g / gsz) % nA, iB = in_g % gsz % nB;
-    // A only where the XCD's tiles share it (a K slice's row panel is read once per XCD: nothing to share, and 128 more requests per K-tile
-    // overload the L1 fill path: 1793 -> 2243 cycles per K-tile on fc2's slices at B = 4) and when asked for (p.tile_flags bit 0: A/B runs)
-    const int a_cnt = (nA > 1 && (pf_a & 1)) ? BM / nA : 0, b_cnt = (BN + nB - 1) / nB;
-    const int slot = wave * 64 + lane;
-    if (slot < a_cnt) {
-      const int row = m0 + iA * a_cnt + slot;
-      if (row < p.M) { pf_src = Ab + (long long)row * p.lda * 4; pf_inc = 128; }
-    } else if (slot < a_cnt + b_cnt) {
-      const int rl = iB * b_cnt + slot - a_cnt, row = n0 + rl;
-      if (rl < BN && row < p.N) { pf_src = Bb + (long long)row * p.ldb * 4; pf_inc = 128; }
-    }
-    // K-tiles NSTAGE - 1 .. PF - 1 while the loaders fetch the first ones; from then on one per K-tile
-    pf_src += (long long)pf_inc * (NSTAGE - 1);
-    pf_left = KT - (NSTAGE - 1);
-    for (int i = NSTAGE - 1; i < PF; ++i) {
-      if (pf_left > 0) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
-        pf_src += pf_inc;
-      }
-      --pf_left;
-    }
-  }
-  // ... and, once the operands are all requested (the last PF K-tiles), the tile's RESIDUAL lines: 32 rows per wave x 576 bytes = five lines per
-  // row, one line index per K-tile (lanes 32-63 repeat lanes 0-31).  The epilogue's residual reads then hit L2 instead of queueing 73 KB per
-  // CU of HBM / Infinity Cache reads in front of its stores (in situ: 23-25 k cycles of epilogue on proj at B = 16 against 12 k warm).
-  const float* res_pf = (p.res && (pf_a & 2)) ? p.res + (long long)z * p.sRes : nullptr;
-  auto prefetch_next = [&]() {
-    if constexpr (PF > 0) {
-      if (pf_left == 0 && res_pf) {
-        const int row = m0 + arow0 + (lane & 31);
-        const bool ok = row < p.M;
-        pf_src = ok ? reinterpret_cast<const char*>(res_pf + (long long)row * p.ldres + n0) : zero_page;
-        pf_inc = ok ? 128 : 0;
-      }
-      if (pf_left > (res_pf ? -5 : 0)) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pf_src, (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
-        pf_src += pf_inc;
-      }
-      --pf_left;
-    }
-  };
   __builtin_amdgcn_s_barrier();                         // barrier P (loaders: tile 0 landed)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
@@ -265,7 +264,6 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     if (DBG) tacc[0] += now() - ta;
     __builtin_amdgcn_sched_barrier(0);
     const char* nst = ring + s1 * STAGE;
-    prefetch_next();
     term(I1{}, cur, lo, nxt, nst, I1{});
     term(I2{}, cur, lo, nxt, nst, I1{});
     s1 = s1 == NSTAGE - 1 ? 0 : s1 + 1;
@@ -385,7 +383,7 @@ int gemm144_launch(const GemmParams& p, hipStream_t s) {
   }
   constexpr int NSTAGE = 4;      // 144 KiB of the 160: one workgroup per CU (profiler id 135)
   constexpr int PFD = 8;         // L2 prefetch distance in K-tiles (kernel: PF).  Same box, C2 step / B = 4 forward: 4 -> 12.58 / 5.50 ms, 8 -> 12.12 / 5.30, 16 -> 12.32 / 5.40
-  static const int pf_on = getenv("RGM_G144_PF") ? atoi(getenv("RGM_G144_PF")) : 3;   // bit 0: prefetch, bit 1: A panels too (where shared), bit 2: the residual's lines in the last K-tiles (measured: no change, off)
+  static const int pf_on = getenv("RGM_G144_PF") ? atoi(getenv("RGM_G144_PF")) : 3;   // bit 0: prefetch, bit 1: A panels too (where shared)
   const int tm = cdiv(p.M, BM), tn = p.N / BN;
   const size_t lds = (size_t)NSTAGE * STAGE + 1024;      // + the prefetch's scratch KiB
   GemmParams pr = p;
