@@ -404,7 +404,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
 }
 
 }  // namespace rgm
-int g_attn_co_sched = 0;   // dit.hip: the launches of a forward run as two half batches are being issued
+thread_local int g_attn_co_sched = 0;   // dit.hip (the issuing host thread): the launches of a forward run as two half batches are being issued
 namespace rgm {
 template <int HD>
 static int launch_attn_x3_blocked(const float* qkv, float* o, const float* ct, const float* st, int N, int T, int heads, int rot_half,

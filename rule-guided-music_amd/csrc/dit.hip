@@ -19,7 +19,7 @@
 #include <math.h>
 #include "common.h"
 
-extern int g_attn_co_sched;   // attention_x3.hip
+extern thread_local int g_attn_co_sched;   // attention_x3.hip
 namespace rgm {
 int patchify_launch(const float* x, float* tok, int N, int C, int H, int W, int P, hipStream_t s);
 int unpatchify_launch(const float* tok, float* out, int N, int OC, int H, int W, hipStream_t s);
