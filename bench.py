@@ -648,7 +648,7 @@ def main():
         batch_shard.partition_roles = lambda B, ws=None, r=None: batch_shard._orig_partition_roles(B, Rn, 0)   # rank 0: an eps row (the longer role)
         batch_shard.gather_rows = lambda ts: [t.repeat((Rn,) + (1,) * (t.dim() - 1)) for t in ts]   # stand-in: shapes, not values
         batch_shard.window_ranks = lambda: Rn                          # B = 1 (C5): the collage windows of the x_t forward, rank 0's share
-        batch_shard.window_world = lambda: (Rn, 0) if batch_shard.WINDOW_SHARD else (1, 0)
+        batch_shard.window_world = lambda: (Rn, 0) if batch_shard.window_shard_on() else (1, 0)
         batch_shard.reduce_windows = lambda t: t                       # stand-in for the all-reduce of the window eps
     if args.workload in ("c2", "c3", "dps_rule"):
         work.d.batch_shard = False            # the headline runs one independent chain per GPU (weak scaling): nothing to shard

@@ -672,6 +672,9 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
       }
       return RGM_OK;
     };
+    // (a lambda: an error return between the fork and the join below must not leave the side streams running into the shared workspace --
+    // the caller's next launch on `s` would race with them)
+    auto run_blocks = [&]() -> int {
     for (int i = 0; i < c.depth; ++i) {
       const std::string b = "blocks." + std::to_string((dit_exp & 2) ? 0 : i) + ".";
       for (int k = 0; k < nparts; ++k) {
@@ -722,6 +725,15 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
         RGM_TRY(lin2(hid, b + "mlp.fc2.weight", h->p(b + "mlp.fc2.bias"), x, D, 4 * D, 0, 0, m + 5 * D, x, RGM_EXP_ENV("RGM_FC2_TILE"),
                      i + 1 < c.depth ? m + 6 * D : nullptr, &q.xm_ready));
       }
+    }
+    return RGM_OK;
+    };
+    const int blocks_rc = run_blocks();
+    if (blocks_rc != RGM_OK) {
+      g_attn_co_sched = 0;
+      for (int k = 1; k < nparts; ++k) (void)hipStreamSynchronize(parts[k].st);
+      if (!joined && h->side) (void)hipStreamSynchronize(h->side);
+      return blocks_rc;
     }
     for (int k = 1; k < nparts; ++k) {
       hipEvent_t ev = k == 1 ? h->ev_join : h->ev_join_x[k - 2];

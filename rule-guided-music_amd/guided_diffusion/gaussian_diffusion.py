@@ -322,12 +322,12 @@ class GaussianDiffusion:
             return run(x, t, model_kwargs, edit_kwargs)
         if B == 1 and roles is None and cond_fn is None and edit_kwargs is None and batch_shard.window_ranks() > 1:
             # ONE sample on many ranks (BASELINE config 5): nothing to share out by rows -- a DiffCollage eps-network shares out its
-            # windows instead (diff_collage/condind_long.py + batch_shard.WINDOW_SHARD) and every rank ends with the same full eps
-            batch_shard.WINDOW_SHARD = True
+            # windows instead (diff_collage/condind_long.py + batch_shard.set_window_shard) and every rank ends with the same full eps
+            batch_shard.set_window_shard(True)
             try:
                 return run(x, t, model_kwargs, edit_kwargs)
             finally:
-                batch_shard.WINDOW_SHARD = False
+                batch_shard.set_window_shard(False)
         if roles is not None:
             # R >= 2 B: eps of row b on rank b, its guidance gradient on rank B + b, at the same time; one all-gather of (eps | grad)
             row, role = roles

@@ -11,6 +11,7 @@ repeating them.  Batches that do not divide by the world size stay replicated.
 
 Pure host logic (no HIP calls): the N > 1 control flow is testable with world_size-2 gloo on CPU.
 """
+import threading
 import torch
 import torch.distributed as dist
 
@@ -68,10 +69,21 @@ _orig_partition_roles = partition_roles
 
 # ---- window sharding of a replicated DiffCollage forward (BASELINE config 5: ONE long sample on 8 ranks)
 # The x_t forward of a search step is per-sample work; with B = 1 every rank would repeat all 7 + 6 windows of the collage.  While
-# WINDOW_SHARD is set (gaussian_diffusion._search_step_inputs, around that forward only) diff_collage's CondIndSimple evaluates the
+# the window-shard flag is set (set_window_shard, by gaussian_diffusion._search_step_inputs around that forward only) diff_collage's CondIndSimple evaluates the
 # windows whose index is congruent to this rank and completes the rest with ONE all-reduce of the (zero-filled) window eps: every element
 # has exactly one non-zero contributor, so the sum is exact and identical on every rank.
-WINDOW_SHARD = False
+# Per THREAD (advisor, round 4): a collage model evaluated on another host thread while this one is inside its sharded forward must not enter
+# the all-reduce -- if only some ranks took that path the collective would deadlock.
+_window_tls = threading.local()
+
+
+def window_shard_on():
+    """True while THIS thread is inside the sharded x_t forward of a search step"""
+    return getattr(_window_tls, "on", False)
+
+
+def set_window_shard(on):
+    _window_tls.on = bool(on)
 
 
 def window_ranks():
@@ -81,7 +93,7 @@ def window_ranks():
 
 def window_world():
     """(world size, rank) the collage worker shards its windows over -- (1, 0) outside a sharded x_t forward"""
-    return world() if WINDOW_SHARD else (1, 0)
+    return world() if window_shard_on() else (1, 0)
 
 
 def window_share(n_full, n_half, world_size, rank):

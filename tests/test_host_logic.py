@@ -665,7 +665,7 @@ def test_role_split_and_window_share_rules():
                 half += list(h)
                 assert abs((len(f) + len(h)) - (n_full + n_half) / R) < 1.0 + 1e-9          # balanced to within one window
             assert sorted(full) == list(range(n_full)) and sorted(half) == list(range(n_half)), (n_full, n_half, R)
-    assert bs.window_world() == (1, 0) and bs.WINDOW_SHARD is False
+    assert bs.window_world() == (1, 0) and bs.window_shard_on() is False
 
 
 def _prevx_partition_worker(rank, world, port, q):
