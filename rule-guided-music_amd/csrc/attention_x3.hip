@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512) void rotary_attention_x3_blocked_kernel(const 
             lo[0] = (split_t)(ov.x - (float)hi[0]); lo[1] = (split_t)(ov.y - (float)hi[1]);
             lo[2] = (split_t)(ov.z - (float)hi[2]); lo[3] = (split_t)(ov.w - (float)hi[3]);
             split_t* rp = reinterpret_cast<split_t*>(o + ((long long)n * T + q) * D);
-            store_split4_pair<false, 32>(rp, head * HD + d, hi, lo);   // lanes l / l + 32 (hh = 0 / 1) hold one 8-aligned group of the same row: 16 bytes each
+            store_split4_maybe_pair<32>(rp, head * HD + d, hi, lo);   // lanes l / l + 32 (hh = 0 / 1) hold one 8-aligned group of the same row: 16 bytes each
           } else {
             *reinterpret_cast<float4*>(op + d) = ov;
           }

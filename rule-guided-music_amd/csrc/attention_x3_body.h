@@ -357,7 +357,7 @@ __device__ __forceinline__ void attn_x3_body(char* smem3, const float* __restric
               if constexpr (COH) {   // lanes l (hh = 0: channels 8g .. +3) and l + 32 (hh = 1: +4 .. +7) hold one 8-aligned group (HD % 8 == 0)
                 store_split4_pair_sc1<32>(rp, head * HD + d, hi, lo);
               } else {
-                store_split4_pair<false, 32>(rp, head * HD + d, hi, lo);   // the same pairing, ordinary stores
+                store_split4_maybe_pair<32>(rp, head * HD + d, hi, lo);   // the same pairing, ordinary stores
               }
             } else {
               *reinterpret_cast<float4*>(op + d) = ov;

@@ -147,6 +147,21 @@ __device__ __forceinline__ void store_split4_pair(split_t* rowp, int col, const 
   else *dst = __builtin_bit_cast(f32x4, out);
 }
 
+// The row kernels (LayerNorm bodies, attention output, the 144-column GEMM): paired unless the build says otherwise (-DRGM_ROW_SPLIT_PAIR=0: the
+// A/B build of tools/ab_lib.sh)
+#ifndef RGM_ROW_SPLIT_PAIR
+#define RGM_ROW_SPLIT_PAIR 1
+#endif
+template <int XOR>
+__device__ __forceinline__ void store_split4_maybe_pair(split_t* rowp, int col, const split_x4& hi, const split_x4& lo) {
+  if constexpr (RGM_ROW_SPLIT_PAIR) {
+    store_split4_pair<false, XOR>(rowp, col, hi, lo);
+  } else {
+    *reinterpret_cast<split_x4*>(rowp + split_idx(col)) = hi;
+    *reinterpret_cast<split_x4*>(rowp + split_idx(col) + 32) = lo;
+  }
+}
+
 // 16-byte load from GLOBAL memory, said so: a pointer that reaches a device function through a descriptor in memory (chain.hip) is a
 // generic pointer to the compiler -- flat loads, which count on lgkmcnt as well and serialise against the LDS traffic around them
 __device__ __forceinline__ float4 ldg16(const float* q) {
@@ -245,6 +260,8 @@ struct GemmParams {
   int raster_group = 0;
   // one-wave-per-SIMD tiles: ordinary instead of non-temporal output stores (set by launch2 from RGM_ST_PLAIN: bit 0 fp32 rows, bit 1 split rows)
   int st_plain = 0;
+  // gemm2 epilogues: split rows as lane pairs, 16 bytes per lane (set by launch2: RGM_SPLIT_PAIR, default by kernel family)
+  int split_pair = 0;
   // loader/consumer tiles (PIPE 4): L2 prefetch distance of the B panel in K-tiles, 0 = off (set by launch2: RGM_P4_PF, and only where the scratch KiB fits)
   int pf_kt = 0;
   // K-slice launches of gemm2_launch (fc2 of a DiT block): the reduce kernel holds whole output rows, so it can also write the NEXT

@@ -343,7 +343,7 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
           lo[e] = (split_t)(v[e] - (float)hi[e]);
         }
         split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
-        if (ok) store_split4_pair<false, 16>(rowp, col, hi, lo);     // 16 bytes per lane: the hi halves of 8 columns (kb even) / their lo halves
+        if (ok) store_split4_maybe_pair<16>(rowp, col, hi, lo);     // 16 bytes per lane: the hi halves of 8 columns (kb even) / their lo halves
         continue;
       }
       if (!ok) continue;

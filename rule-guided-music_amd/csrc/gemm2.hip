@@ -104,6 +104,11 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   dim3 grid(tm * tn, 1, p.batch), block(WM * WN * 64 * (PIPE == 4 ? 2 : 1));
   GemmParams pr = p;
   pr.pf_kt = pf4 ? p4_pf : 0;
+  {
+    // -1 (default): paired everywhere but on the one-wave-per-SIMD tiles (gemm2_body.h split_store); 0 / 1: never / always (A/B runs)
+    static const int sp = getenv("RGM_SPLIT_PAIR") ? atoi(getenv("RGM_SPLIT_PAIR")) : -1;
+    pr.split_pair = sp < 0 ? (PIPE == 5 ? 0 : 1) : sp;
+  }
   if (PIPE == 5) {
     static const int st_plain = getenv("RGM_ST_PLAIN") ? atoi(getenv("RGM_ST_PLAIN")) : 0;
     pr.st_plain = p.out_split ? (st_plain >> 1) & 1 : st_plain & 1;

@@ -855,6 +855,23 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
       }
     };
+    // split rows: 2 x 8 bytes per lane (hi halves, lo halves of its 4 columns), or lanes (2k, 2k+1) paired to one 16-byte store each
+    // (p.split_pair, launch2).  Pairing halves the store instructions but pays two DPP moves and four selects per row in VALU: it wins where
+    // other waves hide that (the LayerNorm rows, the 144-column kernel's two waves per SIMD) and LOSES on the one-wave-per-SIMD tiles --
+    // 256x256 epilogue, isolated: 33.8 -> 39.4 k cycles with split rows, 39.0 -> 48.5 k with GELU (tools/gemm_stamp.py SPLIT=1) -- so those keep 2 x 8.
+    typedef split_t bf16x4_t __attribute__((ext_vector_type(4)));
+    auto split_store = [&](split_t* rowp, int col, const bf16x4_t& hi, const bf16x4_t& lo) {
+      if (p.split_pair) {
+        if (PIPE == 5 && !p.st_plain) store_split4_pair<true>(rowp, col, hi, lo);
+        else store_split4_pair<false>(rowp, col, hi, lo);
+      } else if (PIPE == 5 && !p.st_plain) {
+        __builtin_nontemporal_store(hi, reinterpret_cast<bf16x4_t*>(rowp + split_idx(col)));
+        __builtin_nontemporal_store(lo, reinterpret_cast<bf16x4_t*>(rowp + split_idx(col) + 32));
+      } else {
+        *reinterpret_cast<bf16x4_t*>(rowp + split_idx(col)) = hi;
+        *reinterpret_cast<bf16x4_t*>(rowp + split_idx(col) + 32) = lo;
+      }
+    };
     auto store_row = [&](int row, const float (&v)[4]) {
       if (p.out_split) {   // split-row output (common.h split_idx): 4 hi then, 32 further, 4 lo
         typedef split_t bf16x4 __attribute__((ext_vector_type(4)));
@@ -868,8 +885,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         if constexpr (COH) {
           store_split4_pair_sc1<1>(rowp, col, hi, lo);      // lanes (2k, 2k+1) own columns 8k' .. 8k'+7 of the same row
         } else {
-          if (PIPE == 5 && !p.st_plain) store_split4_pair<true>(rowp, col, hi, lo);   // lanes (2k, 2k+1): one 16-byte store each (hi halves / lo halves of 8 columns)
-          else store_split4_pair<false>(rowp, col, hi, lo);
+          split_store(rowp, col, hi, lo);
         }
       } else if (exp != 4) {
         out16(Cb + (long long)row * p.ldc + col, v);
@@ -927,8 +943,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                   if constexpr (COH) {
                     store_split4_pair_sc1<1>(rowp, col, hi, lo);
                   } else {
-                    if (PIPE == 5 && !p.st_plain) store_split4_pair<true>(rowp, col, hi, lo);
-                    else store_split4_pair<false>(rowp, col, hi, lo);
+                    split_store(rowp, col, hi, lo);
                   }
                 } else {
                   if (exp != 4) out16(Cb + (long long)row * p.ldc + col, v);
@@ -1299,9 +1314,10 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
               estamp(1);
             }
             // this slab's residual rows have landed: only the stores of the previous slab's pass 2 were issued after their DMA
-            // (the counted wait below assumes exactly ONE store per row and lane -- store_row's out16, or its 16-byte half of a lane pair's
-            // split row -- behind the DMA; the experiment variants that drop stores wait for everything)
+            // (the counted waits below assume exactly ONE store per row and lane -- store_row's out16, or its 16-byte half of a lane pair's
+            // split row -- and TWO for unpaired split rows, behind the DMA; the experiment variants that drop stores wait for everything)
             if (im == 0 || !full || exp != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (p.out_split && !p.split_pair) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
             staged_pass1(stg, rslab, row_w + im * 32, g_lo[im], g_hi[im], bnd[im]);
             if constexpr (im + 1 < TM) {

@@ -100,7 +100,7 @@ __device__ __forceinline__ void ln_mod_finish(const LnRow<MAXV>& st, float* __re
       if constexpr (COH) {
         store_split4_pair_sc1<1>(rp, c * 4, hi, lo);       // lanes (2k, 2k+1) hold chunks (2j, 2j+1): one 8-aligned group
       } else {
-        store_split4_pair<false>(rp, c * 4, hi, lo);       // the same pairing, ordinary stores: 16 bytes per lane instead of 2 x 8
+        store_split4_maybe_pair<1>(rp, c * 4, hi, lo);     // the same pairing, ordinary stores: 16 bytes per lane instead of 2 x 8
       }
     } else {
       orow[c] = y;
@@ -241,7 +241,7 @@ __device__ __forceinline__ void splitk_reduce_ln_finish(const RedRow<MAXV, S>& s
       if constexpr (COH) {
         store_split4_pair_sc1<1>(rp, c * 4, hi, lo);
       } else {
-        store_split4_pair<false>(rp, c * 4, hi, lo);
+        store_split4_maybe_pair<1>(rp, c * 4, hi, lo);
       }
     } else {
       orow[c] = y;
