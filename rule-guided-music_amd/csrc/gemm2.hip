@@ -105,9 +105,10 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   GemmParams pr = p;
   pr.pf_kt = pf4 ? p4_pf : 0;
   {
-    // -1 (default): paired everywhere but on the one-wave-per-SIMD tiles (gemm2_body.h split_store); 0 / 1: never / always (A/B runs)
+    // -1 (default): lane pairs everywhere but on the one-wave-per-SIMD tiles, which give a lane EIGHT columns in the plain split-row epilogue
+    // (2; gemm2_body.h plain_rows8: C2 12.17 -> 12.11 ms same box) and 2 x 8-byte stores elsewhere; 0 / 1 / 2: forced (A/B runs)
     static const int sp = getenv("RGM_SPLIT_PAIR") ? atoi(getenv("RGM_SPLIT_PAIR")) : -1;
-    pr.split_pair = sp < 0 ? (PIPE == 5 ? 0 : 1) : sp;
+    pr.split_pair = sp < 0 ? (PIPE == 5 ? 2 : 1) : sp;
   }
   if (PIPE == 5) {
     static const int st_plain = getenv("RGM_ST_PLAIN") ? atoi(getenv("RGM_ST_PLAIN")) : 0;

@@ -861,7 +861,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // 256x256 epilogue, isolated: 33.8 -> 39.4 k cycles with split rows, 39.0 -> 48.5 k with GELU (tools/gemm_stamp.py SPLIT=1) -- so those keep 2 x 8.
     typedef split_t bf16x4_t __attribute__((ext_vector_type(4)));
     auto split_store = [&](split_t* rowp, int col, const bf16x4_t& hi, const bf16x4_t& lo) {
-      if (p.split_pair) {
+      if (p.split_pair == 1) {
         if (PIPE == 5 && !p.st_plain) store_split4_pair<true>(rowp, col, hi, lo);
         else store_split4_pair<false>(rowp, col, hi, lo);
       } else if (PIPE == 5 && !p.st_plain) {
@@ -952,9 +952,76 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
             }
           }
         };
+        // split rows with EIGHT columns per lane (p.split_pair == 2; the one-wave-per-SIMD tiles): 16 lanes per row, 4 rows per instruction --
+        // a lane stores the 8 hi halves (16 bytes) and the 8 lo halves (16 bytes) of its columns itself: half the store instructions of the
+        // 4-column mapping without the lane exchange of the paired variant (its DPP moves + selects are VALU time nobody hides here)
+        auto plain_rows8 = [&](auto act_c) {
+          constexpr int ACT = decltype(act_c)::value;
+          constexpr int LPR8 = WCOLS / 8, RPI8 = 64 / LPR8;
+          const int lr8 = lane / LPR8, lc8 = (lane % LPR8) * 8;
+          const int col8 = n0 + bcol0 + lc8;
+          const bool ok8 = col8 < p.N;
+          float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+          if (biasb && ok8) {
+            b0 = ldg16(biasb + col8);
+            b1 = ldg16(biasb + col8 + 4);
+          }
+          asm volatile("" : "+v"(b0.x), "+v"(b0.y), "+v"(b0.z), "+v"(b0.w), "+v"(b1.x), "+v"(b1.y), "+v"(b1.z), "+v"(b1.w));
+          const int rbase = row0 - lr + lr8;                      // row0 carries the 4-column mapping's row offset
+          const int nj8 = nj * RPI / RPI8;
+          typedef split_t bf16x8_t __attribute__((ext_vector_type(8)));
+          constexpr int U8 = 2;
+#pragma unroll 1
+          for (int j0 = 0; j0 < nj8; j0 += U8) {
+            float4 a8[U8][2];
+#pragma unroll
+            for (int u = 0; u < U8; ++u) {
+              const float* sp = slab + ((j0 + u) * RPI8 + lr8) * WCOLS + lc8;
+              a8[u][0] = *reinterpret_cast<const float4*>(sp);
+              a8[u][1] = *reinterpret_cast<const float4*>(sp + 4);
+            }
+#pragma unroll
+            for (int u = 0; u < U8; ++u) {
+              const int row = rbase + (j0 + u) * RPI8;
+              if (row < p.M && ok8) {
+                float v[8] = {a8[u][0].x * p.alpha + b0.x, a8[u][0].y * p.alpha + b0.y, a8[u][0].z * p.alpha + b0.z, a8[u][0].w * p.alpha + b0.w,
+                              a8[u][1].x * p.alpha + b1.x, a8[u][1].y * p.alpha + b1.y, a8[u][1].z * p.alpha + b1.z, a8[u][1].w * p.alpha + b1.w};
+                if (p.C2) {
+                  const float v0[4] = {v[0], v[1], v[2], v[3]}, v1[4] = {v[4], v[5], v[6], v[7]};
+                  out16(Cb + (long long)row * p.ldc + col8, v0);
+                  out16(Cb + (long long)row * p.ldc + col8 + 4, v1);
+                }
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) v[q8] = ACT == 1 ? silu_f(v[q8]) : (ACT == 2 ? gelu_tanh_fast_f(v[q8]) : v[q8]);
+                bf16x8_t hi, lo;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                  hi[q8] = (split_t)v[q8];
+                  lo[q8] = (split_t)(v[q8] - (float)hi[q8]);
+                }
+                split_t* rowp = p.C2 ? reinterpret_cast<split_t*>(p.C2 + (long long)z * p.sC + (long long)row * p.ldc2)
+                                     : reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
+                bf16x8_t* dh = reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8));
+                bf16x8_t* dl = reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8) + 32);
+                if (p.st_plain) {
+                  *dh = hi;
+                  *dl = lo;
+                } else {
+                  __builtin_nontemporal_store(hi, dh);
+                  __builtin_nontemporal_store(lo, dl);
+                }
+              }
+            }
+          }
+        };
         using I0 = std::integral_constant<int, 0>;
         using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>;
+        if (PIPE == 5 && !COH && p.out_split && p.split_pair == 2) {
+          if (p.act == 0) plain_rows8(I0{});
+          else if (p.act == 1) plain_rows8(I1{});
+          else plain_rows8(I2{});
+        } else
         if (p.out_split) {
           if (p.act == 0) plain_rows(I0{}, I1{});
           else if (p.act == 1) plain_rows(I1{}, I1{});
@@ -1317,7 +1384,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
             // (the counted waits below assume exactly ONE store per row and lane -- store_row's out16, or its 16-byte half of a lane pair's
             // split row -- and TWO for unpaired split rows, behind the DMA; the experiment variants that drop stores wait for everything)
             if (im == 0 || !full || exp != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (p.out_split && !p.split_pair) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+            else if (p.out_split && p.split_pair != 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NJ) : "memory");
             staged_pass1(stg, rslab, row_w + im * 32, g_lo[im], g_hi[im], bnd[im]);
             if constexpr (im + 1 < TM) {
