@@ -384,9 +384,10 @@ def measure_traffic(kernel, args):
         return None, "rocprofv3 not found"
     want = re.sub(r"\s+", "", kernel)
     out = {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    busy = None
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"):
         d = tempfile.mkdtemp(prefix="rgm_pmc_", dir="/tmp")
-        cmd = [exe, "--pmc", counter, "--kernel-trace", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
+        cmd = [exe, "--pmc"] + counter.split() + ["--kernel-trace", "-d", d, "--", sys.executable, os.path.abspath(__file__), "--traffic-child",
                "--workload", args.workload, "--precision", args.precision, "--steps", "3", "--warmup", "1"]
         if args.batch:
             cmd += ["--batch", str(args.batch)]
@@ -395,9 +396,23 @@ def measure_traffic(kernel, args):
                            timeout=420, check=True)
             dbs = glob.glob(os.path.join(d, "**", "*.db"), recursive=True)
             cur = sqlite3.connect(dbs[0]).cursor()
+            if " " in counter:      # matrix-pipe duty of the kernel: MFMA-busy cycles (summed over the 1024 SIMDs) over the cycles it had (summed over 8 XCDs)
+                both = {}
+                for cn in counter.split():
+                    v = [x for n, x in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (cn,)) if want in re.sub(r"\s+", "", n)]
+                    both[cn] = float(np.mean(v)) if v else None
+                shutil.rmtree(d, ignore_errors=True)
+                if both.get("SQ_VALU_MFMA_BUSY_CYCLES") and both.get("GRBM_GUI_ACTIVE"):
+                    busy = {"value": round(both["SQ_VALU_MFMA_BUSY_CYCLES"] / (both["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0), 4),
+                            "SQ_VALU_MFMA_BUSY_CYCLES": round(both["SQ_VALU_MFMA_BUSY_CYCLES"]), "GRBM_GUI_ACTIVE": round(both["GRBM_GUI_ACTIVE"]),
+                            "formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), in-situ launches averaged; 3 bf16 MFMAs per "
+                                       "fp32-equivalent product, so busy * 2500 TFLOP/s * sustained/nominal clock / 3 is the kernel's fp32-equivalent rate"}
+                continue
             rows = cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)).fetchall()
         except Exception as e:
             shutil.rmtree(d, ignore_errors=True)
+            if " " in counter:
+                continue                     # the duty counters are an extra: never lose the traffic figure over them
             return None, f"{counter} pass failed: {e!r}"
         shutil.rmtree(d, ignore_errors=True)
         vals = [v for n, v in rows if want in re.sub(r"\s+", "", n)]
@@ -409,7 +424,8 @@ def measure_traffic(kernel, args):
     detail = {"method": "rocprofv3 --pmc (separate FETCH_SIZE / WRITE_SIZE passes) over this workload, all in-situ launches of the kernel",
               "fetch_bytes_corrected": round(fetch), "write_bytes": round(write), "launches_sampled": out["FETCH_SIZE"][1],
               "fetch_kib_min_max": [round(out["FETCH_SIZE"][2]), round(out["FETCH_SIZE"][3])],
-              "formula": "2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)"}
+              "formula": "2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE tallies 128-B requests at 64 B)",
+              "mfma_busy": busy}
     return round(fetch + write), detail
 
 
@@ -472,13 +488,18 @@ def uint8_flip_record(device):
     lat = d.ddim_sample_loop(partial(model_fn, model=m, num_classes=3, class_cond=True, cfg=False, w=0.), (2, 4, 128, 16),
                              clip_denoised=False, model_kwargs={"y": torch.from_numpy(g["y"]).to(device)}, device=device, eta=1.0)
     err = float((lat.cpu().numpy().astype(np.float64) - g["latent"]).__abs__().max() / np.abs(g["latent"]).max())
-    u8 = decode_sample_for_midi(lat, embed_model=vae, scale_factor=1.2465, threshold=-0.95).cpu().numpy()
-    roll = _decode(lat, vae, scale_factor=1.2465).cpu().numpy().astype(np.float64).transpose(0, 2, 3, 1)
+    from rgm import native as R
+    u8 = decode_sample_for_midi(lat, embed_model=vae, scale_factor=1.2465, threshold=-0.95).cpu().numpy()     # exact-fp32 decode (default)
+    u8_loop = decode_sample_for_midi(lat, embed_model=vae, scale_factor=1.2465, threshold=-0.95, exact=False).cpu().numpy()
+    with R.gemm_precision_scope("fp32"):
+        roll = _decode(lat, vae, scale_factor=1.2465).cpu().numpy().astype(np.float64).transpose(0, 2, 3, 1)
     bad = u8 != g["u8"]
     qv = (roll[bad] + 1.0) * 63.5
     dist = np.minimum(np.abs(qv - np.round(qv)) / 63.5, np.abs(roll[bad] + 0.95)) if bad.any() else np.zeros(1)
     return {"mismatches": int(bad.sum()), "of": int(bad.size), "not_boundary_adjacent_1e-4": int((dist >= 1e-4).sum()),
-            "latent_rel_err": float(f"{err:.3g}")}
+            "latent_rel_err": float(f"{err:.3g}"),
+            "final_decode": "exact fp32 MFMA (midi_util.FINAL_DECODE_EXACT), the 50 steps in the headline arithmetic",
+            "mismatches_with_decode_in_loop_arithmetic": int((u8_loop != g["u8"]).sum())}
 
 
 def time_steps(work, steps, world, dist):
@@ -674,6 +695,9 @@ def main():
         except Exception as e:
             tb, detail = None, repr(e)
         if tb is not None:
+            mb = detail.pop("mfma_busy", None)
+            roof["mfma_busy"] = mb["value"] if mb else None          # matrix-pipe duty of the dominant kernel (rocprofv3 --pmc, in situ)
+            roof["mfma_busy_detail"] = mb
             roof["traffic"], roof["traffic_detail"] = tb, detail
             roof["traffic_over_algorithmic"] = round(tb / max(1.0, roof.get("algorithmic_bytes_per_launch", 0) or 1.0), 3) if roof.get("algorithmic_bytes_per_launch") else None
         else:
@@ -746,6 +770,12 @@ def main():
                        # whole-step FLOPs over ONE simulated rank's time would read as several times the chip's peak: no figure there
                        "algorithmic_tflops": None if args.simulate_ranks > 1 else round(work.flop_per_step * units / dt / 1e12, 2)},
         }
+        if roof is not None and res["config"]["algorithmic_tflops"] is not None:
+            # the number the north star's ">= 40 % on the DiT forward" is about: the step's algorithmic FLOPs over the timed
+            # region, against the peak of the arithmetic the step ran in (per GPU)
+            wpeak = F32_MFMA_PEAK_TFLOPS if args.precision == "fp32" else BF16X3_EQUIV_PEAK_TFLOPS
+            roof["whole_step_tflops"] = round(res["config"]["algorithmic_tflops"] / world, 2)
+            roof["whole_step_frac"] = round(res["config"]["algorithmic_tflops"] / world / wpeak, 4)
         if same_winners is not None:
             res["config"]["same_winners_on_every_rank"] = bool(same_winners)
         if "uint8_flips" in extras:

@@ -152,29 +152,11 @@ long long rgm_gn_fallback_tiles(int reset);
  * min_batch samples take it; 0 = never; -1 (default) = the batch sizes where a same-box sweep found it ahead (2, 5..9, 17..39, 57..).
  * *prev (optional) receives the previous setting. */
 int rgm_set_dit_halves(int min_batch, int* prev);
-/* Blocks of an eps-network forward (ref guided_diffusion/dit.py:332-336, 618-634) as ONE persistent launch (csrc/chain.hip): 256 resident
- * workgroups claim the forward's work items -- qkv tile, attention (sample, head), proj tile, LayerNorm rows, fc1 tile, fc2 K-slice tile,
- * reduce + next LayerNorm rows -- in a fixed order, each waiting on its sample's progress counter (samples are independent inside a
- * block), outputs handed over device-coherent inside the launch.  Forwards of at least min_batch samples that qualify (pre-split
- * arithmetic, 256 tokens per sample, head_dim 72) take it; 0 = never; -1 = the batch sizes where it measured ahead.  *prev (optional)
- * receives the previous setting.  rgm_dit_chain_launches: persistent launches so far (tests).  rgm_dit_chain_status: synchronises the
- * device; *status = 0 when every item of the handle's last persistent forward ran, k > 0 when item k - 1 gave up its bounded wait. */
 /* Short-sequence attention of the bf16x3 modes at head_dim 72 (T <= 128: C5's half windows; ref guided_diffusion/dit.py:263-288) with TWO
  * workgroups per CU (four waves and 79 KiB of LDS each) instead of the one-per-CU guard of round 3: the guard answered a hazard of the
  * interleaved Q prologue, which the two-phase prologue removed (profiles/r05_attn_hazard_two_phase_n96.txt).  1 = on,
  * 0 = guard (default).  Returns the previous setting. */
 int rgm_set_attn_pairs(int on);
-int rgm_set_dit_chain(int min_batch, int* prev);
-long long rgm_dit_chain_launches(void);
-int rgm_dit_chain_status(rgm_dit* h, int* status);
-/* debugging: `words` control words of the handle's persistent forward -- [0] items claimed, [1] error, [8 + g] finished items of sample g,
- * [8 + 4096 + 2 w] { item + 1, state } of workgroup w when RGM_CHAIN_TRACE=1 -- copied on a private stream without waiting for the launch */
-int rgm_dit_chain_peek(rgm_dit* h, unsigned* out, int words);
-/* measurement (RGM_CHAIN_TIMES=1 in the environment before the first forward): per work item of the handle's last persistent forward --
- * out_times (8 words) { claimed, dependencies met, finished, workgroup, wave 0 left the body, wave 0's stores retired, -, - } on the
- * 100 MHz clock, out_items (4 words) { op | sample << 16,
- * sub | K slice << 16, need, 0 } (op = 7 * block + phase); both optional; *n_items = number of items; synchronises the device */
-int rgm_dit_chain_times(rgm_dit* h, unsigned long long* out_times, unsigned* out_items, int cap_items, int* n_items);
 /* Deterministic split-K of the pre-split GEMM (csrc/gemm2.hip: K slices as a batch + one fixed-order reduce kernel, which for the fc2
  * of a DiT block also writes the next adaLN-LayerNorm): the scratch is caller memory like every other workspace,
  * rgm_gemm_scratch_bytes(M, N) bytes for GEMMs of up to M rows and N columns, 16-byte aligned, no initialisation.  tile 0 lets the

@@ -14,7 +14,6 @@
 //       probabilities cover in one k16 step (C/D layout of S^T: register r <-> key (r&3) + 8*(r>>2) + 4*half) are 16
 //       contiguous bytes: position 16*h2 + 8*half + j  <->  key (j&3) + 8*(2*h2 + (j>>2)) + 4*half.
 #include <stdlib.h>
-#include <stdlib.h>
 #include "common.h"
 #include "attention_x3_body.h"
 

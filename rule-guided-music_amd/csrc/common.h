@@ -327,32 +327,6 @@ double gemm2_prof_bytes(int kernel);
 int big_tiles_mode();   // rgm_set_big_tiles (gemm2.hip)
 int big_tiles_min();
 
-// ---------------------------------------------------------------------------------------------
-// chain.hip: the blocks of a DiT forward as one persistent launch.  An op = one phase of one block (its tensors); an item = one unit of an
-// op's work for one row group (= the 256 rows of a sample): packed as uint4 { op | group << 16, sub | z << 16, need, 0 } -- `need` = finished
-// items of the group's earlier phases the item waits for.
-// ---------------------------------------------------------------------------------------------
-enum { CHAIN_GEMM = 0, CHAIN_ATTN = 1, CHAIN_LN = 2, CHAIN_REDUCE_LN = 3, CHAIN_REDUCE = 4 };
-constexpr int CHAIN_CTL_HEAD = 0, CHAIN_CTL_ERROR = 1, CHAIN_CTL_PROGRESS = 8, CHAIN_MAX_GROUPS = 4096, CHAIN_MAX_CUS = 512;
-constexpr int CHAIN_CTL_TRACE = CHAIN_CTL_PROGRESS + CHAIN_MAX_GROUPS, CHAIN_CTL_WORDS = CHAIN_CTL_TRACE + 2 * CHAIN_MAX_CUS;
-struct ChainOp {
-  GemmParams g;            // CHAIN_GEMM: the GEMM (whole batch; item = 256x256 tile (group, sub), K slice z)
-                           // CHAIN_ATTN: A = qkv, C = attention output (split rows); item = (sample, head)
-                           // CHAIN_LN: A = x, ln_out / ln_shift / ln_scale / ln_mod_ld / ln_rows_per_batch / ln_eps, N = D, M = rows
-                           // CHAIN_REDUCE(_LN): the K-sliced GEMM's epilogue (bias, gate, res, C) + ln_* of the next LayerNorm
-  int kind = 0;
-  int tiles_n = 0;         // CHAIN_GEMM: column tiles
-  int rows_per_item = 0;   // row ops: rows of one item (4 waves share them)
-  int rows_per_group = 0;  // row ops: rows of a group (T)
-  const float* P = nullptr;   // CHAIN_REDUCE*: the K slices' partial sums [3][M][N]
-  const float* cos_tab = nullptr;
-  const float* sin_tab = nullptr;
-  int T = 0, heads = 0, rot_half = 0;
-};
-int dit_chain_launch(const ChainOp* d_ops, const uint4* d_items, int n_items, unsigned* d_ctl, int n_groups, hipStream_t s,
-                     unsigned long long* d_times = nullptr);
-long long dit_chain_launch_count();
-
 // elementwise / reductions (elementwise.hip)
 int layernorm_modulate_launch(const float* x, float* out, int M, int D, float eps, const float* weight,
                               const float* bias, const float* shift, const float* scale, int mod_ld,

@@ -65,16 +65,6 @@ static bool dit_halves_for(int N) {
 }
 // parts of a split forward (2 .. 4; read once: the workspace plan depends on it).  Three and four parts measured behind two at every batch
 // size but B = 112 (profiles/r04_halves_parts.txt): the parts of a forward re-read the weights and shrink the tile grids
-// The blocks of an eps-network forward as ONE persistent launch (chain.hip): g_dit_chain (rgm_set_dit_chain / RGM_DIT_CHAIN): 0 = never,
-// n > 0 = every forward of at least n samples that qualifies (pre-split arithmetic, T = 256 tokens -- one 256-row GEMM tile per sample --,
-// head_dim 72), -1 = the batch sizes where it measured ahead.
-static int g_dit_chain = getenv("RGM_DIT_CHAIN") ? atoi(getenv("RGM_DIT_CHAIN")) : 0;
-static int g_dit_chain_order = getenv("RGM_DIT_CHAIN_ORDER") ? atoi(getenv("RGM_DIT_CHAIN_ORDER")) : 0;   // item order (build_chain)
-static bool dit_chain_for(int N) {
-  if (g_dit_chain == 0) return false;
-  if (g_dit_chain > 0) return N >= g_dit_chain;
-  return N >= 12;
-}
 static const int g_dit_parts = getenv("RGM_DIT_PARTS") ? atoi(getenv("RGM_DIT_PARTS")) : 2;
 // where in block 0 of the first part the other parts are released: 0 = with it, 1 .. 5 = behind its qkv / attention / proj / second LayerNorm /
 // fc1 (the parts then run out of phase: one's short-K GEMMs beside the other's long-K ones).  Measured: no gain (profiles/r04_halves_stagger.txt)
@@ -105,15 +95,6 @@ struct rgm_dit {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t side_x[2] = {nullptr, nullptr};       // third / fourth part of a forward split into more than two parts (g_dit_parts)
   hipEvent_t ev_join_x[2] = {nullptr, nullptr};
-  // the persistent forward (chain.hip): op table (depends on the caller's workspace) and item list (depends on N) of the last shape seen
-  ChainOp* chain_ops = nullptr;
-  uint4* chain_items = nullptr;
-  unsigned* chain_ctl = nullptr;
-  size_t chain_ops_cap = 0, chain_items_cap = 0;
-  int chain_N = 0, chain_H = 0, chain_n_items = 0, chain_order = -1;
-  unsigned long long* chain_times = nullptr;   // RGM_CHAIN_TIMES=1: per-item time stamps of the last persistent forward
-  size_t chain_times_cap = 0;
-  const void* chain_ws = nullptr;
 
   const float* p(const std::string& k) const { return arena + slots.at(k).off; }
   float* sp(const Slot& sl) const { return (sl.in_t ? arena_t : arena) + sl.off; }
@@ -283,10 +264,6 @@ extern "C" void rgm_dit_destroy(rgm_dit* h) {
     if (h->side_x[i]) (void)hipStreamDestroy(h->side_x[i]);
     if (h->ev_join_x[i]) (void)hipEventDestroy(h->ev_join_x[i]);
   }
-  if (h->chain_ops) (void)hipFree(h->chain_ops);
-  if (h->chain_items) (void)hipFree(h->chain_items);
-  if (h->chain_ctl) (void)hipFree(h->chain_ctl);
-  if (h->chain_times) (void)hipFree(h->chain_times);
   delete h;
 }
 
@@ -468,114 +445,6 @@ int lin_gated(const float* A, int lda, const float* W, const float* bias, float*
   return gemm_launch(g, s);
 }
 
-// ---- the blocks as one persistent launch (chain.hip).  Seven ops per block; items in claim order (every dependency of an item is in
-// front of it): block-major, phase-major, sample-major.  need = the sample's finished items of all earlier phases.
-constexpr int CHAIN_S = 3;                 // K slices of fc2 (the slice count of the launch-per-GEMM forward at B = 16: same sums)
-constexpr int CHAIN_LN_ROWS = 16;          // rows of a LayerNorm / reduce item: 4 per wave
-bool chain_applies(const rgm_dit* h, const Plan& p) {
-  const rgm_dit_cfg& c = h->cfg;
-  return c.kind == 0 && dit_chain_for(p.N) && p.T == 256 && h->hd == 72 && c.hidden % 32 == 0 && ((4 * c.hidden / 32) % CHAIN_S) == 0 &&
-         p.N <= CHAIN_MAX_GROUPS && c.depth * 7 < 65536 &&
-         GEMM_SK_FLAG_BYTES + (size_t)CHAIN_S * p.M * c.hidden * sizeof(float) <= p.sk_bytes;
-}
-
-int run_chain(rgm_dit* h, const Plan& p, const void* ws, hipStream_t s) {
-  const rgm_dit_cfg& c = h->cfg;
-  const int D = c.hidden, T = p.T, L = (int)p.L, N = p.N, M = p.M;
-  const int tn_qkv = cdiv(3 * D, 256), tn_d = cdiv(D, 256), tn_fc1 = cdiv(4 * D, 256);
-  const int ln_items = cdiv(T, CHAIN_LN_ROWS);
-  const int per_phase[7] = {tn_qkv, c.heads, tn_d, ln_items, tn_fc1, tn_d * CHAIN_S, ln_items};
-  if (!h->chain_ctl) RGM_CHECK_HIP(hipMalloc(&h->chain_ctl, sizeof(unsigned) * CHAIN_CTL_WORDS));
-  // ---- ops: rebuilt when the shape or the caller's workspace changed; items: when the batch or the order changed
-  const bool new_items = h->chain_N != N || h->chain_order != g_dit_chain_order;
-  if (h->chain_N != N || h->chain_H != p.H || h->chain_ws != ws || new_items) {
-    std::vector<ChainOp> ops((size_t)c.depth * 7);
-    float* partial = reinterpret_cast<float*>(p.sk + GEMM_SK_FLAG_BYTES);
-    for (int i = 0; i < c.depth; ++i) {
-      const std::string b = "blocks." + std::to_string(i) + ".";
-      const float* m = p.mod + (size_t)i * 6 * D;
-      ChainOp* o = &ops[(size_t)i * 7];
-      auto gemm = [&](ChainOp& op, const float* A, int lda, const std::string& wkey, const float* bias, float* C, int Nn, int K) {
-        op.kind = CHAIN_GEMM;
-        op.tiles_n = cdiv(Nn, 256);
-        GemmParams& g = op.g;
-        g.A = A; g.lda = lda; g.B = h->p(wkey + ".S"); g.ldb = K; g.C = C; g.ldc = Nn; g.M = M; g.N = Nn; g.K = K; g.bias = bias;
-      };
-      gemm(o[0], p.xm, D, b + "attn.qkv.weight", h->p(b + "attn.qkv.bias"), p.qkv, 3 * D, D);
-      o[1].kind = CHAIN_ATTN;
-      o[1].g.A = p.qkv; o[1].g.C = p.ao; o[1].cos_tab = h->cos_tab; o[1].sin_tab = h->sin_tab; o[1].T = T; o[1].heads = c.heads; o[1].rot_half = h->rot_half;
-      gemm(o[2], p.ao, D, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), p.x, D, D);
-      o[2].g.gate = m + 2 * D; o[2].g.gate_ld = L; o[2].g.rows_per_gate = T; o[2].g.res = p.x; o[2].g.ldres = D;
-      o[3].kind = CHAIN_LN;
-      o[3].rows_per_item = CHAIN_LN_ROWS; o[3].rows_per_group = T;
-      o[3].g.A = p.x; o[3].g.M = M; o[3].g.N = D; o[3].g.ln_out = p.xm; o[3].g.ln_shift = m + 3 * D; o[3].g.ln_scale = m + 4 * D;
-      o[3].g.ln_mod_ld = L; o[3].g.ln_rows_per_batch = T; o[3].g.ln_eps = 1e-6f; o[3].g.ln_out_split = 1;
-      gemm(o[4], p.xm, D, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), p.hid, 4 * D, D);
-      o[4].g.act = 2; o[4].g.out_split = 1;
-      // fc2 as K slices (gemm2_launch's batch form): raw partial sums, no epilogue
-      gemm(o[5], p.hid, 4 * D, b + "mlp.fc2.weight", nullptr, partial, D, 4 * D / CHAIN_S);
-      o[5].g.ldb = 4 * D; o[5].g.batch = CHAIN_S; o[5].g.sA = o[5].g.K; o[5].g.sB = o[5].g.K; o[5].g.sC = (long long)M * D;
-      // the reduce holds whole rows: bias, gate, residual, and the NEXT block's first adaLN-LayerNorm (none behind the last block)
-      const bool last = i + 1 == c.depth;
-      o[6].kind = last ? CHAIN_REDUCE : CHAIN_REDUCE_LN;
-      o[6].rows_per_item = CHAIN_LN_ROWS; o[6].rows_per_group = T; o[6].P = partial;
-      GemmParams& r = o[6].g;
-      r.C = p.x; r.ldc = D; r.M = M; r.N = D; r.K = 4 * D; r.bias = h->p(b + "mlp.fc2.bias");
-      r.gate = m + 5 * D; r.gate_ld = L; r.rows_per_gate = T; r.res = p.x; r.ldres = D;
-      if (!last) {
-        r.ln_out = p.xm; r.ln_shift = m + 6 * D; r.ln_scale = m + 7 * D; r.ln_mod_ld = L; r.ln_rows_per_batch = T; r.ln_eps = 1e-6f; r.ln_out_split = 1;
-      }
-    }
-    if (ops.size() > h->chain_ops_cap) {
-      if (h->chain_ops) RGM_CHECK_HIP(hipFree(h->chain_ops));
-      RGM_CHECK_HIP(hipMalloc(&h->chain_ops, ops.size() * sizeof(ChainOp)));
-      h->chain_ops_cap = ops.size();
-    }
-    RGM_CHECK_HIP(hipStreamSynchronize(s));          // (a launch of an earlier shape may still read the table; shapes change rarely)
-    RGM_CHECK_HIP(hipMemcpy(h->chain_ops, ops.data(), ops.size() * sizeof(ChainOp), hipMemcpyHostToDevice));
-    // ---- items
-    if (new_items) {
-      std::vector<uint4> items;
-      items.reserve((size_t)c.depth * N * 96);
-      std::vector<unsigned> done(N, 0);
-      auto push = [&](int op, int grp, int sub, int z) {
-        items.push_back(make_uint4((unsigned)op | ((unsigned)grp << 16), (unsigned)sub | ((unsigned)z << 16), done[grp], 0u));
-      };
-      static const int stop_op = getenv("RGM_CHAIN_STOP_OP") ? atoi(getenv("RGM_CHAIN_STOP_OP")) : 1 << 30;   // debugging: only the first ops
-      for (int i = 0; i < c.depth; ++i) {
-        for (int ph = 0; ph < 7; ++ph) {
-          if (i * 7 + ph >= stop_op) break;
-          for (int g = 0; g < N; ++g) {
-            if (ph == 5) {
-              for (int z = 0; z < CHAIN_S; ++z)
-                for (int t = 0; t < tn_d; ++t) push(i * 7 + ph, g, t, z);
-            } else {
-              for (int t = 0; t < per_phase[ph]; ++t) push(i * 7 + ph, g, t, 0);
-            }
-          }
-          for (int g = 0; g < N; ++g) done[g] += (unsigned)per_phase[ph];
-        }
-      }
-      if (items.size() > h->chain_items_cap) {
-        if (h->chain_items) RGM_CHECK_HIP(hipFree(h->chain_items));
-        RGM_CHECK_HIP(hipMalloc(&h->chain_items, items.size() * sizeof(uint4)));
-        h->chain_items_cap = items.size();
-      }
-      RGM_CHECK_HIP(hipMemcpy(h->chain_items, items.data(), items.size() * sizeof(uint4), hipMemcpyHostToDevice));
-      h->chain_n_items = (int)items.size();
-      h->chain_order = g_dit_chain_order;
-    }
-    h->chain_N = N; h->chain_H = p.H; h->chain_ws = ws;
-  }
-  static const int want_times = getenv("RGM_CHAIN_TIMES") ? atoi(getenv("RGM_CHAIN_TIMES")) : 0;
-  if (want_times && h->chain_times_cap < (size_t)h->chain_n_items) {
-    if (h->chain_times) RGM_CHECK_HIP(hipFree(h->chain_times));
-    RGM_CHECK_HIP(hipMalloc(&h->chain_times, (size_t)h->chain_n_items * 8 * sizeof(unsigned long long)));
-    h->chain_times_cap = (size_t)h->chain_n_items;
-  }
-  return dit_chain_launch(h->chain_ops, h->chain_items, h->chain_n_items, h->chain_ctl, N, s, want_times ? h->chain_times : nullptr);
-}
-
 // embedders + blocks; leaves the residual stream in plan.x and SiLU(c) modulation in plan.mod
 int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, const int32_t* y, hipStream_t s) {
   const rgm_dit_cfg& c = h->cfg;
@@ -636,11 +505,6 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     Part parts[4];
     int nparts = 1;
     parts[0] = Part{0, p.N, s, p.sk, 0};
-    if (joined && chain_applies(h, p)) {
-      // block 0's first adaLN-LayerNorm by its own launch; everything up to the last block's fc2 reduce inside ONE persistent launch
-      RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, p.mod, p.mod + D, L, T, s, 1));
-      return run_chain(h, p, p.tok_in, s);
-    }
     const bool halves = c.kind == 0 && dit_halves_for(p.N) && joined;
     if (halves) {
       if (!h->side) {
@@ -1199,57 +1063,6 @@ extern "C" int rgm_set_dit_halves(int min_batch, int* prev) {
   RGM_REQUIRE(min_batch >= -1, "set_dit_halves: %d", min_batch);
   if (prev) *prev = g_dit_halves;
   g_dit_halves = min_batch;
-  return RGM_OK;
-}
-
-// Eps-network forwards of at least `min_batch` samples (that qualify: chain_applies) run their blocks as ONE persistent launch (chain.hip);
-// 0 = never, -1 = where it measured ahead.  *prev (optional) receives the previous setting.
-extern "C" int rgm_set_dit_chain(int min_batch, int* prev) {
-  RGM_REQUIRE(min_batch >= -1, "set_dit_chain: %d", min_batch);
-  if (prev) *prev = g_dit_chain;
-  g_dit_chain = min_batch;
-  return RGM_OK;
-}
-extern "C" long long rgm_dit_chain_launches(void) { return rgm::dit_chain_launch_count(); }
-// status of the handle's last persistent forward (synchronises the device): 0 = every item ran; k > 0 = item k - 1 gave up waiting for its
-// dependencies (bounded wait, chain.hip) and the forward's output is invalid
-extern "C" int rgm_dit_chain_status(rgm_dit* h, int* status) {
-  RGM_REQUIRE(h && status, "dit_chain_status: null argument");
-  *status = 0;
-  if (!h->chain_ctl) return RGM_OK;
-  unsigned v[2] = {0, 0};
-  RGM_CHECK_HIP(hipDeviceSynchronize());
-  RGM_CHECK_HIP(hipMemcpy(v, h->chain_ctl, sizeof(v), hipMemcpyDeviceToHost));
-  *status = (int)v[CHAIN_CTL_ERROR];
-  return RGM_OK;
-}
-
-// debugging: the control words of the handle's persistent forward (head, error, per-sample progress, per-workgroup trace with
-// RGM_CHAIN_TRACE=1) copied on a private stream WITHOUT waiting for the launch -- readable while it runs
-extern "C" int rgm_dit_chain_peek(rgm_dit* h, unsigned* out, int words) {
-  RGM_REQUIRE(h && out && words > 0 && words <= CHAIN_CTL_WORDS, "dit_chain_peek: bad arguments");
-  if (!h->chain_ctl) return RGM_ERR_STATE;
-  static hipStream_t ps = nullptr;
-  if (!ps) RGM_CHECK_HIP(hipStreamCreateWithFlags(&ps, hipStreamNonBlocking));
-  RGM_CHECK_HIP(hipMemcpyAsync(out, h->chain_ctl, sizeof(unsigned) * words, hipMemcpyDeviceToHost, ps));
-  RGM_CHECK_HIP(hipStreamSynchronize(ps));
-  return RGM_OK;
-}
-
-// debugging / measurement (RGM_CHAIN_TIMES=1): per item of the handle's last persistent forward { claimed, dependencies met, finished,
-// workgroup, wave 0 left the body, wave 0's stores retired, -, - } (8 words) on the 100 MHz clock, and the item list itself { op | group << 16, sub | z << 16, need, 0 }; synchronises the device.
-// *n_items receives the item count; out_times / out_items (optional) take 4 words per item.
-extern "C" int rgm_dit_chain_times(rgm_dit* h, unsigned long long* out_times, unsigned* out_items, int cap_items, int* n_items) {
-  RGM_REQUIRE(h && n_items, "dit_chain_times: null argument");
-  *n_items = h->chain_n_items;
-  if (!out_times && !out_items) return RGM_OK;
-  RGM_REQUIRE(cap_items >= h->chain_n_items, "dit_chain_times: room for %d items, %d needed", cap_items, h->chain_n_items);
-  RGM_CHECK_HIP(hipDeviceSynchronize());
-  if (out_times) {
-    RGM_REQUIRE(h->chain_times, "dit_chain_times: no time stamps (RGM_CHAIN_TIMES=1 before the first forward)");
-    RGM_CHECK_HIP(hipMemcpy(out_times, h->chain_times, (size_t)h->chain_n_items * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  }
-  if (out_items) RGM_CHECK_HIP(hipMemcpy(out_items, h->chain_items, (size_t)h->chain_n_items * sizeof(uint4), hipMemcpyDeviceToHost));
   return RGM_OK;
 }
 

@@ -675,8 +675,18 @@ class GaussianDiffusion:
         x0 = self._predict_xstart_from_eps(cand, t_rep, eps)
         if edit_kwargs is not None:                                          # only the editable rows are decoded and scored
             x0 = x0[:, :, int(edit_kwargs["l_start"]):int(edit_kwargs["l_end"]), :].contiguous()
+        # chord rules: the host analyser runs BESIDE the GPU -- the candidates are decoded in row chunks and each chunk's
+        # rolls go to the analyser's workers while the next chunk decodes; the answers are joined where the rule loop reaches the rule
+        seg_mode = dc_kwargs is not None and getattr(dc_kwargs, "base", 0) > 0
+        chord_fut = {}
+        async_names = [] if seg_mode else _async_chord_rules(model_kwargs["rule"])
         if embed_model is not None:
-            x0 = _decode(x0, embed_model, scale_factor=scale_factor)
+            if async_names and x0.shape[0] > 1:
+                x0, chord_fut = _decode_scoring_chords(x0, embed_model, scale_factor, async_names)
+            else:
+                x0 = _decode(x0, embed_model, scale_factor=scale_factor)
+        if async_names and not chord_fut and x0.is_cuda:
+            chord_fut = {name: [_chords_async(name, x0.clone())] for name in async_names}
         def rebuild(max_ind, seg_rows=None):
             """Winners regenerated from the shared noise stream on the device: mean + g * noise[max_ind[seg, b], b] -- no host
             read of max_ind.  max_ind (B,) or (S,B) int64; seg_rows = latent rows per segment (None: one winner per sample)."""
@@ -700,7 +710,7 @@ class GaussianDiffusion:
             return self._scg_select_segments(cand, x0, mean_pred, model_kwargs, scg_kwargs, dc_kwargs, nl, n, sharded, rebuild)
         total, each = None, {}
         for name, target in model_kwargs["rule"].items():
-            gen = _extract_rule(name, x0)
+            gen = _join_chords(chord_fut[name], dev) if name in chord_fut else _extract_rule(name, x0)
             lp = -LOSS_DICT[name](gen, target.repeat(nl, 1))
             each[name] = lp
             w = scg_kwargs.get(name, 1.)
@@ -760,11 +770,14 @@ class GaussianDiffusion:
         rule_base = dc_kwargs.base // 16
         bounds = [(s0, min(s0 + seg, total_len)) for s0 in range(0, total_len, seg)]
         totals = []
+        # chord rules: every segment's rolls go to the host analyser first; the device rules of all segments are enqueued while it works
+        async_names = _async_chord_rules(model_kwargs["rule"]) if x0_dec.is_cuda else []
+        seg_fut = [{name: [_chords_async(name, x0_dec[:, :, :, s0:s1].contiguous())] for name in async_names} for s0, s1 in bounds]
         for i, (s0, s1) in enumerate(bounds):
             cur = x0_dec[:, :, :, s0:s1].contiguous()
             total = None
             for name, target in model_kwargs["rule"].items():
-                gen = _extract_rule(name, cur)
+                gen = _join_chords(seg_fut[i][name], dev) if name in seg_fut[i] else _extract_rule(name, cur)
                 if name == "note_density":
                     half = target.shape[-1] // 2
                     sl = slice(i * rule_base, min((i + 1) * rule_base, half))
@@ -1075,6 +1088,72 @@ def _extract_rule(rule_name, pred_xstart):
             out = out.unsqueeze(0)
         return out.to(pred_xstart.device)
     return FUNC_DICT[rule_name](pred_xstart)
+
+
+# rules whose in-place writes into the roll (piano_like mask, < -0.95 background snap) are a subset of the chord preamble's own: a chord
+# rule BEHIND them in the rule dict reads the same integer roll whether or not they ran first, so its analysis may start ahead of them
+_CHORD_NEUTRAL_RULES = ("pitch_hist", "note_density", "note_density_hr_1", "note_density_hr_2", "note_density_class", "note_density_pixel")
+CHORD_ASYNC = __import__("os").environ.get("RGM_CHORD_ASYNC", "1") != "0"       # 0: the reference's blocking order (A/B runs, tests)
+CHORD_CHUNKS = int(__import__("os").environ.get("RGM_CHORD_CHUNKS", "4"))      # decode chunks of a search step when a chord rule is scored
+
+
+def _chord_call(rule_name):
+    """-> keyword arguments of music_rules.get_chords behind FUNC_DICT[rule_name], or None when the entry is not the built-in analyser
+    dispatch (a user's own function under a chord name runs through the blocking path)."""
+    from functools import partial
+    from music_rule_guidance import music_rules
+    fn = FUNC_DICT.get(rule_name)
+    if fn is music_rules.get_chords:
+        return {}
+    if isinstance(fn, partial) and fn.func is music_rules.get_chords and not fn.args:
+        return dict(fn.keywords)
+    return None
+
+
+def _async_chord_rules(rules):
+    """The chord rules of a search step that may be analysed beside the GPU: built-in dispatch, an analyser registered, and only rules with
+    chord-neutral writes in front of them in the dict (the reference evaluates the rules in dict order on ONE roll they write into)."""
+    from music_rule_guidance import music_rules
+    if not CHORD_ASYNC or music_rules._CHORD_BACKEND is None:
+        return []
+    names, neutral = [], True
+    for name in rules:
+        if "chord" in name:
+            if neutral and _chord_call(name) is not None:
+                names.append(name)
+        elif name not in _CHORD_NEUTRAL_RULES or FUNC_DICT.get(name) is None:
+            neutral = False
+    return names
+
+
+def _chords_async(rule_name, roll_copy):
+    """roll_copy: a device roll the preamble may write into (the reference analyses .cpu() copies: the caller's roll stays untouched)."""
+    from music_rule_guidance import music_rules
+    return music_rules.get_chords_async(roll_copy, **_chord_call(rule_name))
+
+
+def _join_chords(futures, device):
+    """the chunks' answers in row order, as _extract_rule returns them: (rows, windows) on `device`"""
+    outs = []
+    for f in futures:
+        o = f.result()
+        outs.append(o.unsqueeze(0) if o.dim() == 1 else o)
+    return th.cat(outs, dim=0).to(device)
+
+
+def _decode_scoring_chords(x0_lat, embed_model, scale_factor, chord_names):
+    """_decode of a candidate batch in CHORD_CHUNKS row chunks; every chunk's rolls are handed to the chord analyser (device preamble on
+    a copy, uint8 rolls to pinned memory on a side stream, worker pool) as soon as its decode is enqueued, so the host analyses chunk i
+    while the GPU decodes chunk i + 1.  -> (the whole roll, {rule: [ChordFuture per chunk]})."""
+    rows = x0_lat.shape[0]
+    per = -(-rows // max(1, min(CHORD_CHUNKS, rows)))
+    rolls, fut = [], {name: [] for name in chord_names}
+    for r0 in range(0, rows, per):
+        roll = _decode(x0_lat[r0:r0 + per].contiguous(), embed_model, scale_factor=scale_factor)
+        for name in chord_names:
+            fut[name].append(_chords_async(name, roll.clone()))
+        rolls.append(roll)
+    return (rolls[0] if len(rolls) == 1 else th.cat(rolls, dim=0)), fut
 
 
 def _encode(pred_xstart, embed_model, scale_factor=1.):

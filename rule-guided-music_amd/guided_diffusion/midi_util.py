@@ -29,15 +29,27 @@ def load_config(filename):
         return dict_to_obj(yaml.safe_load(f))
 
 
+# The final decode is the one place where a float becomes an INTEGER (truncating cast + background threshold): a roll value within the
+# decoder's arithmetic error of a boundary flips.  It runs once per sample, outside the step loop, so it always takes the exact-fp32
+# MFMA decoder (v_mfma_f32_32x32x2_f32: the reference's own arithmetic up to summation order), whatever the sampling loop ran in --
+# measured on the reference's 50-step golden: 250 -> the fp32 level of mismatching entries of 786 432 (docs/rounds/r06.md).
+# RGM_FINAL_DECODE_EXACT=0 / exact=False: the process-wide arithmetic instead (A/B runs).
+FINAL_DECODE_EXACT = os.environ.get("RGM_FINAL_DECODE_EXACT", "1") != "0"
+
+
 @torch.no_grad()
-def decode_sample_for_midi(sample, embed_model=None, scale_factor=1., threshold=-0.95):
+def decode_sample_for_midi(sample, embed_model=None, scale_factor=1., threshold=-0.95, exact=None):
     """Latent batch -> uint8 piano roll (B, 128, T, 3) in [0, 127].
 
     With the native AutoencoderKL the whole chain (1/scale_factor, square gather, decoder, background
     threshold, (x+1)*63.5 clamp, truncating cast, layout change) is one decode call; other embed models are
-    driven through tensor views and only the final quantisation runs in the HIP kernel."""
+    driven through tensor views and only the final quantisation runs in the HIP kernel.
+    exact (default FINAL_DECODE_EXACT = True): run this decode in exact-fp32 arithmetic (reference midi_util.py:42-64 is fp32)."""
+    if exact is None:
+        exact = FINAL_DECODE_EXACT
     if embed_model is not None and hasattr(embed_model, "decode_latent") and sample.shape[-2] >= sample.shape[-1]:
-        return embed_model.decode_latent(sample, scale_factor, want_u8=True, threshold=threshold, want_float=False)
+        with _rgm.gemm_precision_scope("fp32" if exact else None):
+            return embed_model.decode_latent(sample, scale_factor, want_u8=True, threshold=threshold, want_float=False)
     sample = sample / scale_factor
     if embed_model is not None:
         h, w = sample.shape[-2:]

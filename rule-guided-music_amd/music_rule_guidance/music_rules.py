@@ -138,32 +138,102 @@ def _chord_job(args):
     return fn(roll, **kw)
 
 
-def get_chords(piano_roll_batch, given_key=None, fs=100, window_size=1.28, return_key=False):
-    """FUNC_DICT['chord_progression']: (N,C,128,T) roll -> chords (N, windows) LongTensor [(windows,) when N == 1]
-    (+ keys, correlation coefficients with return_key) -- reference music_rules.py:97-130."""
+def _chord_pool():
+    """the persistent spawn-context worker pool (None: evaluate in the calling thread)"""
     global _CHORD_POOL
-    if _CHORD_BACKEND is None:
-        raise ImportError("chord rules need a host analyser (the reference's is music21-based and not vendored): "
-                          "music_rule_guidance.music_rules.register_chord_backend(piano_roll_to_chords)")
-    rolls = chord_quantise(piano_roll_batch).cpu().numpy().astype(np.intc)
-    kw = dict(given_key=given_key, fs=fs, window_size=window_size, return_key=return_key)
-    jobs = [(_CHORD_BACKEND, rolls[i], kw) for i in range(rolls.shape[0])]
+    if _CHORD_WORKERS <= 1:
+        return None
+    if _CHORD_POOL is None:
+        import multiprocessing
+        _CHORD_POOL = multiprocessing.get_context("spawn").Pool(_CHORD_WORKERS)
+    return _CHORD_POOL
+
+
+def _run_chord_jobs(jobs):
     outs = None
     if _CHORD_WORKERS > 1 and len(jobs) > 1:
         try:
-            if _CHORD_POOL is None:
-                import multiprocessing
-                _CHORD_POOL = multiprocessing.get_context("spawn").Pool(_CHORD_WORKERS)
-            outs = _CHORD_POOL.map(_chord_job, jobs)
+            outs = _chord_pool().map(_chord_job, jobs)
         except (AttributeError, TypeError, ImportError) as e:      # an unpicklable backend (lambda / closure): run it here
             if "pickle" not in str(e).lower() and "local object" not in str(e).lower():
                 raise
             outs = None
     if outs is None:
         outs = [_chord_job(j) for j in jobs]
+    return outs
+
+
+def _pack_chords(outs, return_key):
     chords = torch.stack([torch.as_tensor(o["chords"], dtype=torch.long) for o in outs], dim=0)
     if chords.shape[0] == 1:
         chords = chords.squeeze(0)
     if return_key:
         return chords, [o["key"] for o in outs], [o["correlationCoefficient"] for o in outs]
     return chords
+
+
+# ---- the analyser OVERLAPPED with the GPU (SURVEY 8 f3).  The reference blocks the step on pool.map (gaussian_diffusion.py:1363-1375);
+# here get_chords_async enqueues the device preamble on the caller's stream, copies the uint8 rolls to pinned host memory on a side
+# stream and hands the analysis to a driver thread (which waits for THAT copy only, then feeds the worker pool) -- the caller goes on
+# enqueueing GPU work (the next chunk's decode, the other rules) and joins the answer where it needs it (ChordFuture.result()).
+_CHORD_SIDE = {}            # device index -> side stream of the D2H copies
+_CHORD_DRIVER = None        # one driver thread: futures complete in submission order
+
+
+class ChordFuture:
+    """result() -> what get_chords returns for the same roll (chords [, keys, correlation coefficients])."""
+
+    def __init__(self, fut, return_key):
+        self._fut, self._return_key = fut, return_key
+
+    def done(self):
+        return self._fut.done()
+
+    def result(self):
+        return _pack_chords(self._fut.result(), self._return_key)
+
+
+def get_chords_async(piano_roll_batch, given_key=None, fs=100, window_size=1.28, return_key=False):
+    """get_chords without the wait: (N,C,128,T) DEVICE roll -> ChordFuture.  The roll is read (and, like get_chords, written: mask +
+    background snap) by a kernel on the current stream; the caller may go on using it on that stream at once."""
+    global _CHORD_DRIVER
+    if _CHORD_BACKEND is None:
+        raise ImportError("chord rules need a host analyser (the reference's is music21-based and not vendored): "
+                          "music_rule_guidance.music_rules.register_chord_backend(piano_roll_to_chords)")
+    _rgm.require_cuda(piano_roll_batch)
+    q = chord_quantise(piano_roll_batch)                                  # (N,128,T) uint8, current stream
+    dev = q.device
+    cur = torch.cuda.current_stream(dev)
+    side = _CHORD_SIDE.get(dev.index)
+    if side is None:
+        side = _CHORD_SIDE[dev.index] = torch.cuda.Stream(device=dev)
+    host = torch.empty(q.shape, dtype=torch.uint8, pin_memory=True)
+    ready = torch.cuda.Event()
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        host.copy_(q, non_blocking=True)
+        ready.record(side)
+    q.record_stream(side)                                                 # the allocator must not hand q out again before the copy ran
+    kw = dict(given_key=given_key, fs=fs, window_size=window_size, return_key=return_key)
+    fn = _CHORD_BACKEND
+
+    def work():
+        ready.synchronize()                                               # this copy only -- not the device
+        rolls = host.numpy().astype(np.intc)
+        return _run_chord_jobs([(fn, rolls[i], kw) for i in range(rolls.shape[0])])
+    if _CHORD_DRIVER is None:
+        from concurrent.futures import ThreadPoolExecutor
+        _CHORD_DRIVER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="rgm-chord")
+    return ChordFuture(_CHORD_DRIVER.submit(work), return_key)
+
+
+def get_chords(piano_roll_batch, given_key=None, fs=100, window_size=1.28, return_key=False):
+    """FUNC_DICT['chord_progression']: (N,C,128,T) roll -> chords (N, windows) LongTensor [(windows,) when N == 1]
+    (+ keys, correlation coefficients with return_key) -- reference music_rules.py:97-130.  Blocking, like the reference; the
+    samplers' search step uses get_chords_async."""
+    if _CHORD_BACKEND is None:
+        raise ImportError("chord rules need a host analyser (the reference's is music21-based and not vendored): "
+                          "music_rule_guidance.music_rules.register_chord_backend(piano_roll_to_chords)")
+    rolls = chord_quantise(piano_roll_batch).cpu().numpy().astype(np.intc)
+    kw = dict(given_key=given_key, fs=fs, window_size=window_size, return_key=return_key)
+    return _pack_chords(_run_chord_jobs([(_CHORD_BACKEND, rolls[i], kw) for i in range(rolls.shape[0])]), return_key)

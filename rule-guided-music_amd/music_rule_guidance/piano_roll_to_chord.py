@@ -4,10 +4,12 @@ Reference: music_rule_guidance/piano_roll_to_chord.py:167-275 (piano_roll_to_pre
 events a generated (3,128,T) roll [velocity | onset | pedal] turns into) and guided_diffusion/midi_util.py:67-93
 (save_piano_roll_midi).  The event extraction is restated here and pinned to the reference's output
 (tests/golden/midi_events.npz).  The container classes mirror the pretty_midi attributes the reference touches
-(`.instruments[0].notes`, `.control_changes`, `.write(path)`), the byte layout of the file follows the SMF 1.0
-specification (format 1, 220 ticks per quarter note at 120 bpm -- pretty_midi's defaults); it is NOT claimed to be
-byte-identical to pretty_midi's writer (parity unpinned: the library is absent).  Chord analysis (music21) stays a host plug-in:
-music_rules.register_chord_backend.  Host-side I/O only -- nothing here is on the sampling hot path.
+(`.instruments[0].notes`, `.control_changes`, `.write(path)`).  The writer's whole MESSAGE STREAM -- tick conversion, the order of
+events at equal ticks, channels, track layout, delta ticks -- is pinned to what the reference's vendored pretty_midi fork hands to
+mido (tests/golden/midi_writer.npz, tests/test_host_logic.py); only mido's byte serialisation of those messages is this module's own,
+following the SMF 1.0 specification (format 1, 220 ticks per quarter note at 120 bpm -- pretty_midi's defaults).  Chord analysis
+(music21) stays a host plug-in: music_rules.register_chord_backend (blocking get_chords, or get_chords_async beside the GPU in the
+samplers' search step).  Host-side I/O only -- nothing here is on the sampling hot path.
 """
 import math
 import struct

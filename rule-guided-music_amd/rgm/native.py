@@ -82,12 +82,7 @@ def _load():
         "rgm_set_fuse_reduce_ln": (C.c_int, [i32]),
         "rgm_set_adaln_overlap": (C.c_int, [i32]),
         "rgm_set_dit_halves": (C.c_int, [i32, vp]),
-        "rgm_set_dit_chain": (C.c_int, [i32, vp]),
         "rgm_set_attn_pairs": (C.c_int, [i32]),
-        "rgm_dit_chain_launches": (C.c_longlong, []),
-        "rgm_dit_chain_status": (C.c_int, [vp, vp]),
-        "rgm_dit_chain_peek": (C.c_int, [vp, vp, i32]),
-        "rgm_dit_chain_times": (C.c_int, [vp, vp, vp, i32, vp]),
         "rgm_set_gn_fuse": (C.c_int, [i32, vp]),
         "rgm_gn_fused_launches": (C.c_longlong, []),
         "rgm_gn_fallback_tiles": (C.c_longlong, [i32]),
@@ -134,6 +129,28 @@ def set_gemm_precision(name):
     hi + lo into two bf16 while staged, 3 bf16 MFMAs per product, ~2^-16 relative per product) or 'bf16x3_presplit' (same numerics,
     operands split once by their producer, LDS-DMA staging; the default of bench.py and the CLIs)."""
     check(lib.rgm_set_gemm_precision(PRECISIONS[name]))
+
+
+class gemm_precision_scope:
+    """`with gemm_precision_scope("fp32"): ...` -- the arithmetic for the launches enqueued inside the block, the previous one
+    restored behind it.  The precision is read on the host when a launch is enqueued (never by a kernel in flight), so the scope is
+    exact for a rank's single sampling thread.  Used for the ONE decode per run whose output is an integer piano roll
+    (guided_diffusion/midi_util.decode_sample_for_midi, reference midi_util.py:42-64): the exact-fp32 decoder there, bf16x3 everywhere
+    else (SCG's inner decodes included)."""
+
+    def __init__(self, name):
+        self.name = name
+        self.prev = None
+
+    def __enter__(self):
+        self.prev = int(lib.rgm_get_gemm_precision())
+        if self.name is not None:
+            check(lib.rgm_set_gemm_precision(PRECISIONS[self.name]))
+        return self
+
+    def __exit__(self, *exc):
+        check(lib.rgm_set_gemm_precision(self.prev))
+        return False
 
 
 def check(status):

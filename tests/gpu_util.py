@@ -91,3 +91,14 @@ def split_torch_dtype():
     """torch dtype of the hi / lo halves of a split row: bfloat16 in the default build, float16 in the RGM_SPLIT_F16 build"""
     from rgm import native as R
     return torch.float16 if int(R.lib.rgm_split_dtype()) == 1 else torch.bfloat16
+
+
+SLOW_CHORD_SLEEP = 0.0      # seconds per excerpt of slow_chord_backend (set by the test that uses it; in-process backend only)
+
+
+def slow_chord_backend(pr, given_key=None, return_key=False, fs=100., window_size=1.28):
+    """fake_chord_backend that takes SLOW_CHORD_SLEEP seconds per excerpt, like a real symbolic analyser would (the sleep releases the GIL,
+    as the reference's worker processes leave the sampling process free)."""
+    import time
+    time.sleep(SLOW_CHORD_SLEEP)
+    return fake_chord_backend(pr, given_key=given_key, return_key=return_key, fs=fs, window_size=window_size)

@@ -53,3 +53,19 @@ def test_c5_guided_step_against_the_reference(precision):
     assert np.array_equal(d.last_scg["max_ind"].cpu().numpy(), g["c5.max_ind"])
     assert rel(out["sample"].cpu().numpy(), g["c5.sample"]) < (5e-5 if precision == "fp32" else 2e-4)
     assert rel(out["pred_xstart"].cpu().numpy(), g["c5.pred_xstart"]) < (5e-5 if precision == "fp32" else 3e-4)
+
+
+def test_kernels_with_the_load_wait_use_pattern_are_bit_stable():
+    """tools/isa_lint.py finds the instruction pattern of the round-4 attention hazard in most kernels -- it is the plain way to
+    consume a vector load.  Those that share their CUs with lock-step twins of themselves are soaked here: 12 runs per case on fixed
+    inputs (tools/hazard_soak.py; the round's record holds 100), every run bit-identical to the first."""
+    import os, sys
+    from rgm import native as R
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import hazard_soak
+    prev = R.lib.rgm_get_gemm_precision()
+    lines = []
+    try:
+        assert hazard_soak.soak(12, log=lines.append) == 0, lines
+    finally:
+        R.lib.rgm_set_gemm_precision(prev)

@@ -1,0 +1,110 @@
+"""-m gpu: round-6 additions -- the chord analyser beside the GPU (reference guided_diffusion/gaussian_diffusion.py:1363-1375
+blocks the step on pool.map) and the exact-fp32 final decode (reference guided_diffusion/midi_util.py:42-64)."""
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from test_gpu_sampler import SM, _diffusion, _dit, _model_fn, _vae
+
+pytestmark = pytest.mark.gpu
+F32 = np.float32
+
+
+def _scg_step(rules, weights, n=16, seg=False):
+    """one SCG p_sample step of the small eps-network + the real decoder on the 'steps' golden's inputs (B = 2); -> closure(d) -> results"""
+    from gpu_util import dev
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    g = load_golden("steps")
+    m, vae = _dit(SM, 11), _vae(2)
+    guid = SimpleNamespace(schedule=True, t_start=750, t_end=0, interval=1, method="no_guidance")
+    scg = dict(num_samples=n, **weights)
+
+    def run():
+        d = _diffusion("")
+        d.t_end = 0
+        d.noise = PhiloxNoise(seed=99)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = d.p_sample(_model_fn(m), dev(g["x"]), dev(g["scg.t"]), clip_denoised=False, model_kwargs={"y": dev(g["y"]), "rule": rules},
+                         embed_model=vae, scale_factor=1.2465, guidance_kwargs=guid, scg_kwargs=scg)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out["sample"].clone(), d.last_scg["total_log_prob"].clone(), d.last_scg["max_ind"].clone()
+    return run
+
+
+def test_chord_analyser_runs_beside_the_gpu(monkeypatch):
+    """f3: a search step with a chord rule -- the candidates decode in chunks, every chunk's uint8 rolls go to the host analyser while the
+    next chunk decodes (music_rules.get_chords_async), the answers are joined in the rule loop.  Same table, winners and sample as the
+    reference's blocking order; with an analyser as slow as the GPU's share of the step, the step takes clearly less than their sum."""
+    import gpu_util
+    from gpu_util import dev
+    import guided_diffusion.gaussian_diffusion as gd
+    from music_rule_guidance import music_rules
+    g = load_golden("steps")
+    B, n = 2, 16
+    rules = {"pitch_hist": dev(g["scg.target.pitch_hist"]), "note_density": dev(g["scg.target.note_density"]),
+             "chord_progression": torch.tensor([[1, 3, 5, 0, 2, 4, 6, 1]] * B, dtype=torch.long, device="cuda")}
+    run = _scg_step(rules, {"pitch_hist": 40., "note_density": 1., "chord_progression": 2.})
+    no_chord = _scg_step({k: v for k, v in rules.items() if "chord" not in k}, {"pitch_hist": 40., "note_density": 1.})
+    try:
+        music_rules.register_chord_backend(gpu_util.slow_chord_backend, workers=0)
+        monkeypatch.setattr(gpu_util, "SLOW_CHORD_SLEEP", 0.0)
+        for _ in range(2):
+            no_chord()
+        t_dev = min(no_chord()[0] for _ in range(3))                     # the GPU's share: decode of 32 candidates + the device rules
+        sleep = max(t_dev, 0.02) / (n * B)
+        monkeypatch.setattr(gpu_util, "SLOW_CHORD_SLEEP", sleep)            # host share == device share
+        monkeypatch.setattr(gd, "CHORD_ASYNC", False)
+        assert gd._async_chord_rules(rules) == []
+        run()
+        sync = [run() for _ in range(3)]
+        monkeypatch.setattr(gd, "CHORD_ASYNC", True)
+        assert gd._async_chord_rules(rules) == ["chord_progression"]
+        run()
+        asyn = [run() for _ in range(3)]
+    finally:
+        music_rules.register_chord_backend(None)
+    t_sync, t_async = min(r[0] for r in sync), min(r[0] for r in asyn)
+    print(f"[chord overlap] device share {1e3 * t_dev:.1f} ms, analyser {1e3 * sleep * n * B:.1f} ms: blocking {1e3 * t_sync:.1f} ms, beside the GPU {1e3 * t_async:.1f} ms")
+    for a, b in zip(sync[0][1:], asyn[0][1:]):
+        assert torch.equal(a, b)                                          # sample, (n, B) table, winners: identical
+    assert t_sync > 1.7 * t_dev                                           # the blocking order pays device + host
+    assert t_async < 0.8 * t_sync, (t_dev, t_sync, t_async)                # beside the GPU: ~ one chunk's decode + the analyser
+    # the order rule: a user's rule in FRONT of the chord rule may write anything into the roll -> the reference's blocking order is kept
+    from music_rule_guidance.rule_maps import FUNC_DICT
+    try:
+        music_rules.register_chord_backend(gpu_util.fake_chord_backend, workers=0)
+        FUNC_DICT["my_rule"] = lambda roll: roll[:, 0].mean(dim=(1, 2)).unsqueeze(-1)
+        assert gd._async_chord_rules({"my_rule": None, "chord_progression": None}) == []
+        assert gd._async_chord_rules({"chord_progression": None, "my_rule": None}) == ["chord_progression"]
+        assert gd._async_chord_rules({"chord_progression_pixel": None}) == ["chord_progression_pixel"]
+    finally:
+        FUNC_DICT.pop("my_rule", None)
+        music_rules.register_chord_backend(None)
+
+
+def test_chord_futures_return_what_get_chords_returns():
+    from conftest import chord_test_roll
+    from gpu_util import dev, fake_chord_backend
+    from music_rule_guidance import music_rules
+    g = load_golden("chord_quantise")
+    try:
+        for workers in (0, 2):
+            music_rules.register_chord_backend(fake_chord_backend, workers=workers)
+            roll = dev(chord_test_roll(int(g["seed"])))
+            futs = [music_rules.get_chords_async(roll.clone(), return_key=True), music_rules.get_chords_async(roll[:1].clone())]
+            want = music_rules.get_chords(roll.clone(), return_key=True)
+            got = futs[0].result()
+            assert torch.equal(got[0], want[0]) and got[1] == want[1] and got[2] == want[2]
+            assert futs[1].result().shape == (2,)                        # N == 1 squeezes, like get_chords
+            # the preamble's writes land in the roll it was given, like get_chords'
+            a, b = dev(chord_test_roll(int(g["seed"]))), dev(chord_test_roll(int(g["seed"])))
+            music_rules.get_chords_async(a).result()
+            music_rules.get_chords(b)
+            assert torch.equal(a, b)
+    finally:
+        music_rules.register_chord_backend(None)

@@ -19,7 +19,6 @@ tools/prof_bench.sh ${R}_c2_b8 --no-extras --batch 8 --steps 20 --warmup 5 > /de
 python tools/batch_sweep.py > gpurun_out/${R}_batch_sweep.txt 2>&1
 python tools/cls_time.py 1 4 8 16 32 > gpurun_out/${R}_cls_time.txt 2>&1
 python tools/hazard_soak.py 100 > gpurun_out/${R}_hazard_soak.txt 2>&1
-RGM_CHAIN_TIMES=1 python tools/chain_spans.py 16 28 > gpurun_out/${R}_chain_spans.txt 2>&1
 for f in gpurun_out/${R}_*_bench_under_rocprof.json gpurun_out/${R}_bench_default_n1.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:

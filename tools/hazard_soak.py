@@ -3,7 +3,7 @@ its s_waitcnt vmcnt(0): DESIGN 4h): the kernels that carry it AND share their CU
 K-slice reduce, the 128-row GEMMs, the classifier chain, GroupNorm passes, the sampler's element-wise kernels -- are run N times on the same
 inputs; every run must equal the first bit for bit.  The attention instance of the hazard showed in ~1 workgroup of 4000; one XL-28 forward
 at B = 16 alone launches ~10^5 workgroups of these kernels.
-    python tools/hazard_soak.py [N]        (default 100; tests/test_gpu_chain.py runs a short one)"""
+    python tools/hazard_soak.py [N]        (default 100; tests/test_gpu_round5.py runs a short one)"""
 import os
 import sys
 
