@@ -86,6 +86,11 @@ int rgm_gemm(const float* A, int lda, const float* B, int ldb, float* C, int ldc
 int rgm_layernorm_modulate(const float* x, float* out, int M, int D, float eps, const float* weight,
                            const float* bias, const float* shift, const float* scale, int mod_ld,
                            int rows_per_batch, void* stream);
+/* adaLN conditioning of a whole forward in one weight-streaming pass (csrc/adaln_stream.hip): mod[N, L] = cs[N, D] . W^T[L, D] + bias[L],
+ * cs = SiLU(c) -- the Linear of every block's adaLN_modulation (ref guided_diffusion/dit.py:318-322, 333) and of the final layer (:366-369,
+ * 374), whose weights the DiT handles keep contiguous.  Exact fp32 (v_mfma_f32_16x16x4_f32); one pass over the weights per 32 rows.  N <= 256, D in {384, 768, 1152}, L % 16 == 0,
+ * 16-byte aligned pointers; RGM_ERR_INVALID for any other shape (rgm_dit_forward then runs its tiled GEMM instead). */
+int rgm_adaln_stream(const float* cs, const float* W, const float* bias, float* mod, int N, int D, int L, void* stream);
 /* RotaryAttention core (dit.py:263-277): qkv (N*T, 3*heads*hd) -> o (N*T, heads*hd); rotary on the first
  * 2*rot_half channels of q,k with cos/sin tables (T, rot_half); softmax scale hd^-0.5. hd in {64,72}. */
 int rgm_rotary_attention(const float* qkv, float* o, const float* cos_tab, const float* sin_tab,

@@ -14,6 +14,7 @@
 //   * dkv kernel: Q (pre-scaled), dO, lse, D resident in LDS; a wave owns 32 keys (columns of S), streams query
 //                 tiles; P and dS registers feed dV^T = dO^T P and dK^T = Q^T dS directly.
 // No atomics: every output element is owned by exactly one wave, so the result is deterministic.
+#include <stdlib.h>
 #include "common.h"
 
 namespace rgm {
@@ -26,6 +27,46 @@ __device__ __forceinline__ float exp_le0(float x) {
   r = fmaf(x, L2E_LO, r);
   const float e = __builtin_amdgcn_exp2f(t);
   return fmaf(e, r * 0.693147182464599609375f, e);
+}
+
+// ---- bf16x3 arithmetic of the backward (round 6; the bf16x3 / bf16x3_presplit modes): the same five contractions on v_mfma_f32_32x32x16_bf16,
+// every operand split hi + lo when it is fetched (a*b ~= al*bh + ah*bl + ah*bh, fp32 accumulate -- the forward's and the GEMMs' arithmetic),
+// from the SAME fp32 LDS images and register layouts as the fp32 kernels: 16 channels (or 16 keys / queries) per MFMA instead of 2 -- 36
+// (dq) / 48 (dkv) MFMAs of 32 cycles per tile pair where the fp32 path issues 96 / 128 of 64.  The splits are VALU work every wave repeats
+// for the tile it reads (a pre-split, key-blocked image would share them: K, V and K^T of 257 tokens do not fit the LDS at once).
+typedef split_t bsplit8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void bwd_split8(const float* v, bsplit8& hi, bsplit8& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hi[i] = (split_t)v[i];
+    lo[i] = (split_t)(v[i] - (float)hi[i]);
+  }
+}
+#ifdef RGM_SPLIT_F16
+#define RGM_BWD_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+#define RGM_BWD_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
+// acc += A . B with both operands split: term order al*bh, ah*bl, ah*bh (as everywhere)
+__device__ __forceinline__ void mfma_x3(f32x16& acc, const bsplit8& ah, const bsplit8& al, const bsplit8& bh, const bsplit8& bl) {
+  acc = RGM_BWD_MFMA(al, bh, acc, 0, 0, 0);
+  acc = RGM_BWD_MFMA(ah, bl, acc, 0, 0, 0);
+  acc = RGM_BWD_MFMA(ah, bh, acc, 0, 0, 0);
+}
+// 8 consecutive floats of an LDS row (16-byte aligned) as a split fragment; zero = the chunk lies beyond the row's channels
+__device__ __forceinline__ void frag_row8(const float* p, bool zero, bsplit8& hi, bsplit8& lo) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  const float v[8] = {zero ? 0.f : a.x, zero ? 0.f : a.y, zero ? 0.f : a.z, zero ? 0.f : a.w, zero ? 0.f : b.x, zero ? 0.f : b.y, zero ? 0.f : b.z, zero ? 0.f : b.w};
+  bwd_split8(v, hi, lo);
+}
+// the transposed fragment: channel `col` of the 8 rows a lane's C/D registers 8 h2 .. 8 h2 + 7 stand for -- row (j & 3) + 8 (2 h2 + (j >> 2))
+// + 4 hh of the 32-row tile at `tile` (row stride HDP floats): slot j of the B operand built from those registers meets slot j here
+template <int HDP>
+__device__ __forceinline__ void frag_col8(const float* tile, int col, int h2, int hh, bsplit8& hi, bsplit8& lo) {
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = tile[((j & 3) + 8 * (2 * h2 + (j >> 2)) + 4 * hh) * HDP + col];
+  bwd_split8(v, hi, lo);
 }
 
 __device__ __forceinline__ float4 rotate4(float4 v, const float* __restrict__ ct, const float* __restrict__ st, int pi, bool inverse) {
@@ -67,7 +108,7 @@ __device__ __forceinline__ void dqkv_store1(float* __restrict__ dqkv, long long 
   }
 }
 
-template <int HD, int NKT, bool SPLIT>
+template <int HD, int NKT, bool SPLIT, bool X3 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                           const float* __restrict__ d_o, const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, const float* __restrict__ cos_tab,
@@ -107,9 +148,33 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
   for (int qt = qt0; qt < nqt; qt += SPLIT ? nqt_all : 8) {
     const int q = qt * 32 + l31, qc = min(q, T - 1);
     const long long orow = ((long long)n * T + qc) * D + head * HD;
-    f32x4 qf[KB], dof[KB];
+    f32x4 qf[X3 ? 1 : KB], dof[X3 ? 1 : KB];
+    constexpr int KS = (HD + 15) / 16;                       // k16 steps of the contractions over the channels (hd = 72: the fifth is half empty)
+    bsplit8 qh[X3 ? KS : 1], ql[X3 ? KS : 1], gh[X3 ? KS : 1], gl[X3 ? KS : 1];
     float dsum = 0.f;
-    {
+    if constexpr (X3) {   // lane (query l31, half hh) holds channels 16 j + 8 hh .. + 7 of Q (rotated, scaled) and dO: B operands of S^T and dP^T
+      const float* qp = base + (long long)qc * D3;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        float q8[8], g8[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d0 = 16 * j + 8 * hh + 4 * u;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f), g = v;
+          if (d0 < HD) {
+            v = *reinterpret_cast<const float4*>(qp + d0);
+            if (d0 < R) v = rotate4(v, cos_tab, sin_tab, qc * rot_half + (d0 >> 1), false);
+            g = *reinterpret_cast<const float4*>(d_o + orow + d0);
+            const float4 ov = *reinterpret_cast<const float4*>(o + orow + d0);
+            dsum += (g.x * ov.x + g.y * ov.y) + (g.z * ov.z + g.w * ov.w);
+          }
+          q8[4 * u] = v.x * scale; q8[4 * u + 1] = v.y * scale; q8[4 * u + 2] = v.z * scale; q8[4 * u + 3] = v.w * scale;
+          g8[4 * u] = g.x; g8[4 * u + 1] = g.y; g8[4 * u + 2] = g.z; g8[4 * u + 3] = g.w;
+        }
+        bwd_split8(q8, qh[j], ql[j]);
+        bwd_split8(g8, gh[j], gl[j]);
+      }
+    } else {
       const float* qp = base + (long long)qc * D3;
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
@@ -136,6 +201,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+      if constexpr (X3) {
+        const float* kp = Ks + (kt * 32 + l31) * HDP + 8 * hh;
+        const float* vp = Vs + (kt * 32 + l31) * HDP + 8 * hh;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const bool past = 16 * j + 8 * hh >= HD;            // (hd = 72: the pad of the row is not initialised)
+          bsplit8 kh, kl, vh, vl;
+          frag_row8(kp + 16 * j, past, kh, kl);
+          frag_row8(vp + 16 * j, past, vh, vl);
+          mfma_x3(s, kh, kl, qh[j], ql[j]);                   // S^T[key][query]
+          mfma_x3(dp, vh, vl, gh[j], gl[j]);                  // dP^T[key][query]
+        }
+      } else {
       const float* kp = Ks + (kt * 32 + l31) * HDP + 4 * hh;
       const float* vp = Vs + (kt * 32 + l31) * HDP + 4 * hh;
 #pragma unroll
@@ -148,6 +226,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
           dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[u], dof[j][u], dp, 0, 0, 0);   // dP^T[key][query]
         }
       }
+      }
       f32x16 ds;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -155,12 +234,29 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
         if (kt == ktr && (e & 3) + 8 * (e >> 2) + 4 * hh >= tr) p = 0.f;               // ragged last key tile
         ds[e] = p * (dp[e] - dsum);
       }
+      if constexpr (X3) {   // dQ^T[d][query] += K^T[d][key] dS^T[key][query]: the registers of dS^T are the B operand, K^T comes column-wise from the image
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float d8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) d8[j] = ds[8 * h2 + j];
+          bsplit8 dsh, dsl;
+          bwd_split8(d8, dsh, dsl);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            bsplit8 ah, al;
+            frag_col8<HDP>(Ks + kt * 32 * HDP, dt * 32 + l31, h2, hh, ah, al);
+            mfma_x3(dq[dt], ah, al, dsh, dsl);
+          }
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const float* kr = Ks + (kt * 32 + (u & 3) + 8 * (u >> 2) + 4 * hh) * HDP + l31;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) dq[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[dt * 32], ds[u], dq[dt], 0, 0, 0);
         if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
       }
     }
     if constexpr (SPLIT) {   // partial dQ of this wave's key tiles -> LDS [wave][query][HDP] over the K image; fixed-order sum; scale, un-rotate, store
@@ -255,7 +351,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------- dK, dV
 // SPLIT: one workgroup per (sample, head, KEY TILE); wave w takes query tiles w, w + 8, ...; partial dK / dV tiles summed through LDS
-template <int HD, int NKT, bool SPLIT>
+template <int HD, int NKT, bool SPLIT, bool X3 = false>
 __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv, const float* __restrict__ o,
                                                            const float* __restrict__ d_o, const float* __restrict__ lse,
                                                            float* __restrict__ dqkv, const float* __restrict__ cos_tab,
@@ -312,7 +408,30 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
   for (int kt = kt0; kt < nkt; kt += SPLIT ? nkt_all : 8) {
     const int key = kt * 32 + l31, kc = min(key, T - 1);
     f32x4 kf[KB], vf[KB];
-    {
+    constexpr int KS = (HD + 15) / 16;
+    bsplit8 kh[X3 ? KS : 1], kl[X3 ? KS : 1], vh[X3 ? KS : 1], vl[X3 ? KS : 1];   // lane (key l31, half hh): channels 16 j + 8 hh .. + 7 (B operands of S and dP)
+    if constexpr (X3) {
+      const float* rowp = base + (long long)kc * D3;
+#pragma unroll
+      for (int j = 0; j < KS; ++j) {
+        float k8[8], v8[8];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int d0 = 16 * j + 8 * hh + 4 * u;
+          float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+          if (d0 < HD) {
+            kv = *reinterpret_cast<const float4*>(rowp + D + d0);
+            if (d0 < R) kv = rotate4(kv, cos_tab, sin_tab, kc * rot_half + (d0 >> 1), false);
+            vv = *reinterpret_cast<const float4*>(rowp + 2 * D + d0);
+          }
+          k8[4 * u] = kv.x; k8[4 * u + 1] = kv.y; k8[4 * u + 2] = kv.z; k8[4 * u + 3] = kv.w;
+          v8[4 * u] = vv.x; v8[4 * u + 1] = vv.y; v8[4 * u + 2] = vv.z; v8[4 * u + 3] = vv.w;
+        }
+        bwd_split8(k8, kh[j], kl[j]);
+        bwd_split8(v8, vh[j], vl[j]);
+      }
+    }
+    auto load_kf = [&]() __attribute__((always_inline)) {          // the fp32 fragments: the fp32 MFMAs' B operands; the lone-query update's rows
       const float* rowp = base + (long long)kc * D3;
 #pragma unroll
       for (int j = 0; j < KB; ++j) {
@@ -323,7 +442,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         kf[j][0] = kv.x; kf[j][1] = kv.y; kf[j][2] = kv.z; kf[j][3] = kv.w;
         vf[j][0] = vv.x; vf[j][1] = vv.y; vf[j][2] = vv.z; vf[j][3] = vv.w;
       }
-    }
+    };
+    if constexpr (!X3) load_kf();
     const bool key_ok = key < T;
     f32x16 dk[DT], dv[DT];
 #pragma unroll
@@ -336,6 +456,19 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
       f32x16 s, dp;
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
+      if constexpr (X3) {
+        const float* qp = Qs + (qt * 32 + l31) * HDP + 8 * hh;
+        const float* gp = Gs + (qt * 32 + l31) * HDP + 8 * hh;
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+          const bool past = 16 * j + 8 * hh >= HD;
+          bsplit8 qfh, qfl, gfh, gfl;
+          frag_row8(qp + 16 * j, past, qfh, qfl);
+          frag_row8(gp + 16 * j, past, gfh, gfl);
+          mfma_x3(s, qfh, qfl, kh[j], kl[j]);                  // S[query][key]
+          mfma_x3(dp, gfh, gfl, vh[j], vl[j]);                 // dP[query][key]
+        }
+      } else {
       const float* qp = Qs + (qt * 32 + l31) * HDP + 4 * hh;
       const float* gp = Gs + (qt * 32 + l31) * HDP + 4 * hh;
 #pragma unroll
@@ -348,6 +481,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
           dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[u], vf[j][u], dp, 0, 0, 0);   // dP[query][key]
         }
       }
+      }
       f32x16 p, ds;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
@@ -357,6 +491,28 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         p[e] = pv;
         ds[e] = pv * (dp[e] - Ds[qt * 32 + qrow]);
       }
+      if constexpr (X3) {   // dV^T[d][key] += dO^T[d][query] P[query][key], dK^T[d][key] += Q^T[d][query] dS[query][key]
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+          float p8[8], d8[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            p8[j] = p[8 * h2 + j];
+            d8[j] = ds[8 * h2 + j];
+          }
+          bsplit8 ph, pl, dsh, dsl;
+          bwd_split8(p8, ph, pl);
+          bwd_split8(d8, dsh, dsl);
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            bsplit8 ah, al;
+            frag_col8<HDP>(Gs + qt * 32 * HDP, dt * 32 + l31, h2, hh, ah, al);
+            mfma_x3(dv[dt], ah, al, ph, pl);
+            frag_col8<HDP>(Qs + qt * 32 * HDP, dt * 32 + l31, h2, hh, ah, al);
+            mfma_x3(dk[dt], ah, al, dsh, dsl);
+          }
+        }
+      } else {
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int qrow = qt * 32 + (u & 3) + 8 * (u >> 2) + 4 * hh;
@@ -369,9 +525,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
         }
         if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
+      }
     }
     if constexpr (!SPLIT) {
       if (lone) {   // the lone last query q* against this wave's 32 keys: s, dp from the K / V fragments the lanes hold, then
+        if constexpr (X3) load_kf();              // (not kept through the query loop in the x3 kernel: 64 registers)
         const int qs_ = T - 1;                    // dV^T[d][key] += dO[q*][d] p[key], dK^T[d][key] += Q[q*][d] ds[key]
         const float* qr = Qs + qs_ * HDP;
         const float* gr = Gs + qs_ * HDP;
@@ -496,7 +654,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 
 static int g_attn_split = -1;   // rgm_set_attn_split: -1 auto, 0 never, 1 always
 
-template <int HD, int NKT>
+template <int HD, int NKT, bool X3>
 static int launch_bwd(const float* qkv, const float* o, const float* d_o, const float* lse, float* dqkv, const float* ct,
                       const float* st, int N, int T, int heads, int rot_half, hipStream_t s, int osplit) {
   constexpr int TP = NKT * 32, HDP = HD + 4;
@@ -511,8 +669,8 @@ static int launch_bwd(const float* qkv, const float* o, const float* d_o, const 
   if (split) {
     const size_t lds_q = attn_lds_one_per_cu(images > (size_t)8 * 32 * HDP * 4 ? images : (size_t)8 * 32 * HDP * 4);
     const size_t lds_kv = attn_lds_one_per_cu((images > (size_t)16 * 32 * HDP * 4 ? images : (size_t)16 * 32 * HDP * 4) + (size_t)2 * TP * sizeof(float));
-    auto kq = attn_bwd_dq_kernel<HD, NKT, true>;
-    auto kkv = attn_bwd_dkv_kernel<HD, NKT, true>;
+    auto kq = attn_bwd_dq_kernel<HD, NKT, true, X3>;
+    auto kkv = attn_bwd_dkv_kernel<HD, NKT, true, X3>;
     static bool prepared = false;
     if (!prepared) {
       RGM_TRY(attn_prepare_kernel(kq, 512, lds_q, "attn_bwd_dq_kernel (per query tile)"));
@@ -531,8 +689,8 @@ static int launch_bwd(const float* qkv, const float* o, const float* d_o, const 
   const size_t lds_kv = attn_lds_one_per_cu(images + (size_t)2 * TP * sizeof(float) + scr_kv);
   static const int lone_off = getenv("RGM_ATTN_LONE") ? !atoi(getenv("RGM_ATTN_LONE")) : 0;      // RGM_ATTN_LONE=0: every tile through the MFMAs (A/B)
   const int lone = (!lone_off && (T & 31) == 1 && nt > 1 && lds_kv <= 160 * 1024) ? 1 : 0;
-  auto kq = attn_bwd_dq_kernel<HD, NKT, false>;
-  auto kkv = attn_bwd_dkv_kernel<HD, NKT, false>;
+  auto kq = attn_bwd_dq_kernel<HD, NKT, false, X3>;
+  auto kkv = attn_bwd_dkv_kernel<HD, NKT, false, X3>;
   static bool prepared = false;
   if (!prepared) {
     RGM_TRY(attn_prepare_kernel(kq, 512, lds_q <= 160 * 1024 ? lds_q : attn_lds_one_per_cu(images), "attn_bwd_dq_kernel"));
@@ -555,15 +713,23 @@ int rotary_attention_bwd_launch(const float* qkv, const float* o, const float* d
   RGM_REQUIRE(hd == 64 || hd == 72, "attention backward: head_dim %d (64 = the S/B family, 72 = XL)", hd);
   RGM_REQUIRE(T > 0 && T <= 288, "attention backward: T=%d", T);
   const int nkt = (T + 31) / 32;
+  // the bf16x3 modes run the x3 kernels (the forward attention and every GEMM of the chain already compute that way); fp32 mode and
+  // RGM_ATTN_BWD_X3=0 (A/B runs) the fp32 MFMAs
+  static const int x3_off = getenv("RGM_ATTN_BWD_X3") ? !atoi(getenv("RGM_ATTN_BWD_X3")) : 0;
+  const bool x3 = rgm_get_gemm_precision() != 0 && !x3_off;
+#define RGM_BWD_GO(HDv, NKTv)                                                                                                       \
+  return x3 ? launch_bwd<HDv, NKTv, true>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit)               \
+            : launch_bwd<HDv, NKTv, false>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit)
   if (hd == 72) {   // XL eps-network (DPS guidance): Q/dO resp. K/V of one head + lse/D = 157.7 KB of LDS at T = 256
     RGM_REQUIRE(nkt <= 8, "attention backward: head_dim 72 supports T <= 256, got %d", T);
-    if (nkt <= 4) return launch_bwd<72, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
-    return launch_bwd<72, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
+    if (nkt <= 4) { RGM_BWD_GO(72, 4); }
+    RGM_BWD_GO(72, 8);
   }
-  if (nkt <= 4) return launch_bwd<64, 4>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
-  if (nkt <= 5) return launch_bwd<64, 5>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
-  if (nkt <= 8) return launch_bwd<64, 8>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
-  return launch_bwd<64, 9>(qkv, o, d_o, lse, dqkv, cos_tab, sin_tab, N, T, heads, rot_half, s, osplit);
+  if (nkt <= 4) { RGM_BWD_GO(64, 4); }
+  if (nkt <= 5) { RGM_BWD_GO(64, 5); }
+  if (nkt <= 8) { RGM_BWD_GO(64, 8); }
+  RGM_BWD_GO(64, 9);
+#undef RGM_BWD_GO
 }
 
 int attn_split_mode() { return g_attn_split; }

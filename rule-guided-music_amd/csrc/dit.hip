@@ -35,6 +35,7 @@ int gate_rows_launch(const float* dx, const float* gate, float* out, int M, int 
 int act_rows_launch(const float* in, float* out, long long rows, int D, int act, hipStream_t s, int out_split = 0);
 int loss_grad_launch(const float* logits, const void* target, float* dl, int rows, int K, int Kp, float scale, int kind, hipStream_t s);
 int scatter_rows_launch(const float* src, float* dx, int N, int T, int D, int first, int groups, int per, hipStream_t s);
+int adaln_stream_launch(const float* cs, const float* W, const float* bias, float* out, int N, int D, int L, int ldo, hipStream_t s);   // adaln_stream.hip
 }  // namespace rgm
 
 using namespace rgm;
@@ -445,6 +446,14 @@ int lin_gated(const float* A, int lda, const float* W, const float* bias, float*
   return gemm_launch(g, s);
 }
 
+// adaLN conditioning mod[N, L] = SiLU(c) . W_ada^T + b of ALL blocks (+ final layer): the weight-streaming kernel (adaln_stream.hip: exact fp32,
+// one pass over the 0.9 GB at HBM rate) for up to 32 rows, the tiled GEMM otherwise
+int cond_mod(const float* cs, const float* W, const float* bias, float* mod, int N, int D, int L, hipStream_t s) {
+  const int rc = adaln_stream_launch(cs, W, bias, mod, N, D, L, L, s);
+  if (rc <= 0) return rc;
+  return lin(cs, D, W, bias, mod, L, N, L, D, 0, s);
+}
+
 // embedders + blocks; leaves the residual stream in plan.x and SiLU(c) modulation in plan.mod
 int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, const int32_t* y, hipStream_t s) {
   const rgm_dit_cfg& c = h->cfg;
@@ -487,7 +496,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     RGM_CHECK_HIP(hipEventRecord(h->ev_join, h->side));
     joined = false;
   } else {
-    RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, p.N, L, D, 0, s));
+    RGM_TRY(cond_mod(p.cs, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, p.N, D, L, s));
   }
   auto join = [&]() -> int {
     if (!joined) RGM_CHECK_HIP(hipStreamWaitEvent(s, h->ev_join, 0));
@@ -836,7 +845,7 @@ static int grad_forward(rgm_dit* h, const GPlan& p, const float* x, const int64_
     const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
     RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, N, D, s));
   }
-  RGM_TRY(lin(p.cs, D, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, L, N, L, D, 0, s));
+  RGM_TRY(cond_mod(p.cs, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), p.mod, N, D, L, s));
   const size_t lse_sz = (size_t)N * c.heads * T;
   const bool v2 = rgm_get_gemm_precision() == 2;
   h->sk_ws = p.sk;

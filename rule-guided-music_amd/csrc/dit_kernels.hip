@@ -9,6 +9,7 @@
 //
 // All are one pass over their tensor with 16-byte lanes; LN keeps the row in registers (one wave
 // per row, shuffle reductions), so x is read once and the modulated row written once.
+#include <stdlib.h>
 #include "common.h"
 #include "ln_body.h"
 
@@ -19,9 +20,19 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
                                                      float eps, const float* __restrict__ weight,
                                                      const float* __restrict__ bias, const float* __restrict__ shift,
                                                      const float* __restrict__ scale, int mod_ld, int rows_per_batch,
-                                                     int out_split) {
+                                                     int out_split, int preload) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
+  if (preload && scale && !weight) {
+    // adaLN rows (every LayerNorm of a DiT block): the sample's shift / scale row is requested WITH the row itself -- read behind the two
+    // wave reductions it was a second dependent round trip of every wave of the launch (one wave per row: nothing else hides it)
+    LnRow<MAXV> st;
+    LnMod<MAXV> md;
+    ln_mod_load<MAXV>(st, x, row, D);
+    ln_mod_load_mod<MAXV>(md, shift, scale, D, (long long)(row / rows_per_batch) * mod_ld);
+    ln_mod_finish<MAXV, 0, 1>(st, out, row, D, eps, nullptr, nullptr, shift, scale, mod_ld, rows_per_batch, out_split, md);
+    return;
+  }
   ln_mod_row<MAXV>(x, out, row, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
 }
 
@@ -34,12 +45,13 @@ int layernorm_modulate_launch(const float* x, float* out, int M, int D, float ep
   if (rows_per_batch <= 0) rows_per_batch = 1;
   dim3 grid(cdiv(M, 4)), block(256);
   const int nv = D / 4;
+  static const int preload = getenv("RGM_LN_PRELOAD") ? atoi(getenv("RGM_LN_PRELOAD")) : 1;     // 0: shift / scale read behind the reductions (A/B runs)
   if (nv <= 128)
-    hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
+    hipLaunchKernelGGL(ln_mod_kernel<2>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split, preload);
   else if (nv <= 320)
-    hipLaunchKernelGGL(ln_mod_kernel<5>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
+    hipLaunchKernelGGL(ln_mod_kernel<5>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split, preload);
   else
-    hipLaunchKernelGGL(ln_mod_kernel<8>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split);
+    hipLaunchKernelGGL(ln_mod_kernel<8>, grid, block, 0, s, x, out, M, D, eps, weight, bias, shift, scale, mod_ld, rows_per_batch, out_split, preload);
   RGM_LAUNCH_CHECK();
   return RGM_OK;
 }

@@ -33,6 +33,7 @@ def _load():
         "rgm_dit_classify": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
         "rgm_gemm": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, vp]),
         "rgm_gemm_tile": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp]),
+        "rgm_adaln_stream": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, vp]),
         "rgm_layernorm_modulate": (C.c_int, [vp, vp, i32, i32, f32, vp, vp, vp, vp, i32, i32, vp]),
         "rgm_rotary_attention": (C.c_int, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),
         "rgm_rotary_attention_lse": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp]),

@@ -70,8 +70,9 @@ def test_chord_classifier_heads(precision):
     assert rel(ch.cpu().numpy(), g["chord.logits"]) < TOL
 
 
-def test_attention_backward_kernel_vs_oracle():
-    """d(qkv) of the rotary attention core against the hand-written numpy backward (pinned to autograd goldens)."""
+def test_attention_backward_kernel_vs_oracle(precision):
+    """d(qkv) of the rotary attention core against the hand-written numpy backward (pinned to autograd goldens): the fp32-MFMA kernels in fp32
+    mode, the bf16x3 ones (round 6: every operand split hi + lo as it is fetched, v_mfma_f32_32x32x16_bf16) in the bf16x3 modes."""
     from gpu_util import dev, rel
     from rgm import native as R
     from rgm.synth import rotary_freqs
@@ -109,7 +110,7 @@ def test_attention_backward_kernel_vs_oracle():
         R.check(R.lib.rgm_rotary_attention_bwd(R.ptr(qd), R.ptr(od), R.ptr(gd), R.ptr(lse), R.ptr(out), R.ptr(cd), R.ptr(sd_),
                                                N, T, heads, hd, hd // 4, R.current_stream()))
         torch.cuda.synchronize()
-        assert rel(out.cpu().numpy(), ref) < 1e-5, (N, T, heads, hd)
+        assert rel(out.cpu().numpy(), ref) < (1e-5 if precision == "fp32" else 4e-5), (N, T, heads, hd)
 
 
 @pytest.mark.parametrize("tag,depth", [("s8d2", 2), ("s8", 12)])

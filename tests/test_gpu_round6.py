@@ -108,3 +108,28 @@ def test_chord_futures_return_what_get_chords_returns():
             assert torch.equal(a, b)
     finally:
         music_rules.register_chord_backend(None)
+
+
+@pytest.mark.parametrize("N,D,L", [(16, 1152, 195840), (1, 1152, 195840), (32, 1152, 6 * 1152), (5, 384, 27648), (17, 384, 27648), (2, 768, 6 * 768 * 2), (68, 1152, 14 * 1152)])
+def test_adaln_stream_kernel_is_the_exact_fp32_product(N, D, L):
+    """csrc/adaln_stream.hip: mod = SiLU(c) . W^T + b of all blocks in one weight-streaming pass (ref guided_diffusion/dit.py:333, :374)
+    against the float64 product -- fp32 products, fp32 accumulation: error at the level of an fp32 dot product of D terms."""
+    from rgm import native as R
+    g = torch.Generator(device="cuda").manual_seed(N * 7 + D)
+    cs = torch.randn(N, D, device="cuda", generator=g)
+    W = torch.randn(L, D, device="cuda", generator=g) * 0.05
+    b = torch.randn(L, device="cuda", generator=g)
+    out = torch.full((N, L), float("nan"), device="cuda")
+    R.check(R.lib.rgm_adaln_stream(R.ptr(cs), R.ptr(W), R.ptr(b), R.ptr(out), N, D, L, R.current_stream()))
+    ref = cs.double() @ W.double().t() + b.double()
+    err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-6, err
+    out2 = torch.empty_like(out)
+    R.check(R.lib.rgm_adaln_stream(R.ptr(cs), R.ptr(W), None, R.ptr(out2), N, D, L, R.current_stream()))
+    assert torch.equal(out2 + b, out) or (out2 + b - out).abs().max().item() < 1e-6
+    # a row is the same fixed-order sum in any batch
+    k = min(N, 3)
+    R.check(R.lib.rgm_adaln_stream(R.ptr(cs[N - k:].contiguous()), R.ptr(W), R.ptr(b), R.ptr(out2), k, D, L, R.current_stream()))
+    assert torch.equal(out2[:k], out[N - k:])
+    with pytest.raises(R.RgmError):
+        R.check(R.lib.rgm_adaln_stream(R.ptr(cs), R.ptr(W), R.ptr(b), R.ptr(out), 257, D, L, R.current_stream()))

@@ -23,8 +23,8 @@ def db_of(d):
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "").replace("rgm::", "")
     name = re.sub(r"\(.*$", "", name)                       # drop the argument list
-    name = name.replace("void ", "").replace("rgm::", "")
     return name[:70]
 
 
@@ -41,9 +41,11 @@ def main():
     cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
     dur = "duration" if "duration" in cols else "(end - start)"
     rows = list(cur.execute(f"select name, count(*), sum({dur}), avg({dur}) from kernels group by name"))
+    # shares over the library's own kernels: the run also builds synthetic weights (torch elementwise kernels, device copies)
+    rows = [r for r in rows if "rgm::" in r[0]]
     total = sum(r[2] for r in rows)
     fetch, write, sq = counters(dfetch), counters(dwrite), counters(dsq)
-    print(f"# workload {w}: in-situ kernels with >= 1.5 % of the GPU time (rocprofv3 --kernel-trace; counters from separate --pmc passes of the same command)")
+    print(f"# workload {w}: in-situ kernels with >= 1.5 % of the library's GPU time (rocprofv3 --kernel-trace; counters from separate --pmc passes of the same command)")
     print(f"# {'kernel':70s} {'share':>6s} {'calls':>6s} {'avg us':>8s} {'MFMA busy':>9s} {'HBM MB/launch':>13s} {'HBM GB/s':>9s} {'fetch MB':>9s} {'write MB':>9s}")
     for name, calls, tot, avg in sorted(rows, key=lambda r: -r[2]):
         if tot < 0.015 * total:
