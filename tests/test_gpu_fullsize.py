@@ -776,7 +776,7 @@ def test_per_tile_attention_workgroups_match_the_per_head_ones(N, T, heads, hd, 
     """rgm_set_attn_split: the classifier path's attention (257 tokens = 9 tiles on 8 waves, 6 x B (sample, head) pairs on 256 CUs) runs
     one workgroup per (sample, head, tile) in the backward -- the eight waves share the tile's key / query loop, partial dQ / dK / dV tiles
     meet in LDS and are summed in wave order -- and two workgroups per (sample, head) in the forward.  Same products, another summation
-    order of the eight partials: forward bit-identical, backward to 3e-6 of the gradient's scale; both repeat bit for bit.  At T = 257 the
+    order of the eight partials: forward bit-identical, backward to 3e-6 of the gradient's scale (4e-5 in the bf16x3 modes, see below); both repeat bit for bit.  At T = 257 the
     per-head launch (mode 0) also takes the lone-token paths -- the 257th token's rows as plain FMA sums of 257 terms and a rank-1 update
     instead of a ninth MFMA tile -- which this comparison covers against the all-MFMA per-tile kernels."""
     from gpu_util import dev
@@ -809,7 +809,10 @@ def test_per_tile_attention_workgroups_match_the_per_head_ones(N, T, heads, hd, 
     assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(g1, g2)
     assert torch.equal(o0, o1) and torch.equal(l0, l1)
     assert bool(torch.isfinite(g1).all())
-    assert float((g0 - g1).abs().max()) <= 3e-6 * float(g0.abs().max())
+    # fp32 mode: the same exact products in another order.  bf16x3 modes (round 6: the backward's products are split hi + lo like the forward's):
+    # at T = 257 the per-head launch computes the lone token's rows with plain fp32 FMAs where the per-tile kernels run a ninth x3 MFMA tile
+    # -- those terms differ by the split's 2^-16 per product
+    assert float((g0 - g1).abs().max()) <= (3e-6 if precision == "fp32" else 4e-5) * float(g0.abs().max())
 
 
 def test_half_window_batches_through_the_xl_model_are_deterministic(precision):

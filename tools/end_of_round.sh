@@ -19,6 +19,9 @@ tools/prof_bench.sh ${R}_c2_b8 --no-extras --batch 8 --steps 20 --warmup 5 > /de
 python tools/batch_sweep.py > gpurun_out/${R}_batch_sweep.txt 2>&1
 python tools/cls_time.py 1 4 8 16 32 > gpurun_out/${R}_cls_time.txt 2>&1
 python tools/hazard_soak.py 100 > gpurun_out/${R}_hazard_soak.txt 2>&1
+# round 6: counter evidence per kernel, in situ (MFMA-busy %, HBM GB/s), and the round's own tests with their measurements printed
+tools/pmc_round.sh ${R} c2 scg c3 > gpurun_out/${R}_pmc_all.log 2>&1
+python -m pytest tests/test_gpu_round6.py tests/test_gpu_sampler.py tests/test_gpu_pins2.py -q -m gpu -s -k "chord_analyser or end_to_end or two_step or vae_decoder" 2>&1 | grep "^\[\|passed\|failed" > gpurun_out/${R}_round6_tests_printed.txt
 for f in gpurun_out/${R}_*_bench_under_rocprof.json gpurun_out/${R}_bench_default_n1.json; do echo "== $f"; python - "$f" <<'PY'
 import json, sys
 try:
