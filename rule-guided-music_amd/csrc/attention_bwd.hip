@@ -31,9 +31,9 @@ __device__ __forceinline__ float exp_le0(float x) {
 
 // ---- bf16x3 arithmetic of the backward (round 6; the bf16x3 / bf16x3_presplit modes): the same five contractions on v_mfma_f32_32x32x16_bf16,
 // every operand split hi + lo when it is fetched (a*b ~= al*bh + ah*bl + ah*bh, fp32 accumulate -- the forward's and the GEMMs' arithmetic),
-// from the SAME fp32 LDS images and register layouts as the fp32 kernels: 16 channels (or 16 keys / queries) per MFMA instead of 2 -- 36
-// (dq) / 48 (dkv) MFMAs of 32 cycles per tile pair where the fp32 path issues 96 / 128 of 64.  The splits are VALU work every wave repeats
-// for the tile it reads (a pre-split, key-blocked image would share them: K, V and K^T of 257 tokens do not fit the LDS at once).
+// with the register layouts of the fp32 kernels: 16 channels (or 16 keys / queries) per MFMA instead of 2 -- 36 (dq) / 48 (dkv) MFMAs of 32
+// cycles per tile pair where the fp32 path issues 96 / 128 of 64.  The LDS images are pre-split rows (PsImg below); only the registers that
+// become B operands (Q / dO resp. K / V fragments once per tile, P and dS per tile pair) are split by the wave that holds them.
 typedef split_t bsplit8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void bwd_split8(const float* v, bsplit8& hi, bsplit8& lo) {
 #pragma unroll
@@ -53,20 +53,65 @@ __device__ __forceinline__ void mfma_x3(f32x16& acc, const bsplit8& ah, const bs
   acc = RGM_BWD_MFMA(ah, bl, acc, 0, 0, 0);
   acc = RGM_BWD_MFMA(ah, bh, acc, 0, 0, 0);
 }
-// 8 consecutive floats of an LDS row (16-byte aligned) as a split fragment; zero = the chunk lies beyond the row's channels
-__device__ __forceinline__ void frag_row8(const float* p, bool zero, bsplit8& hi, bsplit8& lo) {
-  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-  const float v[8] = {zero ? 0.f : a.x, zero ? 0.f : a.y, zero ? 0.f : a.z, zero ? 0.f : a.w, zero ? 0.f : b.x, zero ? 0.f : b.y, zero ? 0.f : b.z, zero ? 0.f : b.w};
-  bwd_split8(v, hi, lo);
-}
-// the transposed fragment: channel `col` of the 8 rows a lane's C/D registers 8 h2 .. 8 h2 + 7 stand for -- row (j & 3) + 8 (2 h2 + (j >> 2))
-// + 4 hh of the 32-row tile at `tile` (row stride HDP floats): slot j of the B operand built from those registers meets slot j here
-template <int HDP>
-__device__ __forceinline__ void frag_col8(const float* tile, int col, int h2, int hh, bsplit8& hi, bsplit8& lo) {
-  float v[8];
+// ---- LDS images of the x3 kernels: a row keeps its (HD + 4) * 4 bytes but holds [HD hi halves | HD lo halves | 16 bytes of pad] -- split ONCE
+// by the thread that stages the element (the on-the-fly split of round 6's first version was repeated by each of the eight waves for the tile
+// it read: the kernels were VALU-bound).  Row stride in 16-byte slots: 17 (hd 64) / 19 (hd 72), odd -> conflict-free ds_read_b128 groups.
+template <int HD>
+struct PsImg {
+  static constexpr int RS = (HD + 4) * 4;                    // bytes per row (the fp32 image's HDP floats)
+  static __device__ __forceinline__ void st4(float* img, int row, int d0, const float4& v) {
+    typedef split_t h4 __attribute__((ext_vector_type(4)));
+    h4 hi, lo;
+    hi[0] = (split_t)v.x; hi[1] = (split_t)v.y; hi[2] = (split_t)v.z; hi[3] = (split_t)v.w;
+    lo[0] = (split_t)(v.x - (float)hi[0]); lo[1] = (split_t)(v.y - (float)hi[1]);
+    lo[2] = (split_t)(v.z - (float)hi[2]); lo[3] = (split_t)(v.w - (float)hi[3]);
+    char* rp = reinterpret_cast<char*>(img) + row * RS + 2 * d0;
+    *reinterpret_cast<h4*>(rp) = hi;
+    *reinterpret_cast<h4*>(rp + 2 * HD) = lo;
+  }
+  // channels d0 .. d0 + 7 of `row` (d0 a multiple of 8) as the split fragment; zero = the chunk lies beyond the row's channels
+  static __device__ __forceinline__ void row8(const float* img, int row, int d0, bool zero, bsplit8& hi, bsplit8& lo) {
+    const char* rp = reinterpret_cast<const char*>(img) + row * RS + 2 * d0;
+    hi = *reinterpret_cast<const bsplit8*>(rp);
+    lo = *reinterpret_cast<const bsplit8*>(rp + 2 * HD);
+    if (zero) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) v[j] = tile[((j & 3) + 8 * (2 * h2 + (j >> 2)) + 4 * hh) * HDP + col];
-  bwd_split8(v, hi, lo);
+      for (int i = 0; i < 8; ++i) { hi[i] = (split_t)0.f; lo[i] = (split_t)0.f; }
+    }
+  }
+  // the transposed fragment: channel `col` of the 8 rows a lane's C/D registers 8 h2 .. 8 h2 + 7 stand for -- row (j & 3) + 8 (2 h2 + (j >> 2))
+  // + 4 hh of the 32-row tile starting at row `r0`: slot j of the B operand built from those registers meets slot j here
+  static __device__ __forceinline__ void col8(const float* img, int r0, int col, int h2, int hh, bsplit8& hi, bsplit8& lo) {
+    const char* cp = reinterpret_cast<const char*>(img) + (long long)r0 * RS + 2 * col;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const char* ep = cp + ((j & 3) + 8 * (2 * h2 + (j >> 2)) + 4 * hh) * RS;
+      hi[j] = *reinterpret_cast<const split_t*>(ep);
+      lo[j] = *reinterpret_cast<const split_t*>(ep + 2 * HD);
+    }
+  }
+  // the element / four elements as floats again (hi + lo: 2^-17 of the fp32 value; the lone-token paths' plain sums)
+  static __device__ __forceinline__ float ld1(const float* img, int row, int d) {
+    const char* ep = reinterpret_cast<const char*>(img) + row * RS + 2 * d;
+    return (float)*reinterpret_cast<const split_t*>(ep) + (float)*reinterpret_cast<const split_t*>(ep + 2 * HD);
+  }
+  static __device__ __forceinline__ float4 ld4(const float* img, int row, int d0) {
+    typedef split_t h4 __attribute__((ext_vector_type(4)));
+    const char* rp = reinterpret_cast<const char*>(img) + row * RS + 2 * d0;
+    const h4 hi = *reinterpret_cast<const h4*>(rp), lo = *reinterpret_cast<const h4*>(rp + 2 * HD);
+    return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+  }
+};
+// one accessor for both image formats (X3: pre-split rows; else fp32 rows of HDP floats)
+template <int HD, bool X3>
+__device__ __forceinline__ float4 img_ld4(const float* img, int row, int d0) {
+  if constexpr (X3) return PsImg<HD>::ld4(img, row, d0);
+  else return *reinterpret_cast<const float4*>(img + row * (HD + 4) + d0);
+}
+template <int HD, bool X3>
+__device__ __forceinline__ float img_ld1(const float* img, int row, int d) {
+  if constexpr (X3) return PsImg<HD>::ld1(img, row, d);
+  else return img[row * (HD + 4) + d];
 }
 
 __device__ __forceinline__ float4 rotate4(float4 v, const float* __restrict__ ct, const float* __restrict__ st, int pi, bool inverse) {
@@ -125,17 +170,46 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
   const float* base = qkv + (long long)n * T * D3 + head * HD;
   const int tid = threadIdx.x;
   constexpr int CPR = HD / 4;
-  for (int c = tid; c < TP * CPR; c += 512) {
-    const int key = c / CPR, d0 = (c - key * CPR) * 4;
-    float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-    if (key < T) {
-      const float* rowp = base + (long long)key * D3;
-      kv = *reinterpret_cast<const float4*>(rowp + D + d0);
-      vv = *reinterpret_cast<const float4*>(rowp + 2 * D + d0);
-      if (d0 < R) kv = rotate4(kv, cos_tab, sin_tab, key * rot_half + (d0 >> 1), false);
+  // every load of the staging -- the rows' chunks and their rotary factors -- is requested before the first is used: chunk by chunk the
+  // loop walked TP * CPR / 512 = 9 dependent round trips (rows, then the cos / sin entries) before the first MFMA of the launch
+  constexpr int NIT = (TP * CPR + 511) / 512;
+  {
+    float4 kvs[NIT], vvs[NIT];
+    float cf[NIT][4];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = tid + i * 512;
+      const int key = c / CPR, d0 = (c - key * CPR) * 4;
+      kvs[i] = vvs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cf[i][0] = cf[i][1] = 1.f;
+      cf[i][2] = cf[i][3] = 0.f;
+      if (c < TP * CPR && key < T) {
+        const float* rowp = base + (long long)key * D3;
+        kvs[i] = *reinterpret_cast<const float4*>(rowp + D + d0);
+        vvs[i] = *reinterpret_cast<const float4*>(rowp + 2 * D + d0);
+        if (d0 < R) {
+          const int pi = key * rot_half + (d0 >> 1);
+          cf[i][0] = cos_tab[pi]; cf[i][1] = cos_tab[pi + 1];
+          cf[i][2] = sin_tab[pi]; cf[i][3] = sin_tab[pi + 1];
+        }
+      }
     }
-    *reinterpret_cast<float4*>(Ks + key * HDP + d0) = kv;
-    *reinterpret_cast<float4*>(Vs + key * HDP + d0) = vv;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = tid + i * 512;
+      if (c >= TP * CPR) continue;
+      const int key = c / CPR, d0 = (c - key * CPR) * 4;
+      const float4 x = kvs[i];
+      const float4 kv = make_float4(x.x * cf[i][0] - x.y * cf[i][2], x.y * cf[i][0] + x.x * cf[i][2],
+                                    x.z * cf[i][1] - x.w * cf[i][3], x.w * cf[i][1] + x.z * cf[i][3]);   // (1, 0) outside the rotary channels: x itself
+      if constexpr (X3) {
+        PsImg<HD>::st4(Ks, key, d0, kv);
+        PsImg<HD>::st4(Vs, key, d0, vvs[i]);
+      } else {
+        *reinterpret_cast<float4*>(Ks + key * HDP + d0) = kv;
+        *reinterpret_cast<float4*>(Vs + key * HDP + d0) = vvs[i];
+      }
+    }
   }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -202,14 +276,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
       if constexpr (X3) {
-        const float* kp = Ks + (kt * 32 + l31) * HDP + 8 * hh;
-        const float* vp = Vs + (kt * 32 + l31) * HDP + 8 * hh;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
-          const bool past = 16 * j + 8 * hh >= HD;            // (hd = 72: the pad of the row is not initialised)
+          const bool past = 16 * j + 8 * hh >= HD;            // (hd = 72: the read runs into the lo halves / the pad)
           bsplit8 kh, kl, vh, vl;
-          frag_row8(kp + 16 * j, past, kh, kl);
-          frag_row8(vp + 16 * j, past, vh, vl);
+          PsImg<HD>::row8(Ks, kt * 32 + l31, 16 * j + 8 * hh, past, kh, kl);
+          PsImg<HD>::row8(Vs, kt * 32 + l31, 16 * j + 8 * hh, past, vh, vl);
           mfma_x3(s, kh, kl, qh[j], ql[j]);                   // S^T[key][query]
           mfma_x3(dp, vh, vl, gh[j], gl[j]);                  // dP^T[key][query]
         }
@@ -245,7 +317,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             bsplit8 ah, al;
-            frag_col8<HDP>(Ks + kt * 32 * HDP, dt * 32 + l31, h2, hh, ah, al);
+            PsImg<HD>::col8(Ks, kt * 32, min(dt * 32 + l31, HD - 1), h2, hh, ah, al);   // (channels past hd: rows of dQ^T nobody stores)
             mfma_x3(dq[dt], ah, al, dsh, dsl);
           }
         }
@@ -323,11 +395,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
       for (int key = lane; key < TP; key += 64) {
         float sacc = 0.f, dpa = 0.f;
         if (key < T) {
-          const float* kr = Ks + key * HDP;
-          const float* vr = Vs + key * HDP;
 #pragma unroll 4
           for (int d0 = 0; d0 < HD; d0 += 4) {
-            const float4 kq = *reinterpret_cast<const float4*>(kr + d0), vq = *reinterpret_cast<const float4*>(vr + d0);
+            const float4 kq = img_ld4<HD, X3>(Ks, key, d0), vq = img_ld4<HD, X3>(Vs, key, d0);
             const float4 qq = *reinterpret_cast<const float4*>(qrow + d0), gq = *reinterpret_cast<const float4*>(grow + d0);
             sacc += (kq.x * qq.x + kq.y * qq.y) + (kq.z * qq.z + kq.w * qq.w);
             dpa += (vq.x * gq.x + vq.y * gq.y) + (vq.z * gq.z + vq.w * gq.w);
@@ -337,7 +407,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
       }
       for (int d = lane; d < HD; d += 64) {        // (same wave wrote dsr: LDS operations of a wave are in order)
         float a = 0.f;
-        for (int key = 0; key < T; ++key) a = fmaf(dsr[key], Ks[key * HDP + d], a);
+        for (int key = 0; key < T; ++key) a = fmaf(dsr[key], img_ld1<HD, X3>(Ks, key, d), a);
         outr[d] = a * scale;
       }
       for (int d0 = lane * 4; d0 < HD; d0 += 256) {
@@ -371,17 +441,44 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
   const int tid = threadIdx.x;
   const float scale = rsqrtf((float)HD);
   constexpr int CPR = HD / 4;
-  for (int c = tid; c < TP * CPR; c += 512) {
-    const int qi = c / CPR, d0 = (c - qi * CPR) * 4;
-    float4 qv = make_float4(0.f, 0.f, 0.f, 0.f), gv = qv;
-    if (qi < T) {
-      qv = *reinterpret_cast<const float4*>(base + (long long)qi * D3 + d0);
-      if (d0 < R) qv = rotate4(qv, cos_tab, sin_tab, qi * rot_half + (d0 >> 1), false);
-      qv = make_float4(qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale);
-      gv = *reinterpret_cast<const float4*>(d_o + ((long long)n * T + qi) * D + head * HD + d0);
+  constexpr int NIT = (TP * CPR + 511) / 512;      // as in the dq kernel: every load of the staging requested before the first is used
+  {
+    float4 qvs[NIT], gvs[NIT];
+    float cf[NIT][4];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = tid + i * 512;
+      const int qi = c / CPR, d0 = (c - qi * CPR) * 4;
+      qvs[i] = gvs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cf[i][0] = cf[i][1] = 1.f;
+      cf[i][2] = cf[i][3] = 0.f;
+      if (c < TP * CPR && qi < T) {
+        qvs[i] = *reinterpret_cast<const float4*>(base + (long long)qi * D3 + d0);
+        gvs[i] = *reinterpret_cast<const float4*>(d_o + ((long long)n * T + qi) * D + head * HD + d0);
+        if (d0 < R) {
+          const int pi = qi * rot_half + (d0 >> 1);
+          cf[i][0] = cos_tab[pi]; cf[i][1] = cos_tab[pi + 1];
+          cf[i][2] = sin_tab[pi]; cf[i][3] = sin_tab[pi + 1];
+        }
+      }
     }
-    *reinterpret_cast<float4*>(Qs + qi * HDP + d0) = qv;
-    *reinterpret_cast<float4*>(Gs + qi * HDP + d0) = gv;
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+      const int c = tid + i * 512;
+      if (c >= TP * CPR) continue;
+      const int qi = c / CPR, d0 = (c - qi * CPR) * 4;
+      const float4 x = qvs[i];
+      float4 qv = make_float4(x.x * cf[i][0] - x.y * cf[i][2], x.y * cf[i][0] + x.x * cf[i][2],
+                              x.z * cf[i][1] - x.w * cf[i][3], x.w * cf[i][1] + x.z * cf[i][3]);
+      qv = make_float4(qv.x * scale, qv.y * scale, qv.z * scale, qv.w * scale);
+      if constexpr (X3) {
+        PsImg<HD>::st4(Qs, qi, d0, qv);
+        PsImg<HD>::st4(Gs, qi, d0, gvs[i]);
+      } else {
+        *reinterpret_cast<float4*>(Qs + qi * HDP + d0) = qv;
+        *reinterpret_cast<float4*>(Gs + qi * HDP + d0) = gvs[i];
+      }
+    }
   }
   for (int qi = tid; qi < TP; qi += 512) {
     float l = 0.f, dd = 0.f;
@@ -457,14 +554,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
       for (int e = 0; e < 16; ++e) { s[e] = 0.f; dp[e] = 0.f; }
       if constexpr (X3) {
-        const float* qp = Qs + (qt * 32 + l31) * HDP + 8 * hh;
-        const float* gp = Gs + (qt * 32 + l31) * HDP + 8 * hh;
 #pragma unroll
         for (int j = 0; j < KS; ++j) {
           const bool past = 16 * j + 8 * hh >= HD;
           bsplit8 qfh, qfl, gfh, gfl;
-          frag_row8(qp + 16 * j, past, qfh, qfl);
-          frag_row8(gp + 16 * j, past, gfh, gfl);
+          PsImg<HD>::row8(Qs, qt * 32 + l31, 16 * j + 8 * hh, past, qfh, qfl);
+          PsImg<HD>::row8(Gs, qt * 32 + l31, 16 * j + 8 * hh, past, gfh, gfl);
           mfma_x3(s, qfh, qfl, kh[j], kl[j]);                  // S[query][key]
           mfma_x3(dp, gfh, gfl, vh[j], vl[j]);                 // dP[query][key]
         }
@@ -506,9 +601,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
           for (int dt = 0; dt < DT; ++dt) {
             bsplit8 ah, al;
-            frag_col8<HDP>(Gs + qt * 32 * HDP, dt * 32 + l31, h2, hh, ah, al);
+            const int dcol = min(dt * 32 + l31, HD - 1);          // (channels past hd: accumulator rows nobody stores)
+            PsImg<HD>::col8(Gs, qt * 32, dcol, h2, hh, ah, al);
             mfma_x3(dv[dt], ah, al, ph, pl);
-            frag_col8<HDP>(Qs + qt * 32 * HDP, dt * 32 + l31, h2, hh, ah, al);
+            PsImg<HD>::col8(Qs, qt * 32, dcol, h2, hh, ah, al);
             mfma_x3(dk[dt], ah, al, dsh, dsl);
           }
         }
@@ -531,12 +627,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
       if (lone) {   // the lone last query q* against this wave's 32 keys: s, dp from the K / V fragments the lanes hold, then
         if constexpr (X3) load_kf();              // (not kept through the query loop in the x3 kernel: 64 registers)
         const int qs_ = T - 1;                    // dV^T[d][key] += dO[q*][d] p[key], dK^T[d][key] += Q[q*][d] ds[key]
-        const float* qr = Qs + qs_ * HDP;
-        const float* gr = Gs + qs_ * HDP;
         float sp = 0.f, dpp = 0.f;
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-          const float4 qq = *reinterpret_cast<const float4*>(qr + 8 * j + 4 * hh), gq = *reinterpret_cast<const float4*>(gr + 8 * j + 4 * hh);
+          const float4 qq = img_ld4<HD, X3>(Qs, qs_, 8 * j + 4 * hh), gq = img_ld4<HD, X3>(Gs, qs_, 8 * j + 4 * hh);
           sp += (kf[j][0] * qq.x + kf[j][1] * qq.y) + (kf[j][2] * qq.z + kf[j][3] * qq.w);
           dpp += (vf[j][0] * gq.x + vf[j][1] * gq.y) + (vf[j][2] * gq.z + vf[j][3] * gq.w);
         }
@@ -549,7 +643,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int d = dt * 32 + 8 * g + 4 * hh;          // registers 4g..4g+3 of tile dt = channels d..d+3 (reads past hd: never stored)
-            const float4 gq = *reinterpret_cast<const float4*>(gr + d), qq = *reinterpret_cast<const float4*>(qr + d);
+            const float4 gq = img_ld4<HD, X3>(Gs, qs_, d), qq = img_ld4<HD, X3>(Qs, qs_, d);
             dv[dt][4 * g] = fmaf(gq.x, pv, dv[dt][4 * g]); dv[dt][4 * g + 1] = fmaf(gq.y, pv, dv[dt][4 * g + 1]);
             dv[dt][4 * g + 2] = fmaf(gq.z, pv, dv[dt][4 * g + 2]); dv[dt][4 * g + 3] = fmaf(gq.w, pv, dv[dt][4 * g + 3]);
             dk[dt][4 * g] = fmaf(qq.x, dsv, dk[dt][4 * g]); dk[dt][4 * g + 1] = fmaf(qq.y, dsv, dk[dt][4 * g + 1]);
@@ -620,11 +714,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
       for (int qi = lane; qi < TP; qi += 64) {
         float sacc = 0.f, dpa = 0.f;
         if (qi < T) {
-          const float* qr = Qs + qi * HDP;
-          const float* gr = Gs + qi * HDP;
 #pragma unroll 4
           for (int d0 = 0; d0 < HD; d0 += 4) {
-            const float4 qq = *reinterpret_cast<const float4*>(qr + d0), gq = *reinterpret_cast<const float4*>(gr + d0);
+            const float4 qq = img_ld4<HD, X3>(Qs, qi, d0), gq = img_ld4<HD, X3>(Gs, qi, d0);
             const float4 kq = *reinterpret_cast<const float4*>(krow + d0), vq = *reinterpret_cast<const float4*>(vrow + d0);
             sacc += (qq.x * kq.x + qq.y * kq.y) + (qq.z * kq.z + qq.w * kq.w);
             dpa += (gq.x * vq.x + gq.y * vq.y) + (gq.z * vq.z + gq.w * vq.w);
@@ -637,8 +729,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
       for (int d = lane; d < HD; d += 64) {
         float av = 0.f, ak = 0.f;
         for (int qi = 0; qi < T; ++qi) {
-          av = fmaf(pr[qi], Gs[qi * HDP + d], av);
-          ak = fmaf(dsr[qi], Qs[qi * HDP + d], ak);
+          av = fmaf(pr[qi], img_ld1<HD, X3>(Gs, qi, d), av);
+          ak = fmaf(dsr[qi], img_ld1<HD, X3>(Qs, qi, d), ak);
         }
         dqkv_store1(dqkv, (long long)n * T + ks_, D3, head * HD + 2 * D + d, av, osplit);
         outr[d] = ak;
