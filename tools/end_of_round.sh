@@ -11,9 +11,9 @@ python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_bench_default_n1.json 2>
 tools/prof_bench.sh ${R}_c2 --no-extras --steps 20 --warmup 5 > /dev/null 2>&1
 tools/prof_bench.sh ${R}_c3 --no-extras --workload c3 --steps 20 --warmup 5 > /dev/null 2>&1
 tools/prof_bench.sh ${R}_scg_b4_n16 --no-extras --workload scg --steps 5 --warmup 2 > /dev/null 2>&1
-tools/prof_bench.sh ${R}_long --no-extras --workload long --steps 5 --warmup 2 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_long_b2 --no-extras --workload long --steps 5 --warmup 2 > /dev/null 2>&1
 tools/prof_bench.sh ${R}_scg_r8 --no-extras --workload scg --simulate-ranks 8 --steps 10 --warmup 3 > /dev/null 2>&1
-tools/prof_bench.sh ${R}_long_r8 --no-extras --workload long --simulate-ranks 8 --steps 5 --warmup 2 > /dev/null 2>&1
+tools/prof_bench.sh ${R}_long_b2_r8 --no-extras --workload long --simulate-ranks 8 --steps 5 --warmup 2 > /dev/null 2>&1
 tools/prof_bench.sh ${R}_c2_b4 --no-extras --batch 4 --steps 20 --warmup 5 > /dev/null 2>&1
 tools/prof_bench.sh ${R}_c2_b8 --no-extras --batch 8 --steps 20 --warmup 5 > /dev/null 2>&1
 python tools/batch_sweep.py > gpurun_out/${R}_batch_sweep.txt 2>&1
@@ -32,7 +32,7 @@ except Exception as e:
 PY
 done
 # un-profiled lines of the multi-stream workloads (rocprofv3's kernel trace serialises the side streams: C3 reads ~2 ms longer under it)
-for w in c3 scg long; do
+for w in c3 scg long; do  # (long: B = 2 per SURVEY 8d)
   python bench.py --no-extras --workload $w --steps $([ $w = c3 ] && echo 20 || echo 5) --warmup 3 > gpurun_out/${R}_${w}_bench_unprofiled.json 2>/dev/null
   python - gpurun_out/${R}_${w}_bench_unprofiled.json <<'PY'
 import json, sys
