@@ -87,7 +87,9 @@ __global__ __launch_bounds__(1024, 1) void adaln_stream_kernel(const float* __re
 template <int NIT, int NB>
 int launch_ada(const float* cs, const float* W, const float* bias, float* out, int N, int L, int ldo, hipStream_t s) {
   auto kern = adaln_stream_kernel<NIT, NB>;
-  const size_t lds = (size_t)NB * NIT * 1024;
+  // ONE workgroup per CU, enforced through the LDS request (common.h attn_lds_one_per_cu): the kernel is sized as a persistent workgroup per CU,
+  // and it never shares a CU with a twin of itself (tools/isa_lint.py counts it as `single`)
+  const size_t lds = attn_lds_one_per_cu((size_t)NB * NIT * 1024);
   static bool attr = false;
   if (!attr) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   attr = true;
