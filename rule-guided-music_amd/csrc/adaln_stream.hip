@@ -90,16 +90,18 @@ int launch_ada(const float* cs, const float* W, const float* bias, float* out, i
   // ONE workgroup per CU, enforced through the LDS request (common.h attn_lds_one_per_cu): the kernel is sized as a persistent workgroup per CU,
   // and it never shares a CU with a twin of itself (tools/isa_lint.py counts it as `single`)
   const size_t lds = attn_lds_one_per_cu((size_t)NB * NIT * 1024);
-  static bool attr = false;
-  if (!attr) RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  attr = true;
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    RGM_CHECK_HIP(hipGetDevice(&dev));
-    RGM_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (cus <= 0) cus = 256;
+  // per device of the calling thread (one process per GPU is the rule; a process that drives several devices gets each one's CU count and attribute)
+  static int cus_of[16] = {0};
+  int dev = 0;
+  RGM_CHECK_HIP(hipGetDevice(&dev));
+  const int slot = dev & 15;
+  if (!cus_of[slot]) {
+    int n = 0;
+    RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    RGM_CHECK_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+    cus_of[slot] = n > 0 ? n : 256;
   }
+  const int cus = cus_of[slot];
   const int ntask = L >> 4;
   const int grid = ntask < cus * 16 ? (ntask + 15) / 16 : cus;      // never more workgroups than tasks / 16
   hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, cs, W, bias, out, N, L, ldo);
