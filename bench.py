@@ -283,10 +283,10 @@ def roofline_pass(work, steps=2):
     R.check(R.lib.rgm_prof_reset())
     # kernel ids (csrc/gemm.hip, gemm2.hip): < 40 gemm_kernel<BM,BN,WM,WN,ALOAD,PREC> = tile + 10*ALOAD + 20*PREC;
     # >= 40 gemm2_kernel<BM,BN,WM,WN,ALOAD,NSTAGE,0,PIPE> = 40 + tile + 10*ALOAD (tiles: gemm2_launch)
-    tiles = {1: "128,128,2,2", 2: "128,64,2,2", 3: "64,64,2,2", 4: "32,128,1,4", 5: "256,128,4,2", 7: "256,256,2,2", 8: "512,128,4,1", 9: "128,256,1,4"}
+    tiles = {1: "128,128,2,2", 2: "128,64,2,2", 3: "64,64,2,2", 4: "32,128,1,4", 5: "256,128,4,2", 7: "256,256,2,2", 8: "512,128,4,1", 9: "128,256,1,4", 10: "256,288,4,1"}
     g2 = {1: (1, 3, 0), 2: (2, 3, 0), 3: (3, 3, 0), 5: (5, 3, 0), 21: (1, 2, 1), 22: (2, 2, 1),
           43: (1, 2, 3), 44: (2, 2, 3), 45: (5, 2, 3), 46: (3, 3, 3), 51: (1, 3, 4), 52: (2, 3, 4),
-          53: (2, 6, 4), 54: (1, 4, 4), 55: (1, 5, 4), 56: (2, 4, 4), 57: (3, 6, 4), 58: (3, 3, 4), 71: (7, 2, 5), 72: (8, 2, 5), 73: (9, 2, 5)}
+          53: (2, 6, 4), 54: (1, 4, 4), 55: (1, 5, 4), 56: (2, 4, 4), 57: (3, 6, 4), 58: (3, 3, 4), 71: (7, 2, 5), 72: (8, 2, 5), 73: (9, 2, 5), 74: (10, 2, 5)}
 
     def kname(k):
         if k == 135:

@@ -78,6 +78,16 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   }
   const int tm = cdiv(p.M, BM), tn = cdiv(p.N, BN);
   size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+  // wide wave tiles (256x288 = 4 waves of 64 x 288; gemm2_body.h SBLO): dense operands, the plain epilogue (bias, SiLU / GELU, fp32 or split rows),
+  // four 32 x 288 slabs + the bias tile in LDS behind the K loop
+  constexpr bool WIDE = PIPE == 5 && (BM / (WM * 32)) * (BN / (WN * 32)) > 16;
+  if (WIDE) {
+    RGM_REQUIRE(!p.aload && !p.gate && !p.res && !p.stats && !p.aux && !p.C2 && p.act < 3 && !p.ln_out && ((p.N | p.ldc) & 7) == 0 &&
+                (((uintptr_t)p.C | (uintptr_t)p.bias) & 15) == 0,
+                "gemm2: the %dx%d tile takes dense operands and the plain epilogue (bias, SiLU / GELU, fp32 or split rows; N %% 8 == 0)", BM, BN);
+    const size_t epi = (size_t)WM * WN * 32 * (BN / WN) * 4 + (size_t)BN * 4;
+    if (epi > lds) lds = epi;
+  }
   // (measured, round 5: XL-28 forward at B = 2 / 3 / 4 / 6 / 8 4.10 / 4.73 / 5.30 / 6.34 / 7.86 ms without, 4.22 / 4.69 / 5.29 / 6.60 / 7.82 with a
   // distance of 8 -- unlike the 144-column kernel, whose loaders were the in-situ bottleneck, these tiles do not gain: off)
   static const int p4_pf = getenv("RGM_P4_PF") ? atoi(getenv("RGM_P4_PF")) : 0;
@@ -86,8 +96,8 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   const size_t lds_attr = (PIPE == 4 && (size_t)NSTAGE * (BM + BN) * 128 + 1024 <= 160 * 1024) ? (size_t)NSTAGE * (BM + BN) * 128 + 1024 : lds;   // the attribute is set once
   static bool attr0 = false, attr1 = false;
   auto k0 = gemm2_kernel<BM, BN, WM, WN, 0, NSTAGE, 0, PIPE>;
-  auto k1 = gemm2_kernel<BM, BN, WM, WN, PIPE == 4 ? 0 : 1, NSTAGE, 0, PIPE>;
-  auto k2 = gemm2_kernel<BM, BN, WM, WN, PIPE == 5 ? 2 : 0, NSTAGE, 0, PIPE>;   // implicit conv with channel-block-major K (PIPE 5 only)
+  auto k1 = gemm2_kernel<BM, BN, WM, WN, (PIPE == 4 || WIDE) ? 0 : 1, NSTAGE, 0, PIPE>;
+  auto k2 = gemm2_kernel<BM, BN, WM, WN, (PIPE == 5 && !WIDE) ? 2 : 0, NSTAGE, 0, PIPE>;   // implicit conv with channel-block-major K (PIPE 5 only)
   RGM_REQUIRE(!p.conv_kmajor || (p.aload == 1 && p.Cin % 32 == 0), "gemm2: conv_kmajor is a property of the implicit 3x3 conv (aload == 1)");
   RGM_REQUIRE(PIPE != 4 || p.aload == 0, "gemm2: the loader/consumer kernels take dense operands only");
   if (lds_attr > 65536) {
@@ -148,7 +158,7 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
     }
     hipLaunchKernelGGL(kd, grid, block, lds, s, pr, (const char*)g_zero_page, tm, tn, g_exp, g_dbg);
   } else if (PIPE == 5 && p.conv_kmajor && g_dbg) {          // the channel-block-major conv of the one-wave-per-SIMD kernels (tools/conv_stamp.py)
-    auto kd = gemm2_kernel<BM, BN, WM, WN, PIPE == 5 ? 2 : 0, NSTAGE, 1, PIPE>;
+    auto kd = gemm2_kernel<BM, BN, WM, WN, (PIPE == 5 && !WIDE) ? 2 : 0, NSTAGE, 1, PIPE>;
     static bool attrd2 = false;
     if (lds > 65536 && !attrd2) {
       RGM_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -376,6 +386,18 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
 
                       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 &&
                       (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0;
+  // ---- 256x288 tiles (tile 74, round 6): N = 4608 = 16 x 288 -- fc1 of DiT-XL -- at M = 4096 is ONE round of 256 of them where the 256x256
+  // tiling needs 288 (a 16 x 16 main launch + 512 columns on 128x64 tiles: 93 + 23 us in the C2 forward).  Taken when the grid is a full round
+  // (at least 224 tiles, at most 256), every tile is whole and the epilogue is the plain one.  RGM_T288=0: off (A/B runs).
+  static const int g_t288 = getenv("RGM_T288") ? atoi(getenv("RGM_T288")) : 1;
+  if (big_ok && g_t288 && (!p.co_sched || g_t288 == 2) && !p.gate && !p.res && !p.C2 && !p.ln_out && p.M % 256 == 0 && p.N % 288 == 0 && (p.ldc & 7) == 0) {
+    const long long t288 = (long long)(p.M / 256) * (p.N / 288), t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256);
+    if (t288 >= 224 && t288 <= 256 && t256 > 256) {
+      GemmParams q = p;
+      q.tile = 74;
+      return gemm2_launch(q, s);
+    }
+  }
   if (big_ok && p.co_sched) {
     // Two half batches in flight (dit.hip): the other stream's kernels fill the CUs a partial round leaves, so what counts is the work per
     // tile, not the fill of the launch's last round.  Whole GEMM on 256x256 tiles from g_co_min tiles up (no column split: fc1's 288 tiles
@@ -593,6 +615,7 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
     case 71: return launch2<256, 256, 2, 2, 2, 5>(p, s, 71);   // 128 KB: 1 per CU, 512 registers
     case 73: return launch2<128, 256, 1, 4, 2, 5>(p, s, 73);   // 96 KB: 128x64 wave tiles, for M of a few thousand rows (B = 8: the shapes B = 16 has at 256 rows)
     case 81: return gemm144_launch(p, s);                     // gemm144.hip: 128x144 tiles on 16x16x32 MFMAs (N % 144 == 0)
+    case 74: return launch2<256, 288, 4, 1, 2, 5>(p, s, 74);   // 145 KB: 64x288 wave tiles (288 accumulator registers) -- fc1 of DiT-XL at M = 4096 as ONE round of 256 tiles
     case 72: return launch2<512, 128, 4, 1, 2, 5>(p, s, 72);   // 160 KB (all of the LDS): the same 128x128 wave tiles for N = 128 (VAE convs at 128 channels)
     default: break;
   }

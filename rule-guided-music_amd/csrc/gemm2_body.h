@@ -363,17 +363,52 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
     // MFMA slots per read / DMA piece: 3 for the 128x128 wave tile (48 MFMAs a phase, 16 reads, 16-20 pieces), 2 for 128x64 (24 / 12 / 12)
     constexpr int EV = (NRD * 3 <= NM && SPW * 3 <= 2 * NM) ? 3 : 2;
     static_assert(NRD * EV <= NM && (EV == 3 ? SPW * 3 <= 2 * NM : SPW * 2 <= NM), "reads and DMA pieces must fit the MFMA slots of a phase");
-    struct FragsK {
-      bf16x8 a[TM][2], b[TN][2];                          // [frag][hi, lo] of one k16 step
+    // SBLO (wave tiles of more than 16 accumulator tiles: the 64 x 288 wave tile of the 256x288 workgroup tile, 288 accumulator registers):
+    // two full fragment sets (2 x 88 registers) do not fit beside them.  Term t of a k16 step multiplies  t = 0: a.lo x b.hi,  t = 1: a.hi x b.lo,
+    // t = 2: a.hi x b.hi  (t-major), so a.lo is dead after the first third of a phase and b.lo after the second: only the hi halves are
+    // double-buffered, the next step's lo halves are read into the SAME registers once their term is behind (as gemm144.hip does).
+    constexpr bool SBLO = TM * TN > 16;
+    static_assert(!SBLO || ALOAD == 0, "the wide wave tiles take dense operands only");
+    // 18 accumulator tiles are 288 registers: 256 of them ARE the AGPRs, the last two tiles live in VGPRs.  Left to the allocator the loop
+    // shuffled accumulators between the two files (1072 v_accvgpr moves + 205 scratch accesses per K-tile): the MFMAs of this path are
+    // asm statements whose constraint names the file of each accumulator.
+    auto mfma_pin = [&](auto ag_c, f32x16& c, const bf16x8& a, const bf16x8& b) __attribute__((always_inline)) {
+#ifdef RGM_SPLIT_F16
+      if constexpr (decltype(ag_c)::value) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
+      if constexpr (decltype(ag_c)::value) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
     };
+    struct FragsK {
+      bf16x8 a[TM][SBLO ? 1 : 2], b[TN][SBLO ? 1 : 2];    // [frag][hi, lo] of one k16 step (SBLO: hi only)
+    };
+    bf16x8 alo[SBLO ? TM : 1], blo[SBLO ? TN : 1];        // SBLO: the single set of lo halves
     auto read_one = [&](FragsK& f, const char* As, auto stc, auto jc) {
       constexpr int st = decltype(stc)::value, j = decltype(jc)::value;
+      if constexpr (SBLO) {
+        // read index j: 0 .. TM + TN - 1 the hi halves (A then B), then the TM a.lo, then the TN b.lo
+        constexpr int lo = j >= TM + TN ? 1 : 0;
+        constexpr int fi = lo ? j - (TM + TN) : j;
+        const int chunk = ((4 * lo + 2 * st + hh) ^ rq) << 4;
+        if constexpr (fi < TM) {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(As + (arow0 + fi * 32 + l31) * 128 + chunk);
+          if constexpr (lo) alo[fi] = v;
+          else f.a[fi][0] = v;
+        } else {
+          const bf16x8 v = *reinterpret_cast<const bf16x8*>(As + BM * 128 + (bcol0 + (fi - TM) * 32 + l31) * 128 + chunk);
+          if constexpr (lo) blo[fi - TM] = v;
+          else f.b[fi - TM][0] = v;
+        }
+      } else {
       constexpr int fi = j / 2, lo = j % 2;
       const int chunk = ((4 * lo + 2 * st + hh) ^ rq) << 4;
       if constexpr (fi < TM) {
         f.a[fi][lo] = *reinterpret_cast<const bf16x8*>(As + (arow0 + fi * 32 + l31) * 128 + chunk);
       } else {
         f.b[fi - TM][lo] = *reinterpret_cast<const bf16x8*>(As + BM * 128 + (bcol0 + (fi - TM) * 32 + l31) * 128 + chunk);
+      }
       }
     };
     // ALOAD == 2: the A pieces of a K-tile (tap, kc) point at line kc of the tap's neighbour pixel, or at the zero page
@@ -438,8 +473,26 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         constexpr int m = decltype(mc)::value;
         constexpr int t = m / (TM * TN), im = (m % (TM * TN)) / TN, in = m % TN;
         // per accumulator the term order stays al*bh, ah*bl, ah*bh (same rounding sequence as the other kernels)
+        if constexpr (SBLO) {
+          using AG = std::integral_constant<bool, (im * TN + in) < 16>;      // the first 16 accumulator tiles: AGPRs
+          if constexpr (t == 0) mfma_pin(AG{}, acc[im][in], alo[im], cur.b[in][0]);
+          if constexpr (t == 1) mfma_pin(AG{}, acc[im][in], cur.a[im][0], blo[in]);
+          if constexpr (t == 2) mfma_pin(AG{}, acc[im][in], cur.a[im][0], cur.b[in][0]);
+          // reads of the next step at the even MFMA slots: the hi halves from slot 0 on, a.lo behind term 0 (slot TM * TN / 2 + ...), b.lo
+          // behind term 1 -- each into registers whose last reader has issued
+          if constexpr (READ && m % 2 == 0) {
+            constexpr int sl = m / 2;
+            constexpr int S_ALO = (TM * TN + 1) / 2 > TM + TN ? (TM * TN + 1) / 2 : TM + TN;      // first slot at or behind the end of term 0
+            constexpr int S_BLO = TM * TN;                                                       // slot 2 TM TN / 2: the end of term 1
+            static_assert(S_ALO + TM <= S_BLO && S_BLO + TN <= (NM + 1) / 2, "the lo reads must fit behind their terms");
+            if constexpr (sl < TM + TN) read_one(nxt, rd, stnc, std::integral_constant<int, sl>{});
+            else if constexpr (sl >= S_ALO && sl < S_ALO + TM) read_one(nxt, rd, stnc, std::integral_constant<int, TM + TN + (sl - S_ALO)>{});
+            else if constexpr (sl >= S_BLO && sl < S_BLO + TN) read_one(nxt, rd, stnc, std::integral_constant<int, 2 * TM + TN + (sl - S_BLO)>{});
+          }
+        } else {
         acc[im][in] = RGM_MFMA_SPLIT_32x32x16(cur.a[im][t == 0 ? 1 : 0], cur.b[in][t == 1 ? 1 : 0], acc[im][in], 0, 0, 0);
         if constexpr (READ && m % EV == 0 && m / EV < NRD) read_one(nxt, rd, stnc, std::integral_constant<int, m / EV>{});
+        }
         if constexpr (AIM && EV == 3) {
           if constexpr (m % 3 == 1 && m / 3 < APIECES) aim_a(std::integral_constant<int, m / 3>{}, aim);
           if constexpr (m % 3 == 2 && m / 3 < APIECES) aim_b(std::integral_constant<int, m / 3>{}, aim);
@@ -806,6 +859,98 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
   const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
   const float* auxb = p.aux ? p.aux + (long long)z * p.sAux : nullptr;   // act 3 / 4: pre-activation whose derivative multiplies the result
+  if constexpr (PIPE == 5 && TN * 32 > 256) {
+    // ---- wide wave tiles (64 x 288: the 256x288 workgroup tile, fc1 of DiT-XL at M = 4096 as ONE round of 256 tiles).  The plain epilogue only
+    // (bias, SiLU / GELU, fp32 or split rows -- launch2 checks): a wave's 32-row slab is 288 columns = 36 units of 8 columns, more than one
+    // wave-row of lanes, so the slab is walked linearly -- unit u = lane + 64 k is row u / 36, columns 8 (u % 36) .. + 7 -- with the bias tile
+    // in LDS (a per-iteration global load would queue behind the previous iteration's stores: one vmcnt).
+    static_assert(NW * 32 * TN * 32 * 4 + BN * 4 <= 160 * 1024, "wide epilogue: four slabs + the bias tile must fit the LDS");
+    constexpr int WCOLS = TN * 32, UPR = WCOLS / 8, UNITS = 32 * UPR, KIT = UNITS / 64;
+    static_assert(UNITS % 64 == 0, "a slab is a whole number of wave-instructions");
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));                              // (as below: lane coordinates re-derived behind an opaque copy)
+    const int lane = tid_e & 63, l31 = tid_e & 31, hh = (tid_e >> 5) & 1;
+    float* stg = reinterpret_cast<float*>(ring) + wave * (32 * WCOLS);
+    float* bias_l = reinterpret_cast<float*>(ring) + NW * 32 * WCOLS;
+    __syncthreads();                                             // every wave is done reading the last stage
+    for (int c = tid_e; c < BN / 4; c += NW * 64) {
+      float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (biasb && n0 + 4 * c < p.N) b4 = ldg16(biasb + n0 + 4 * c);
+      *reinterpret_cast<float4*>(bias_l + 4 * c) = b4;
+    }
+    __syncthreads();
+    typedef split_t bf16x8_t __attribute__((ext_vector_type(8)));
+    auto wide_rows = [&](auto act_c, auto split_c, const float* slab, int row_base) {
+      constexpr int ACT = decltype(act_c)::value;
+      constexpr bool SPLIT = decltype(split_c)::value != 0;
+      constexpr int U8 = 2;
+      static_assert(KIT % U8 == 0, "unroll");
+#pragma unroll 1
+      for (int k0 = 0; k0 < KIT; k0 += U8) {
+        float4 a8[U8][2], b8[U8][2];
+        int rows[U8], cols[U8];
+#pragma unroll
+        for (int u = 0; u < U8; ++u) {
+          const int unit = lane + 64 * (k0 + u);
+          const int r = unit / UPR, c8 = (unit - r * UPR) * 8;
+          rows[u] = row_base + r;
+          cols[u] = c8;
+          const float* sp = slab + r * WCOLS + c8;
+          a8[u][0] = *reinterpret_cast<const float4*>(sp);
+          a8[u][1] = *reinterpret_cast<const float4*>(sp + 4);
+          b8[u][0] = *reinterpret_cast<const float4*>(bias_l + bcol0 + c8);
+          b8[u][1] = *reinterpret_cast<const float4*>(bias_l + bcol0 + c8 + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U8; ++u) {
+          const int row = rows[u], col8 = n0 + bcol0 + cols[u];
+          if (row < p.M && col8 < p.N) {
+            float v[8] = {a8[u][0].x * p.alpha + b8[u][0].x, a8[u][0].y * p.alpha + b8[u][0].y, a8[u][0].z * p.alpha + b8[u][0].z,
+                          a8[u][0].w * p.alpha + b8[u][0].w, a8[u][1].x * p.alpha + b8[u][1].x, a8[u][1].y * p.alpha + b8[u][1].y,
+                          a8[u][1].z * p.alpha + b8[u][1].z, a8[u][1].w * p.alpha + b8[u][1].w};
+#pragma unroll
+            for (int q8 = 0; q8 < 8; ++q8) v[q8] = ACT == 1 ? silu_f(v[q8]) : (ACT == 2 ? gelu_tanh_fast_f(v[q8]) : v[q8]);
+            if constexpr (SPLIT) {
+              bf16x8_t hi, lo;
+#pragma unroll
+              for (int q8 = 0; q8 < 8; ++q8) {
+                hi[q8] = (split_t)v[q8];
+                lo[q8] = (split_t)(v[q8] - (float)hi[q8]);
+              }
+              split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
+              __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8)));
+              __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8) + 32));
+            } else {
+              const f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
+              __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(Cb + (long long)row * p.ldc + col8));
+              __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(Cb + (long long)row * p.ldc + col8 + 4));
+            }
+          }
+        }
+      }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    static_for<0, TM>([&](auto im_c) {
+      constexpr int im = decltype(im_c)::value;
+      static_for<0, TN>([&](auto in_c) {
+        constexpr int in = decltype(in_c)::value;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) stg[((e & 3) + 8 * (e >> 2) + 4 * hh) * WCOLS + in * 32 + l31] = acc[im][in][e];
+      });
+      const int row_base = m0 + arow0 + im * 32;
+      if (p.out_split) {
+        if (p.act == 0) wide_rows(I0{}, I1{}, stg, row_base);
+        else if (p.act == 1) wide_rows(I1{}, I1{}, stg, row_base);
+        else wide_rows(I2{}, I1{}, stg, row_base);
+      } else {
+        if (p.act == 0) wide_rows(I0{}, I0{}, stg, row_base);
+        else if (p.act == 1) wide_rows(I1{}, I0{}, stg, row_base);
+        else wide_rows(I2{}, I0{}, stg, row_base);
+      }
+    });
+  } else {
   const bool vec = vector_epilogue();
   // ---- epilogue (C/D layout: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)); optional split output
   // Vector path: the accumulators of one 32-row slab go through the (now idle) LDS ring so that every lane owns 4
@@ -1452,6 +1597,7 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
       }
     });
   });
+  }   // narrow wave tiles
   if (DBG) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
