@@ -387,12 +387,15 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
                       ((p.N | p.ldc | p.ldres | p.gate_ld) & 3) == 0 &&
                       (((uintptr_t)p.C | (uintptr_t)p.res | (uintptr_t)p.bias | (uintptr_t)p.gate) & 15) == 0;
   // ---- 256x288 tiles (tile 74, round 6): N = 4608 = 16 x 288 -- fc1 of DiT-XL -- at M = 4096 is ONE round of 256 of them where the 256x256
-  // tiling needs 288 (a 16 x 16 main launch + 512 columns on 128x64 tiles: 93 + 23 us in the C2 forward).  Taken when the grid is a full round
-  // (at least 224 tiles, at most 256), every tile is whole and the epilogue is the plain one.  RGM_T288=0: off (A/B runs).
-  static const int g_t288 = getenv("RGM_T288") ? atoi(getenv("RGM_T288")) : 1;
-  if (big_ok && g_t288 && (!p.co_sched || g_t288 == 2) && !p.gate && !p.res && !p.C2 && !p.ln_out && p.M % 256 == 0 && p.N % 288 == 0 && (p.ldc & 7) == 0) {
+  // tiling needs 288 (a 16 x 16 main launch + 512 columns on 128x64 tiles: 93 + 23 us in the C2 forward).  Taken when the grid is a FULL round
+  // (250 .. 256 tiles: at B = 15, 240 tiles, it measured behind -- 11.54 against 11.48 ms), every tile is whole and the epilogue is the plain one;
+  // also for each of two half batches in flight (B = 32: C3 26.95 -> 26.80 ms same box).  Same-box C2: 11.59 -> 11.34 ms
+  // (profiles/r06_c2_tile288_ab.txt).  RGM_T288: bit 0 single stream, bit 1 beside a second stream's launches; 0 = off (A/B runs).
+  static const int g_t288 = getenv("RGM_T288") ? atoi(getenv("RGM_T288")) : 3;
+  if (big_ok && (p.co_sched ? (g_t288 & 2) : (g_t288 & 1)) && !p.gate && !p.res && !p.C2 && !p.ln_out && p.M % 256 == 0 && p.N % 288 == 0 &&
+      (p.ldc & 7) == 0) {
     const long long t288 = (long long)(p.M / 256) * (p.N / 288), t256 = (long long)cdiv(p.M, 256) * cdiv(p.N, 256);
-    if (t288 >= 224 && t288 <= 256 && t256 > 256) {
+    if (t288 >= 250 && t288 <= 256 && t256 > 256) {
       GemmParams q = p;
       q.tile = 74;
       return gemm2_launch(q, s);
