@@ -290,7 +290,7 @@ def roofline_pass(work, steps=2):
 
     def kname(k):
         if k == 135:
-            return "gemm144_kernel<4>"          # csrc/gemm144.hip: 128x144 tiles on 16x16x32 MFMAs (tile 81)
+            return "gemm144_kernel<4,0,0,8>"    # csrc/gemm144.hip: 128x144 tiles on 16x16x32 MFMAs (tile 81; NSTAGE 4, L2 prefetch distance 8 -- the name rocprofv3 reports)
         if k < 40:
             return f"gemm_kernel<{tiles[k % 10]},{(k // 10) % 2},{k // 20}>"
         t = k - 40

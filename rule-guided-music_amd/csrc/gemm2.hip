@@ -80,7 +80,7 @@ static int launch2(const GemmParams& p, hipStream_t s, int tile_id) {
   size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
   // wide wave tiles (256x288 = 4 waves of 64 x 288; gemm2_body.h SBLO): dense operands, the plain epilogue (bias, SiLU / GELU, fp32 or split rows),
   // four 32 x 288 slabs + the bias tile in LDS behind the K loop
-  constexpr bool WIDE = PIPE == 5 && (BM / (WM * 32)) * (BN / (WN * 32)) > 16;
+  constexpr bool WIDE = PIPE == 5 && ((BM / (WM * 32)) * (BN / (WN * 32)) > 16 || 64 % ((BN / (WN * 32)) * 8) != 0);   // (gemm2_body.h: the linear slab epilogue)
   if (WIDE) {
     RGM_REQUIRE(!p.aload && !p.gate && !p.res && !p.stats && !p.aux && !p.C2 && p.act < 3 && !p.ln_out && ((p.N | p.ldc) & 7) == 0 &&
                 (((uintptr_t)p.C | (uintptr_t)p.bias) & 15) == 0,
@@ -401,6 +401,8 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
       return gemm2_launch(q, s);
     }
   }
+  // (256x224 tiles for qkv -- N = 3456 at M = 4096 as 16 x 16 = 256 tiles instead of 224 of 256x256 with 32 CUs idle -- were built, bit-identical, and
+  // measured BEHIND: C2 11.83 -> 11.90 ms, C3 27.14 -> 27.36 same box, profiles/r06_c2_tile224_ab.txt; removed)
   if (big_ok && p.co_sched) {
     // Two half batches in flight (dit.hip): the other stream's kernels fill the CUs a partial round leaves, so what counts is the work per
     // tile, not the fill of the launch's last round.  Whole GEMM on 256x256 tiles from g_co_min tiles up (no column split: fc1's 288 tiles

@@ -859,11 +859,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   const float* resb = p.res ? p.res + (long long)z * p.sRes : nullptr;
   const float* biasb = p.bias ? p.bias + (long long)z * p.sBias : nullptr;
   const float* auxb = p.aux ? p.aux + (long long)z * p.sAux : nullptr;   // act 3 / 4: pre-activation whose derivative multiplies the result
-  if constexpr (PIPE == 5 && TN * 32 > 256) {
-    // ---- wide wave tiles (64 x 288: the 256x288 workgroup tile, fc1 of DiT-XL at M = 4096 as ONE round of 256 tiles).  The plain epilogue only
-    // (bias, SiLU / GELU, fp32 or split rows -- launch2 checks): a wave's 32-row slab is 288 columns = 36 units of 8 columns, more than one
-    // wave-row of lanes, so the slab is walked linearly -- unit u = lane + 64 k is row u / 36, columns 8 (u % 36) .. + 7 -- with the bias tile
-    // in LDS (a per-iteration global load would queue behind the previous iteration's stores: one vmcnt).
+  if constexpr (PIPE == 5 && (TN * 32 > 256 || 64 % (TN * 8) != 0)) {
+    // ---- wave tiles whose rows are not a power-of-two number of lanes (64 x 288: the 256x288 workgroup tile, fc1 of DiT-XL at M = 4096 as ONE round
+    // of 256 tiles; 64 x 224: the 256x224 tile, qkv likewise).  The plain epilogue only (bias, SiLU / GELU, fp32 or split rows -- launch2 checks):
+    // a wave's 32-row slab is WCOLS / 8 = 36 (28) units of 8 columns per row, so the slab is walked linearly -- unit u = lane + 64 k is row
+    // u / 36, columns 8 (u % 36) .. + 7 -- with the bias tile in LDS (a per-iteration global load would queue behind the previous iteration's
+    // stores: one vmcnt).
     static_assert(NW * 32 * TN * 32 * 4 + BN * 4 <= 160 * 1024, "wide epilogue: four slabs + the bias tile must fit the LDS");
     constexpr int WCOLS = TN * 32, UPR = WCOLS / 8, UNITS = 32 * UPR, KIT = UNITS / 64;
     static_assert(UNITS % 64 == 0, "a slab is a whole number of wave-instructions");
