@@ -17,6 +17,7 @@
 #include "common.h"
 
 namespace rgm {
+void gemm2_prof_set_bytes(int idx, double bytes);      // gemm2.hip
 namespace {
 
 typedef split_t bf16x8 __attribute__((ext_vector_type(8)));
@@ -417,6 +418,8 @@ int gemm144_launch(const GemmParams& p, hipStream_t s) {
     return RGM_OK;
   }
   const int pi = gemm2_prof_begin(135, 2.0 * p.M * (double)p.N * p.K * p.batch, s);
+  // A once, B once, C once (+ the residual it is added to): what bench.py prices the in-situ HBM traffic against
+  gemm2_prof_set_bytes(pi, 4.0 * ((double)p.M * p.K * p.batch + (double)p.N * p.K * p.batch + (double)p.M * p.N * p.batch * (p.res ? 2.0 : 1.0)));
   hipLaunchKernelGGL(k, dim3((unsigned)(tm * tn), 1, (unsigned)p.batch), dim3(512), lds, s, pr, (const char*)g_zero144, tm, tn, (long long*)nullptr, pf_on >> 1);
   gemm2_prof_end(pi, s);
   RGM_LAUNCH_CHECK();

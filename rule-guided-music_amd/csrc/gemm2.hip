@@ -676,6 +676,9 @@ int gemm2_prof_begin(int id, double flops, hipStream_t s) {
   g2_prof.push_back(rec);
   return (int)g2_prof.size() - 1;
 }
+void gemm2_prof_set_bytes(int idx, double bytes) {      // algorithmic bytes of the launch (rgm_prof_bytes)
+  if (idx >= 0 && idx < (int)g2_prof.size()) g2_prof[idx].bytes = bytes;
+}
 void gemm2_prof_end(int idx, hipStream_t s) {
   if (idx >= 0 && idx < (int)g2_prof.size()) (void)hipEventRecord(g2_prof[idx].b, s);
 }

@@ -919,12 +919,25 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
                 lo[q8] = (split_t)(v[q8] - (float)hi[q8]);
               }
               split_t* rowp = reinterpret_cast<split_t*>(Cb + (long long)row * p.ldc);
-              __builtin_nontemporal_store(hi, reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8)));
-              __builtin_nontemporal_store(lo, reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8) + 32));
+              bf16x8_t* dh = reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8));
+              bf16x8_t* dl = reinterpret_cast<bf16x8_t*>(rowp + split_idx(col8) + 32);
+              if (p.st_plain) {                                   // (A/B runs: RGM_ST_PLAIN, launch2)
+                *dh = hi;
+                *dl = lo;
+              } else {
+                __builtin_nontemporal_store(hi, dh);
+                __builtin_nontemporal_store(lo, dl);
+              }
             } else {
               const f32x4 v0 = {v[0], v[1], v[2], v[3]}, v1 = {v[4], v[5], v[6], v[7]};
-              __builtin_nontemporal_store(v0, reinterpret_cast<f32x4*>(Cb + (long long)row * p.ldc + col8));
-              __builtin_nontemporal_store(v1, reinterpret_cast<f32x4*>(Cb + (long long)row * p.ldc + col8 + 4));
+              f32x4* d0 = reinterpret_cast<f32x4*>(Cb + (long long)row * p.ldc + col8);
+              if (p.st_plain) {
+                d0[0] = v0;
+                d0[1] = v1;
+              } else {
+                __builtin_nontemporal_store(v0, d0);
+                __builtin_nontemporal_store(v1, d0 + 1);
+              }
             }
           }
         }
