@@ -1,5 +1,6 @@
 """-m gpu: round-6 additions -- the chord analyser beside the GPU (reference guided_diffusion/gaussian_diffusion.py:1363-1375
 blocks the step on pool.map) and the exact-fp32 final decode (reference guided_diffusion/midi_util.py:42-64)."""
+import os
 import time
 from types import SimpleNamespace
 
@@ -186,3 +187,31 @@ def test_256x288_tiles_equal_the_256x256_kernel_bit_for_bit(M, N, K, wide):
             assert torch.equal(h2.view(torch.int32), outs[wide][1].view(torch.int32))
     finally:
         R.set_gemm_precision("fp32")
+
+
+@pytest.mark.parametrize("workers", [0, 2])
+def test_cli_with_a_chord_analyser_runs_the_reference_config_whole(tmp_path, monkeypatch, workers):
+    """scripts/sample_rule.py on cond_table/all/scg_classifier_all.yml AS SHIPPED BY THE REFERENCE -- three classifiers (pitch, note density, chords) AND
+    SCG over three rules incl. chord_progression -- with an analyser registered through --chord_backend (a stand-in with the reference's
+    piano_roll_to_chords signature; music21 is not installable here): the chord rule is scored beside the GPU in every search step (in this process and in
+    the spawn-context worker pool), nothing is dropped, the report carries the chord columns."""
+    import json
+    import pandas as pd
+    from music_rule_guidance import music_rules
+    from test_gpu_cli import CFG, COMMON, _cli
+    monkeypatch.chdir(tmp_path)
+    cli = _cli()
+    cfg = os.path.join(CFG, "cond_table/all/scg_classifier_all.yml")
+    try:
+        res = cli.main(["--config_path", cfg, "--batch_size", "2", "--num_samples", "2", "--diffusion_steps", "25", "--chord_backend",
+                        "gpu_util:fake_chord_backend", "--chord_workers", str(workers)] + COMMON)
+    finally:
+        music_rules.register_chord_backend(None)
+    out_dir = os.path.join("loggings", cli.output_dir_for(cfg, 1))
+    meta = json.load(open(os.path.join(out_dir, "run_metadata.json")))
+    assert not meta["dropped_rules"]
+    df = pd.read_csv(os.path.join(out_dir, "results.csv"))
+    assert len(df) == 2 and len(res) == 2
+    for r in ("pitch_hist", "note_density", "chord_progression"):
+        assert {f"{r}.target_rule", f"{r}.gen_rule", f"{r}.loss"} <= set(df.columns), df.columns
+        assert np.isfinite(df[f"{r}.loss"]).all()
