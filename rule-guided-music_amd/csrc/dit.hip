@@ -587,9 +587,11 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
         g_attn_co_sched = 0;
         RGM_TRY(attn_rc);
         RGM_TRY(release(i, k, 2));
-        RGM_TRY(lin2(ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x, D, D, 0, 0, m + 2 * D, x, 0));
+        // (a K-sliced proj -- small batches, gemm2.hip g_t144 bit 16 -- writes the block's second adaLN-LayerNorm from its reduce kernel)
+        int ln2_done = 0;
+        RGM_TRY(lin2(ao, b + "attn.proj.weight", h->p(b + "attn.proj.bias"), x, D, D, 0, 0, m + 2 * D, x, 0, m + 3 * D, &ln2_done));
         RGM_TRY(release(i, k, 3));
-        RGM_TRY(layernorm_modulate_launch(x, xm, Mq, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, q.st, 1));
+        if (!ln2_done) RGM_TRY(layernorm_modulate_launch(x, xm, Mq, D, 1e-6f, nullptr, nullptr, m + 3 * D, m + 4 * D, L, T, q.st, 1));
         RGM_TRY(release(i, k, 4));
         RGM_TRY(lin2(xm, b + "mlp.fc1.weight", h->p(b + "mlp.fc1.bias"), hid, 4 * D, D, (dit_exp & 1) ? 0 : 2, (dit_exp & 1) ? 0 : 1, nullptr, nullptr,
                      RGM_EXP_ENV("RGM_FC1_TILE")));

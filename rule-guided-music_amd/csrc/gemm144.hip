@@ -52,7 +52,11 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     return t;
   };
-  if (DBG) t_entry = now();
+  unsigned long long rt_entry = 0;
+  if (DBG) {
+    t_entry = now();
+    rt_entry = __builtin_amdgcn_s_memrealtime();
+  }
   const int z = blockIdx.z;
   // XCD-contiguous raster, row tiles fastest: an XCD's tiles are a few column panels of B (weights: read once, by one L2) x all row tiles
   const int bid = blockIdx.x, nb = tiles_m * tiles_n;
@@ -359,9 +363,18 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
     tacc[7] = KT;
     if (blockIdx.x == gridDim.x / 2 && blockIdx.z == 0 && lane == 0)
       for (int i = 0; i < 8; ++i) dbg[wave * 8 + i] = (long long)tacc[i];
+    // every workgroup (first 4096 of z = 0): entry and exit in shader cycles and on the 100 MHz wall clock, K loop, epilogue
+    if (wave == 0 && lane == 0 && blockIdx.z == 0 && blockIdx.x < 4096) {
+      long long* w = dbg + 64 + 8 * blockIdx.x;
+      const unsigned long long rt = __builtin_amdgcn_s_memrealtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      w[0] = (long long)t_entry; w[1] = (long long)now(); w[2] = (long long)rt_entry; w[3] = (long long)rt;
+      w[4] = (long long)tacc[1]; w[5] = (long long)tacc[3]; w[6] = (long long)tacc[2]; w[7] = bid;
+    }
   }
 }
 
+constexpr size_t DBG_SLOTS = 64 + 8 * 4096;
 char* g_zero144 = nullptr;
 long long* g_dbg144 = nullptr;
 }  // namespace
@@ -405,11 +418,11 @@ int gemm144_launch(const GemmParams& p, hipStream_t s) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kd), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       hipLaunchKernelGGL(kd, dim3((unsigned)(tm * tn), 1, (unsigned)p.batch), dim3(512), lds, s, pr, (const char*)g_zero144, tm, tn, g_dbg144, pf_on >> 1);
     };
-    switch (exp) {
-      case 1: launch_dbg(gemm144_kernel<NSTAGE, 1, 1>); break;
-      case 2: launch_dbg(gemm144_kernel<NSTAGE, 1, 2>); break;
-      case 4: launch_dbg(gemm144_kernel<NSTAGE, 1, 4>); break;
-      case 7: launch_dbg(gemm144_kernel<NSTAGE, 1, 7>); break;
+    switch (exp) {            // (with the L2 prefetch, as the product kernel runs)
+      case 1: launch_dbg(gemm144_kernel<NSTAGE, 1, 1, PFD>); break;
+      case 2: launch_dbg(gemm144_kernel<NSTAGE, 1, 2, PFD>); break;
+      case 4: launch_dbg(gemm144_kernel<NSTAGE, 1, 4, PFD>); break;
+      case 7: launch_dbg(gemm144_kernel<NSTAGE, 1, 7, PFD>); break;
       default:
         if (pf_on) launch_dbg(gemm144_kernel<NSTAGE, 1, 0, PFD>);
         else launch_dbg(gemm144_kernel<NSTAGE, 1, 0>);
@@ -431,12 +444,12 @@ int gemm144_launch(const GemmParams& p, hipStream_t s) {
 extern "C" int rgm_gemm144_dbg(int mode, long long* out64) {
   using namespace rgm;
   if (mode == 1) {
-    if (!g_dbg144) RGM_CHECK_HIP(hipMalloc(&g_dbg144, 64 * sizeof(long long)));
-    RGM_CHECK_HIP(hipMemset(g_dbg144, 0, 64 * sizeof(long long)));
-  } else if (mode == 2) {
+    if (!g_dbg144) RGM_CHECK_HIP(hipMalloc(&g_dbg144, DBG_SLOTS * sizeof(long long)));
+    RGM_CHECK_HIP(hipMemset(g_dbg144, 0, DBG_SLOTS * sizeof(long long)));
+  } else if (mode == 2 || mode == 3) {           // 3: + 8 slots per workgroup (the first 4096): 64 + 8 x 4096 values
     RGM_REQUIRE(g_dbg144 && out64, "gemm144_dbg: not armed");
     RGM_CHECK_HIP(hipDeviceSynchronize());
-    RGM_CHECK_HIP(hipMemcpy(out64, g_dbg144, 64 * sizeof(long long), hipMemcpyDeviceToHost));
+    RGM_CHECK_HIP(hipMemcpy(out64, g_dbg144, (mode == 3 ? DBG_SLOTS : 64) * sizeof(long long), hipMemcpyDeviceToHost));
   } else {
     if (g_dbg144) (void)hipFree(g_dbg144);
     g_dbg144 = nullptr;

@@ -294,7 +294,7 @@ static int splitk_factor(const GemmParams& p) {
   return best;
 }
 
-static int g_t144 = getenv("RGM_T144") ? atoi(getenv("RGM_T144")) : 15;   // which grids take the 128x144 tiles (bit mask, gemm2_launch)
+static int g_t144 = getenv("RGM_T144") ? atoi(getenv("RGM_T144")) : 31;   // which grids take the 128x144 tiles (bit mask, gemm2_launch)
 static int g_co_min = getenv("RGM_CO_MIN_TILES") ? atoi(getenv("RGM_CO_MIN_TILES")) : 100;   // co-scheduled launches (GemmParams::co_sched)
 static int g_co_kt = getenv("RGM_CO_KT") ? atoi(getenv("RGM_CO_KT")) : 36;
 static int g_fuse_reduce_ln = getenv("RGM_FUSE_REDUCE_LN") ? atoi(getenv("RGM_FUSE_REDUCE_LN")) : 1;
@@ -368,14 +368,19 @@ int gemm2_launch(const GemmParams& p, hipStream_t s) {
   if (p.tile == 0 && g_t144 && p.batch == 1 && p.M < 2048 && gemm144_supports(p)) {
     const long long t144 = (long long)cdiv(p.M, 128) * (p.N / 144);
     const int KT = p.K >> 5;
-    if ((g_t144 & 8) && p.sk_ws && t144 <= 64 && KT >= 72 && p.act == 0 && !p.out_split) {
+    // bit 16 (round 6): the same for proj (36 K-tiles) when its reduce can write the second adaLN-LayerNorm of the block (ln_out) -- 64 tiles x 4
+    // slices of 9 K-tiles at B = 4 instead of 144 tiles of 128 x 64 on 256 CUs: forward-step 5.03 -> 4.96 ms same box.  Full rounds only: 192 tiles
+    // (B = 3: 48 x 4, B = 2: 32 x 6) measured level to behind (4.55 -> 4.66 ms at B = 3), profiles/r06_b4_proj_slices_ab.txt
+    const bool long_k = (g_t144 & 8) && KT >= 72, proj_k = (g_t144 & 16) && KT >= 36 && KT < 72 && p.ln_out && p.gate && p.res && !p.co_sched;
+    if ((long_k || proj_k) && p.sk_ws && t144 <= 64 && p.act == 0 && !p.out_split) {
       int best = 1;
+      const int min_kt = long_k ? 18 : 9;
       for (int c = 2; c <= 8; ++c) {
-        if (KT % c || KT / c < 18 || t144 * c > 256) continue;
+        if (KT % c || KT / c < min_kt || t144 * c > 256) continue;
         if ((size_t)c * p.M * p.N * sizeof(float) + GEMM_SK_FLAG_BYTES > p.sk_ws_bytes) continue;
         best = c;
       }
-      if (best > 1 && t144 * best >= 192) {
+      if (best > 1 && t144 * best >= (long_k ? 192 : 224)) {
         S = best;
         sk_tile = 81;
       }

@@ -35,9 +35,23 @@ for B in [int(a) for a in sys.argv[1:]] or [16]:
     print(f"B={B} RGM_T144={os.environ.get('RGM_T144', 'default')}: forward {np.median(ts):.3f} ms")
     R.check(R.lib.rgm_gemm144_dbg(1, None))
     m(x, t, y)
-    out = (C.c_longlong * 64)()
-    R.check(R.lib.rgm_gemm144_dbg(2, out))
+    allwg = bool(os.environ.get("ALLWG"))
+    out = (C.c_longlong * (64 + 8 * 4096 if allwg else 64))()
+    R.check(R.lib.rgm_gemm144_dbg(3 if allwg else 2, out))
     R.check(R.lib.rgm_gemm144_dbg(0, None))
+    if allwg:            # every workgroup of the launch: wall clock (s_memrealtime, 100 MHz) and shader cycles
+        w = np.array(out[64:], dtype=np.int64).reshape(4096, 8)
+        w = w[w[:, 3] > 0]
+        rt0 = w[:, 2].min()
+        start, end = (w[:, 2] - rt0) / 100.0, (w[:, 3] - rt0) / 100.0          # us
+        dur, cyc = end - start, (w[:, 1] - w[:, 0]).astype(float)
+        q = lambda v: " / ".join(f"{x:.1f}" for x in np.percentile(v, [0, 50, 90, 100]))
+        print(f"  {len(w)} workgroups; launch span {end.max():.1f} us; start min/med/p90/max {q(start)} us; end {q(end)} us; duration {q(dur)} us")
+        print(f"  shader clock over a workgroup's life (cycles / wall): {q(cyc / dur / 1e3)} GHz; K loop cycles {q(w[:, 4])}; epilogue cycles {q(w[:, 5])}; prologue {q(w[:, 6])}")
+        for x in range(8):
+            sel = (w[:, 7] & 7) == x
+            if sel.any():
+                print(f"    XCD {x}: {sel.sum():3d} workgroups, start {np.median(start[sel]):6.1f}, end med / max {np.median(end[sel]):6.1f} / {end[sel].max():6.1f} us, K loop med {np.median(w[sel, 4]):8.0f} cycles")
     for w in range(8):
         v = [out[w * 8 + i] for i in range(8)]
         kt = max(v[7], 1)
