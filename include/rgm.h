@@ -358,7 +358,9 @@ double rgm_prof_bytes(int kernel);
 /* per-launch records of the pre-split GEMM kernels in launch order (kernel id, milliseconds, algorithmic FLOPs); returns the count */
 int rgm_prof_dump(int cap, int* ids, double* ms, double* flops);
 int rgm_gemm2_dbg(int mode, long long* out64);
-/* the same for the 128x144 kernel (gemm144.hip, tools/g144_stamp.py): always built; 8 waves x 8 slots (cycles of the middle workgroup) */
+/* the same for the 128x144 kernel (gemm144.hip, tools/g144_stamp.py): always built; 8 waves x 8 slots (cycles of the middle workgroup).
+ * mode 1 arms, 2 copies the 64 slots out, 3 copies 64 + 8 x 4096 values (per workgroup of the stamped launch: entry / exit in shader cycles,
+ * entry / exit on the 100 MHz wall clock, K loop, epilogue, prologue cycles, raster id -- tools/g144_insitu_stamp.py ALLWG=1), 0 disarms */
 int rgm_gemm144_dbg(int mode, long long* out64);
 
 /* ------------------------------------------------------------------------------------------------
