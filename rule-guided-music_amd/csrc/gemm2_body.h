@@ -239,6 +239,9 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
   // DBG: per-wave s_memtime deltas summed over the K loop (segments: DMA wait, barrier, DMA issue, read0, mfma0, read1, mfma1)
   unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tp = 0;
   const bool rec = DBG && bid == rec_bid;
+#ifndef RGM_G2_DMA_EVERY2
+#define RGM_G2_DMA_EVERY2 0      // A/B builds: 1 = the wide tile's DMA pieces two MFMAs apart (as before round 6's last change)
+#endif
 #define RGM_STAMP(i)                                               \
   if (DBG) {                                                       \
     __builtin_amdgcn_sched_barrier(0);                             \
@@ -499,8 +502,12 @@ __device__ __forceinline__ void gemm2_body(const GemmParams& p, const char* __re
         } else if constexpr (AIM && m % EV == 1 && m / EV < APIECES) {
           aim_piece(std::integral_constant<int, m / EV>{}, aim);
         }
-        if constexpr (DMA && m % EV == 1 && m / EV < SPW) {
-          constexpr int i = m / EV;
+        // DMA pieces: one per DEV MFMA slots.  The wide wave tile (SBLO: 54 MFMAs a phase, 17 pieces, reads at the even slots) had them behind every
+        // second MFMA -- in situ a piece then cost the phase 34 cycles against 18 in the 256x256 tile, whose pieces sit three MFMAs apart
+        // (stamps: phase B 2305 cycles against a floor of 1728); three apart here too.
+        constexpr int DEV = (SBLO && SPW * 3 <= NM && !RGM_G2_DMA_EVERY2) ? 3 : EV;
+        if constexpr (DMA && m % DEV == 1 && m / DEV < SPW) {
+          constexpr int i = m / DEV;
           dma16(src[i], dst + (wave + i * NW) * 1024);
           src[i] += inc[i];
         }
