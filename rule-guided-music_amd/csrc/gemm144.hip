@@ -104,10 +104,16 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
         if (tiles == decltype(c)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(c)::value * LSEG) : "memory");
       });
     };
+    // (Prologue, stamped in the C2 forward: ~4 k cycles until the addresses are set up -- kernel arguments and code arrive cold --, ~2.5 k for
+    // the first tile's nine pieces to be issued and land, ~1 k more for the next two.  Releasing the consumers as soon as tile 0 is in, the other
+    // two tiles issued behind barrier P, moved the barrier from ~8.9 k to ~7.9 k cycles and the C2 step by nothing: 11.50 / 11.48 ms over three
+    // alternating pairs, B = 4 4.84 -> 4.86; removed.)
+    if (DBG) tacc[3] = now() - t_entry;                 // prologue split: addresses set up ...
     static_for<0, NSTAGE - 1>([&](auto c) {
       if (decltype(c)::value < KT) issue_tile(ring + decltype(c)::value * STAGE);
     });
     wait_flying(min(NSTAGE - 2, KT - 1));
+    if (DBG) tacc[6] = now() - t_entry;                 // ... the first tiles issued, tile 0 landed
     __builtin_amdgcn_s_barrier();                       // barrier P: tile 0 is in LDS
     int s2 = NSTAGE - 1;
     unsigned long long t0 = 0;
@@ -246,7 +252,9 @@ __global__ __launch_bounds__(512) void gemm144_kernel(GemmParams p, const char* 
   using I2 = std::integral_constant<int, 2>;
   static_assert(2 * TM + TN <= NT && TN <= NT, "the next tile's reads fit between the MFMAs of terms 1 and 2");
   Half h0, h1, lo;
+  if (DBG) tacc[4] = now() - t_entry;                   // prologue split: set-up and first prefetches done ...
   __builtin_amdgcn_s_barrier();                         // barrier P (loaders: tile 0 landed)
+  if (DBG) tacc[5] = now() - t_entry;                   // ... barrier P passed (then: tile 0's 22 fragments)
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     rd(h0.a[i], ring, ar + i * 16, 0);

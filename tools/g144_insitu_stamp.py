@@ -56,6 +56,6 @@ for B in [int(a) for a in sys.argv[1:]] or [16]:
         v = [out[w * 8 + i] for i in range(8)]
         kt = max(v[7], 1)
         if w < 4:
-            print(f"  consumer {w}: prologue {v[2]:6d}  K loop {v[1]:7d} = {v[1] / kt:6.0f} / K-tile x {kt} (barrier wait {v[0] / kt:5.0f})  epilogue {v[3]:6d}")
+            print(f"  consumer {w}: prologue {v[2]:6d} (set-up {v[4]}, barrier P passed at {v[5]})  K loop {v[1]:7d} = {v[1] / kt:6.0f} / K-tile x {kt} (barrier wait {v[0] / kt:5.0f})  epilogue {v[3]:6d}")
         else:
-            print(f"  loader   {w}: prologue {v[2]:6d}  K loop {v[1]:7d} = {v[1] / kt:6.0f} / K-tile (issue {v[4] / kt:5.0f}, landing {v[5] / kt:5.0f}, barrier {v[0] / kt:5.0f})")
+            print(f"  loader   {w}: prologue {v[2]:6d} (addresses set up at {v[3]}, first tile(s) issued and tile 0 landed at {v[6]})  K loop {v[1]:7d} = {v[1] / kt:6.0f} / K-tile (issue {v[4] / kt:5.0f}, landing {v[5] / kt:5.0f}, barrier {v[0] / kt:5.0f})")
