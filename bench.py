@@ -502,12 +502,21 @@ def uint8_flip_record(device):
             "mismatches_with_decode_in_loop_arithmetic": int((u8_loop != g["u8"]).sum())}
 
 
+def eps_networks(work):
+    from guided_diffusion.dit import DiTRotary
+    return [v for v in vars(work).values() if isinstance(v, DiTRotary)]
+
+
 def time_steps(work, steps, world, dist):
-    """One timed region of exactly `steps` steps: barrier + synchronise on both sides, MAX over ranks."""
+    """One timed region of exactly `steps` steps: barrier + synchronise on both sides, MAX over ranks.  Conditioning rows computed ahead
+    (guided_diffusion/dit.py cond_hint: one pass over the adaLN weights serves the next 32 (t, y) rows of the schedule) are dropped first:
+    every pass the region's steps need is paid INSIDE the region (at K = 20 one pass per region, where a 50-step chain pays two)."""
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+    for m in eps_networks(work):
+        m._ahead = None
     fence()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -680,7 +689,10 @@ def main():
             work.step()
         torch.cuda.synchronize()
         return
+    for m in eps_networks(work):
+        m.ahead_passes = 0
     regions = [time_steps(work, args.steps, world, dist) for _ in range(max(1, args.repeats))]
+    ahead_passes = sum(getattr(m, "ahead_passes", 0) for m in eps_networks(work))
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     dt, gpu_ms = regions[order[len(order) // 2]]
     try:                                                         # every rank runs it (SCG steps hold a collective)
@@ -767,6 +779,10 @@ def main():
                        "timing": f"median of {len(regions)} timed regions of {args.steps} steps",
                        "repeats_ms_per_step": [round(1e3 * r[0] / args.steps, 3) for r in regions],
                        "gpu_ms_per_step_events": round(gpu_ms / args.steps, 3),
+                       # adaLN conditioning ahead of the step (guided_diffusion/dit.py): rows per pass over the adaLN weights (0 = every forward
+                       # streams them itself) and the passes the timed regions paid -- each region starts without rows
+                       "cond_ahead": {"rows_per_pass": __import__("guided_diffusion.dit", fromlist=["COND_AHEAD"]).COND_AHEAD,
+                                      "weight_passes_in_timed_regions": ahead_passes, "timed_steps": args.steps * len(regions)},
                        # whole-step FLOPs over ONE simulated rank's time would read as several times the chip's peak: no figure there
                        "algorithmic_tflops": None if args.simulate_ranks > 1 else round(work.flop_per_step * units / dt / 1e12, 2)},
         }

@@ -67,6 +67,14 @@ size_t rgm_dit_workspace_bytes(const rgm_dit* h, int N, int H);
  * y (N) int32 row of the label table or NULL; eps (N,out_ch,H,width). */
 int rgm_dit_forward(rgm_dit* h, const float* x, const int64_t* t, const int32_t* y, float* eps,
                     int N, int H, void* ws, size_t ws_bytes, void* stream);
+/* The adaLN modulation of U (t, y) pairs: rows[U][(6 depth + 2) hidden] = adaLN_modulation(SiLU(t_embedder(t) + y_embedder(y))) of every
+ * block and the final layer (dit.py:621-628, :333, :374) -- exactly what rgm_dit_forward computes for a sample with that timestep and label,
+ * row by row (a row's arithmetic does not depend on the batch it sits in).  One pass over the adaLN weights (0.9 GB for XL) per 32 pairs.
+ * A sampler that knows its schedule (gaussian_diffusion.py:833-880: the loop visits fixed timesteps) asks for the next steps' rows at once
+ * and passes them to rgm_dit_forward_cond: sample i takes rows[idx[i]] (idx: device int32, 0 <= idx[i] < U).  ws as for N = U rows. */
+int rgm_dit_cond_rows(rgm_dit* h, const int64_t* t, const int32_t* y, int U, int H, float* rows, void* ws, size_t ws_bytes, void* stream);
+int rgm_dit_forward_cond(rgm_dit* h, const float* x, const float* rows, const int32_t* idx, int U, float* eps,
+                         int N, int H, void* ws, size_t ws_bytes, void* stream);
 /* DiTRotaryClassifier.forward dit.py:803-831.  logits (N,n_out) [kind 1]  or  key (N,25) + chord
  * (N,H/width,n_out) [kind 2; key_out may be NULL]. */
 int rgm_dit_classify(rgm_dit* h, const float* x, const int64_t* t, float* logits, float* key_out,

@@ -455,7 +455,31 @@ int cond_mod(const float* cs, const float* W, const float* bias, float* mod, int
 }
 
 // embedders + blocks; leaves the residual stream in plan.x and SiLU(c) modulation in plan.mod
-int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, const int32_t* y, hipStream_t s) {
+// mod[i][:] = rows[idx[i]][:]  (conditioning rows computed ahead, rgm_dit_cond_rows; idx clamped to the table)
+__global__ void gather_cond_rows_kernel(const float* __restrict__ rows, const int32_t* __restrict__ idx, float* __restrict__ mod, int L4, int U) {
+  const int i = blockIdx.y;
+  int u = idx[i];
+  u = u < 0 ? 0 : (u >= U ? U - 1 : u);
+  const float4* src = reinterpret_cast<const float4*>(rows) + (size_t)u * L4;
+  float4* dst = reinterpret_cast<float4*>(mod) + (size_t)i * L4;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < L4; j += gridDim.x * blockDim.x) dst[j] = src[j];
+}
+
+// SiLU(t_embedder(t) + y_embedder(y)) for p.N rows -> p.cs  (dit.py:621-628)
+static int cond_vector(rgm_dit* h, const Plan& p, const int64_t* t, const int32_t* y, hipStream_t s) {
+  const rgm_dit_cfg& c = h->cfg;
+  const int D = c.hidden;
+  RGM_TRY(timestep_sincos_launch(t, h->tfreqs, p.temb, p.N, 128, s));
+  RGM_TRY(lin(p.temb, 256, h->p("t_embedder.mlp.0.weight"), h->p("t_embedder.mlp.0.bias"), p.c1, D, p.N, D, 256, 1, s));
+  RGM_TRY(lin(p.c1, D, h->p("t_embedder.mlp.2.weight"), h->p("t_embedder.mlp.2.bias"), p.c, D, p.N, D, D, 0, s));
+  const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
+  return cond_finish_launch(p.c, ytab, y, p.cs, p.N, D, s);
+}
+
+// cond_rows / cond_idx (optional, eps-network): the adaLN modulation of every sample is row cond_idx[i] of a table computed ahead
+// (rgm_dit_cond_rows) instead of a pass over the 0.9 GB of adaLN weights in this forward
+int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, const int32_t* y, hipStream_t s,
+                 const float* cond_rows = nullptr, const int32_t* cond_idx = nullptr, int cond_U = 0) {
   const rgm_dit_cfg& c = h->cfg;
   const int D = c.hidden, pc = c.in_ch * c.patch, T = p.T, L = (int)p.L;
   RGM_TRY(patchify_launch(x, p.tok_in, p.N, c.in_ch, p.H, c.width, c.patch, s));
@@ -472,16 +496,15 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
     RGM_TRY(gemm_launch(g, s));
     RGM_TRY(fill_cls_launch(h->p("cls_token"), p.x, p.N, T, D, s));
   }
-  RGM_TRY(timestep_sincos_launch(t, h->tfreqs, p.temb, p.N, 128, s));
-  RGM_TRY(lin(p.temb, 256, h->p("t_embedder.mlp.0.weight"), h->p("t_embedder.mlp.0.bias"), p.c1, D, p.N, D, 256, 1, s));
-  RGM_TRY(lin(p.c1, D, h->p("t_embedder.mlp.2.weight"), h->p("t_embedder.mlp.2.bias"), p.c, D, p.N, D, D, 0, s));
-  const float* ytab = (c.kind == 0 && c.n_embed > 0 && y) ? h->p("y_embedder.embedding_table.weight") : nullptr;
-  RGM_TRY(cond_finish_launch(p.c, ytab, y, p.cs, p.N, D, s));
+  if (!cond_rows) RGM_TRY(cond_vector(h, p, t, y, s));
   // adaLN conditioning of the whole forward: mod[N, L] = cs . W_ada^T + b (all blocks' projections are contiguous in the arena).  Block 0
   // needs only its own 6 D columns up front; the other 0.9 GB of weights stream on the handle's side stream while block 0 computes
   // (the matrix pipes are the limit there and HBM idles) and are joined back before block 0's fc2, whose reduce writes block 1's LayerNorm.
   bool joined = true;
-  if (g_adaln_overlap && c.depth > 1 && L > 6 * D) {
+  if (cond_rows) {
+    hipLaunchKernelGGL(gather_cond_rows_kernel, dim3(8, (unsigned)p.N), dim3(256), 0, s, cond_rows, cond_idx, p.mod, L / 4, cond_U);
+    RGM_LAUNCH_CHECK();
+  } else if (g_adaln_overlap && c.depth > 1 && L > 6 * D) {
     if (!h->side) {
       RGM_CHECK_HIP(hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
       RGM_CHECK_HIP(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
@@ -668,6 +691,8 @@ extern "C" size_t rgm_dit_workspace_bytes(const rgm_dit* h, int N, int H) {
   return make_plan(h, N, H, nullptr, 0).bytes;
 }
 
+static int forward_tail(rgm_dit* h, const Plan& p, float* eps, int N, int H, hipStream_t s);
+
 extern "C" int rgm_dit_forward(rgm_dit* h, const float* x, const int64_t* t, const int32_t* y, float* eps, int N, int H,
                                void* ws, size_t ws_bytes, void* stream) {
   RGM_REQUIRE(h && h->cfg.kind == 0, "dit_forward: handle is not an eps-network");
@@ -675,9 +700,39 @@ extern "C" int rgm_dit_forward(rgm_dit* h, const float* x, const int64_t* t, con
   Plan p;
   RGM_TRY(check_ready(h, N, H, ws_bytes, ws, &p));
   hipStream_t s = (hipStream_t)stream;
+  RGM_TRY(run_backbone(h, p, x, t, y, s));
+  return forward_tail(h, p, eps, N, H, s);
+}
+
+// The adaLN modulation of U (t, y) pairs -- rows[U][(6 depth + 2) hidden], what rgm_dit_forward computes for a sample with that timestep and
+// label -- in one pass over the adaLN weights per 32 pairs (adaln_stream.hip).  A sampler that knows its schedule asks for the next steps'
+// rows at once and hands them to rgm_dit_forward_cond: the 0.9 GB of weights are then read once per group of steps, not once per step.
+extern "C" int rgm_dit_cond_rows(rgm_dit* h, const int64_t* t, const int32_t* y, int U, int H, float* rows, void* ws, size_t ws_bytes,
+                                 void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind == 0, "dit_cond_rows: handle is not an eps-network");
+  RGM_REQUIRE(t && rows && ((uintptr_t)rows & 15) == 0, "dit_cond_rows: null or unaligned tensor");
+  Plan p;
+  RGM_TRY(check_ready(h, U, H, ws_bytes, ws, &p));
+  hipStream_t s = (hipStream_t)stream;
+  RGM_TRY(cond_vector(h, p, t, y, s));
+  return cond_mod(p.cs, h->p("blocks.0.adaLN_modulation.1.weight"), h->p("blocks.0.adaLN_modulation.1.bias"), rows, U, h->cfg.hidden, (int)p.L, s);
+}
+
+// rgm_dit_forward with the conditioning of sample i taken from rows[idx[i]] (rgm_dit_cond_rows; idx on the device, 0 <= idx[i] < U)
+extern "C" int rgm_dit_forward_cond(rgm_dit* h, const float* x, const float* rows, const int32_t* idx, int U, float* eps, int N, int H,
+                                    void* ws, size_t ws_bytes, void* stream) {
+  RGM_REQUIRE(h && h->cfg.kind == 0, "dit_forward_cond: handle is not an eps-network");
+  RGM_REQUIRE(x && rows && idx && eps && U > 0 && ((uintptr_t)rows & 15) == 0, "dit_forward_cond: null or unaligned tensor");
+  Plan p;
+  RGM_TRY(check_ready(h, N, H, ws_bytes, ws, &p));
+  hipStream_t s = (hipStream_t)stream;
+  RGM_TRY(run_backbone(h, p, x, nullptr, nullptr, s, rows, idx, U));
+  return forward_tail(h, p, eps, N, H, s);
+}
+
+static int forward_tail(rgm_dit* h, const Plan& p, float* eps, int N, int H, hipStream_t s) {
   const rgm_dit_cfg& c = h->cfg;
   const int D = c.hidden, L = (int)p.L;
-  RGM_TRY(run_backbone(h, p, x, t, y, s));
   const float* m = p.mod + (size_t)c.depth * 6 * D;
   RGM_TRY(layernorm_modulate_launch(p.x, p.xm, p.M, D, 1e-6f, nullptr, nullptr, m, m + D, L, p.T, s));
   const int po = c.patch * c.out_ch;

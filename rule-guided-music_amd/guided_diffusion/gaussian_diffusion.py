@@ -36,6 +36,7 @@ import torch as th
 
 from rgm import native as _rgm
 from rgm import batch_shard, scg_shard
+from . import dit as _dit
 from music_rule_guidance.rule_maps import FUNC_DICT, LOSS_DICT
 
 
@@ -165,6 +166,7 @@ class GaussianDiffusion:
         self._rows = None             # (b0, nb, B) while a rank computes its rows of a batch-sharded step
         self._tables = {}
         self._t_host = None
+        self._ahead_of = None
         self._grad_streams = {}       # device -> side stream of the guidance gradient of a search step (_search_step_inputs)
 
     # ------------------------------------------------------------------ helpers
@@ -306,7 +308,7 @@ class GaussianDiffusion:
                 with th.cuda.stream(side):
                     grad = the_grad()
             if want_eps:
-                eps = self._model_eps(xr, self._wrap_model(model)(xr, self._scale_timesteps(tr), **kw), tr, denoised_fn)
+                eps = self._model_eps(xr, self._eps_net(self._wrap_model(model), xr, tr, **kw), tr, denoised_fn)
                 if ekw is not None:
                     eps = self._edit_eps(xr, eps, tr, clip_denoised, ekw, denoised_fn)
             if side is not None:
@@ -352,6 +354,20 @@ class GaussianDiffusion:
         if self._t_host is not None:
             return self._t_host
         return int(t[0].item())
+
+    def _eps_net(self, model, x, t, **kw):
+        """model(x, t, **kw) for the eps-network inside a loop step.  The loop (or a caller that steps by hand) set `_t_host`: every sample
+        is at chain index _t_host, and the chain visits _t_host - 1, - 2, ... next -- which lets a DiTRotary take its adaLN modulation from
+        rows computed for several steps in one pass over those weights (dit.cond_hint; same values as the per-forward pass)."""
+        i = self._t_host
+        if i is None or self.rescale_timesteps or _dit.COND_AHEAD <= 0:
+            return model(x, self._scale_timesteps(t), **kw)
+        if self._ahead_of is None or self._ahead_of[0] != i:
+            tm = getattr(self, "timestep_map", None)
+            self._ahead_of = (i, [int(tm[j]) if tm is not None else j for j in range(i, max(i - 64, -1), -1)])
+        up = self._ahead_of[1]
+        with _dit.cond_hint((up[0], up)):
+            return model(x, self._scale_timesteps(t), **kw)
 
     def _per_sample(self, arr, t, like):
         """_extract_into_tensor as a broadcast VIEW (no elementwise kernel)."""
@@ -516,7 +532,7 @@ class GaussianDiffusion:
         self._reject_unsupported(denoised_fn, edit_kwargs)
         model_kwargs = model_kwargs or {}
         assert t.shape == (x.shape[0],)
-        eps = self._model_eps(x, model(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
+        eps = self._model_eps(x, self._eps_net(model, x, t, **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
         mean, x0, _ = self._step("ddpm", x, eps, None, None, t, clip_denoised)
@@ -666,7 +682,7 @@ class GaussianDiffusion:
                 _rgm.check(_rgm.lib.rgm_scg_candidates(_rgm.ptr(mean_pred), _rgm.ptr(g), _rgm.ptr(noise), _rgm.ptr(cand),
                                                        nl, B, E, _rgm.current_stream()))
         t_rep = t.repeat(nl)
-        eps = model(cand, self._scale_timesteps(t_rep), y=model_kwargs["y"].repeat(nl))
+        eps = self._eps_net(model, cand, t_rep, y=model_kwargs["y"].repeat(nl))
         if self._learned() and eps.shape[1] == 2 * cand.shape[1]:
             # learn_sigma=True network: the eps half of its 2C channels, split like p_mean_variance does (:299-301).  The reference's
             # scg_sample does not split and dies in _predict_xstart_from_eps' shape assert (tests/golden round3 'reference_raises');
@@ -743,7 +759,7 @@ class GaussianDiffusion:
                     return x0.view((nl, B) + tuple(x0.shape[1:]))[max_ind, th.arange(B, device=dev)].clone()
                 # the winner may have been scored on another rank: its decoded x0 estimate is recomputed from the rebuilt winner
                 # (one B-row forward + decode, only on the steps that keep a roll)
-                e = model(out, self._scale_timesteps(t), y=model_kwargs["y"])
+                e = self._eps_net(model, out, t, y=model_kwargs["y"])
                 if self._learned() and e.shape[1] == 2 * out.shape[1]:
                     e = e[:, :out.shape[1]].contiguous()
                 xw = self._predict_xstart_from_eps(out, t, e)
@@ -875,7 +891,7 @@ class GaussianDiffusion:
             side.wait_stream(main)
             with th.cuda.stream(side):
                 grad = the_grad()
-        eps = self._model_eps(x, self._wrap_model(model)(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
+        eps = self._model_eps(x, self._eps_net(self._wrap_model(model), x, t, **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
         if side is not None:
@@ -942,7 +958,7 @@ class GaussianDiffusion:
                                      scg_kwargs=scg_kwargs, edit_kwargs=edit_kwargs,
                                      dc_kwargs=getattr(guidance_kwargs, "dc", None), record=record, record_freq=10)
             return {"sample": sample, "pred_xstart": x0}
-        eps = self._model_eps(x, wrapped(x, self._scale_timesteps(t), **model_kwargs), t, denoised_fn)
+        eps = self._model_eps(x, self._eps_net(wrapped, x, t, **model_kwargs), t, denoised_fn)
         if edit_kwargs is not None:
             eps = self._edit_eps(x, eps, t, clip_denoised, edit_kwargs, denoised_fn)
         grad = None

@@ -30,6 +30,8 @@ def _load():
         "rgm_dit_missing_params": (C.c_int, [vp]),
         "rgm_dit_workspace_bytes": (sz, [vp, i32, i32]),
         "rgm_dit_forward": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
+        "rgm_dit_cond_rows": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, sz, vp]),
+        "rgm_dit_forward_cond": (C.c_int, [vp, vp, vp, vp, i32, vp, i32, i32, vp, sz, vp]),
         "rgm_dit_classify": (C.c_int, [vp, vp, vp, vp, vp, i32, i32, vp, sz, vp]),
         "rgm_gemm": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, f32, vp, i32, i32, vp, i32, vp]),
         "rgm_gemm_tile": (C.c_int, [vp, i32, vp, i32, vp, i32, i32, i32, i32, vp, i32, i32, vp]),

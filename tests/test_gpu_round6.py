@@ -215,3 +215,66 @@ def test_cli_with_a_chord_analyser_runs_the_reference_config_whole(tmp_path, mon
     for r in ("pitch_hist", "note_density", "chord_progression"):
         assert {f"{r}.target_rule", f"{r}.gen_rule", f"{r}.loss"} <= set(df.columns), df.columns
         assert np.isfinite(df[f"{r}.loss"]).all()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3", "bf16x3_presplit"])
+def test_conditioning_computed_ahead_is_the_same_forward(precision, monkeypatch):
+    """guided_diffusion/dit.py cond_hint / rgm_dit_cond_rows / rgm_dit_forward_cond: the adaLN modulation of a sample is a function of (t, y)
+    (ref dit.py:621-628, :333, :374), and a loop knows the timesteps it will visit -- the rows of the next steps, for every label of the table,
+    come from ONE pass over the adaLN weights and the forwards gather theirs.  Must be the same numbers, bit for bit: (a) a single forward with
+    and without the hint, (b) a whole DDIM-8 chain with labels and a DDPM chain without, RGM_COND_AHEAD on and off, (c) the weight pass really
+    runs once per group of steps, and parameters loaded later invalidate the rows."""
+    from gpu_util import dev
+    from guided_diffusion import dit as dit_mod
+    from guided_diffusion.gaussian_diffusion import PhiloxNoise
+    from rgm import native as R
+    R.set_gemm_precision(precision)
+    try:
+        m = _dit(SM, 11, final_std=0.05)
+        rng = np.random.RandomState(3)
+        x = dev(rng.randn(5, 4, 128, 16).astype(F32))
+        y = dev(np.array([0, 2, 1, 3, 0], dtype=np.int64))
+        t = torch.full((5,), 620, dtype=torch.int64, device="cuda")
+        monkeypatch.setattr(dit_mod, "COND_AHEAD", 32)
+        plain = m(x, t, y).clone()
+        with dit_mod.cond_hint((620, [620, 600, 580])):
+            ahead = m(x, t, y).clone()
+            ahead_nolabel = m(x, t, None).clone()
+        assert torch.equal(plain, ahead)
+        assert torch.equal(m(x, t, None), ahead_nolabel)
+        # rows of explicit (t, y) pairs == the rows a forward uses: sample 1 above is (620, label 2)
+        rows = m.cond_rows([620, 600], [2, 2], 128)
+        assert rows.shape == (2, (6 * SM["depth"] + 2) * SM["hidden"]) and bool(torch.isfinite(rows).all())
+
+        calls = []
+        real = dit_mod.DiTRotary.cond_rows
+        monkeypatch.setattr(dit_mod.DiTRotary, "cond_rows", lambda self, ts, ys, H: (calls.append(len(ts)), real(self, ts, ys, H))[1])
+
+        def chain(on, labels):
+            monkeypatch.setattr(dit_mod, "COND_AHEAD", 32 if on else 0)
+            d = _diffusion("ddim8" if labels else "8")
+            d.noise = PhiloxNoise(seed=5)
+            kw = {"y": y[:3]} if labels else {}
+            fn = _model_fn(m) if labels else (lambda xx, tt, **k: m(xx, tt, None))
+            loop = d.ddim_sample_loop if labels else d.p_sample_loop
+            return loop(fn, (3, 4, 128, 16), noise=x[:3].clone(), clip_denoised=False, model_kwargs=kw, device="cuda", progress=False).clone()
+
+        for labels in (True, False):
+            calls.clear()
+            a = chain(True, labels)
+            n_on = list(calls)
+            b = chain(False, labels)
+            assert torch.equal(a, b), (labels, float((a - b).abs().max()))
+            # 8 steps: with labels 4 rows per step -> 8 steps fit one pass of 32 rows; without labels 1 row per step
+            assert n_on == ([32] if labels else [8]), n_on
+            assert len(calls) == len(n_on)                      # (the chain with the switch off never asks for rows)
+        # new parameters: the rows computed ahead belong to the old ones
+        monkeypatch.setattr(dit_mod, "COND_AHEAD", 32)
+        m2 = _dit(SM, 12, final_std=0.05)
+        with dit_mod.cond_hint((620, [620, 600])):
+            before = m(x, t, y).clone()
+            m.load_state_dict(m2.state_dict())
+            after = m(x, t, y).clone()
+        assert torch.equal(after, m2(x, t, y)) and not torch.equal(before, after)
+    finally:
+        R.set_gemm_precision("fp32")
