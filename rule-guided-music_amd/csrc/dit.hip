@@ -502,7 +502,7 @@ int run_backbone(rgm_dit* h, const Plan& p, const float* x, const int64_t* t, co
   // (the matrix pipes are the limit there and HBM idles) and are joined back before block 0's fc2, whose reduce writes block 1's LayerNorm.
   bool joined = true;
   if (cond_rows) {
-    hipLaunchKernelGGL(gather_cond_rows_kernel, dim3(8, (unsigned)p.N), dim3(256), 0, s, cond_rows, cond_idx, p.mod, L / 4, cond_U);
+    hipLaunchKernelGGL(gather_cond_rows_kernel, dim3(48, (unsigned)p.N), dim3(256), 0, s, cond_rows, cond_idx, p.mod, L / 4, cond_U);   // (L / 4 = 48 960 float4 for XL: 4 per thread)
     RGM_LAUNCH_CHECK();
   } else if (g_adaln_overlap && c.depth > 1 && L > 6 * D) {
     if (!h->side) {
