@@ -703,3 +703,50 @@ def test_previous_x_search_steps_stay_replicated_two_ranks_gloo():
         for name in ("eps", "x0"):
             assert r[name][0] == ((rank * 2, 2), None) and r[name][1] == ((rank * 2, 2), None) and r[name][2] == (None, None)
         assert r["prev"] == ((None, None),) * 3
+
+
+def test_conditioning_hint_follows_the_chain_the_loop_walks(monkeypatch):
+    """GaussianDiffusion._eps_net (host logic of the conditioning computed ahead, guided_diffusion/dit.py cond_hint): inside a loop step -- `_t_host`
+    set -- the eps-network sees (its own timestep now, the timesteps the chain visits next, in order) through the re-spacing map
+    (ref respace.py:7-128, gaussian_diffusion.py:833-880); no hint when the caller steps by hand, when timesteps are rescaled to floats, or with
+    the switch off.  The model's arguments are untouched either way."""
+    from guided_diffusion import dit as dit_mod
+    from guided_diffusion.script_util import create_diffusion
+    seen = []
+
+    def model(x, t, **kw):
+        seen.append((dit_mod._HINT, t.clone(), dict(kw)))
+        return x
+
+    def diffusion(rs, rescale=False):
+        return create_diffusion(learn_sigma=False, diffusion_steps=1000, noise_schedule="linear", timestep_respacing=rs, use_kl=False,
+                                predict_xstart=False, rescale_timesteps=rescale, rescale_learned_sigmas=False)
+    monkeypatch.setattr(dit_mod, "COND_AHEAD", 32)
+    d = diffusion("ddim50")
+    x, t = torch.zeros(2, 1), torch.full((2,), 7, dtype=torch.int64)
+    d._eps_net(d._wrap_model(model), x, t, y=torch.tensor([1, 2]))
+    assert seen[-1][0] is None                                        # stepping by hand: no hint
+    d._t_host = 7
+    d._eps_net(d._wrap_model(model), x, t, y=torch.tensor([1, 2]))
+    hint, t_seen, kw = seen[-1]
+    tm = list(d.timestep_map)
+    assert hint == (tm[7], [tm[j] for j in range(7, -1, -1)])         # 140, [140, 120, ..., 0]
+    assert t_seen.tolist() == [tm[7]] * 2 and kw["y"].tolist() == [1, 2]
+    assert dit_mod._HINT is None                                      # (the hint does not outlive the call)
+    d._t_host = 49
+    d._eps_net(d._wrap_model(model), x, torch.full((2,), 49, dtype=torch.int64))
+    assert seen[-1][0][0] == tm[49] and len(seen[-1][0][1]) == 50 and seen[-1][0][1][:3] == [tm[49], tm[48], tm[47]]
+    # the full chain: identity map, at most 64 timesteps named
+    full = diffusion("")
+    full._t_host = 999
+    full._eps_net(full._wrap_model(model), x, torch.full((2,), 999, dtype=torch.int64))
+    assert seen[-1][0] == (999, list(range(999, 935, -1)))
+    # fractional timesteps / the switch off: the plain call
+    resc = diffusion("ddim50", rescale=True)
+    resc._t_host = 7
+    resc._eps_net(resc._wrap_model(model), x, t)
+    assert seen[-1][0] is None
+    monkeypatch.setattr(dit_mod, "COND_AHEAD", 0)
+    d._t_host = 7
+    d._eps_net(d._wrap_model(model), x, t)
+    assert seen[-1][0] is None
