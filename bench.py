@@ -14,6 +14,10 @@ one ddim_sample call over that batch (eps-network forward + fused step update + 
 then three timed regions of exactly K steps each, each bracketed by barrier + device synchronise, MAX over ranks per
 region; `value` / `ms_per_step` are the MEDIAN region (all three are listed in config.repeats_ms_per_step).  For N > 1 every
 rank runs its own batch-16 chain (the path shards over samples; no data-path collective): scaling = weak.
+Nothing of a step is skipped or carried over: the one thing the sampler computes for several steps at once -- the adaLN modulation rows of
+the schedule's next timesteps, one pass over those weights per 32 rows (guided_diffusion/dit.py cond_hint; bit-identical chains) -- is
+dropped at the start of every timed region, so each region pays the passes its K steps need (config.cond_ahead counts them;
+RGM_COND_AHEAD=0 runs the pass in every forward).
 
 One JSON line on stdout (rank 0) per the driver contract, plus
   roofline     : the dominant kernel of the headline run (pre-split bf16x3 GEMM) -- algorithmic 2MNK FLOPs of its launches
